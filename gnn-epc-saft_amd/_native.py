@@ -1,0 +1,97 @@
+"""ctypes binding of ``lib/libgnnsaft.so`` (C ABI declared in ``include/gnnsaft.h``).
+
+There is deliberately NO fallback: if the shared library is missing or a symbol
+cannot be resolved, importing this module raises.  The library is built
+in-tree by ``__graft_entry__.build()`` / ``make -C gnn-epc-saft_amd/csrc``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgnnsaft.so")
+
+MAX_TABLES = 16
+
+
+class ModelDesc(ctypes.Structure):
+    """``gnnsaft_model_desc`` (include/gnnsaft.h)."""
+
+    _fields_ = [
+        ("hidden", c_int32), ("num_layers", c_int32), ("pre_layers", c_int32), ("post_layers", c_int32),
+        ("num_mlp_layers", c_int32), ("num_para", c_int32), ("skip_connections", c_int32),
+        ("self_loops", c_int32), ("training", c_int32), ("num_atom_cols", c_int32), ("num_bond_cols", c_int32),
+        ("atom_dims", c_int32 * MAX_TABLES), ("bond_dims", c_int32 * MAX_TABLES),
+        ("bn_eps", c_float), ("bn_momentum", c_float),
+    ]
+
+
+class WorkspaceMap(ctypes.Structure):
+    """``gnnsaft_workspace_map`` (include/gnnsaft.h)."""
+
+    _fields_ = [(n, c_size_t) for n in (
+        "rowptr", "src", "dst", "combo", "log_amp", "log_att", "graph_ptr", "x_embed", "x_final", "pq", "agg", "u",
+        "y", "rtab", "pooled", "total")]
+
+
+P = c_void_p
+# name -> (restype, argtypes); one entry per symbol include/gnnsaft.h declares
+SIGNATURES = {
+    "gnnsaft_abi_version": (c_int32, []),
+    "gnnsaft_error_string": (c_char_p, [c_int32]),
+    "gnnsaft_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "gnnsaft_csr_build": (c_int32, [P, P, c_int64, c_int64, c_int32, POINTER(c_int32), c_int32, P, P, P, P, P, P, P, P,
+                                    c_size_t, P]),
+    "gnnsaft_batch_to_ptr": (c_int32, [P, c_int64, c_int64, P, P, P]),
+    "gnnsaft_embed_sum": (c_int32, [P, c_int64, c_int32, POINTER(c_void_p), POINTER(c_int32), c_int32, P, P, P]),
+    "gnnsaft_bond_combo_embed": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_int32), c_int32, P, P]),
+    "gnnsaft_linear": (c_int32, [P, c_int64, c_int32, P, c_int64, P, P, c_int64, c_int64, c_int32, c_int32, P, P,
+                                 c_int32, P, c_int64, P, P]),
+    "gnnsaft_bn_rows_per_group": (c_int32, []),
+    "gnnsaft_pna_node_terms": (c_int32, [P, c_int64, c_int32, P, P, P, P]),
+    "gnnsaft_pna_edge_table": (c_int32, [P, c_int32, c_int32, P, P, P, P, P, P, P, P, P]),
+    "gnnsaft_pna_edge_mlp": (c_int32, [P, P, P, c_int64, c_int32, P, P, P, P, P, P, P, P]),
+    "gnnsaft_pna_aggregate": (c_int32, [P, P, P, c_int64, c_int32, P, P, P, P, P]),
+    "gnnsaft_pna_update": (c_int32, [P, P, P, P, P, c_int64, c_int32, P, P, P, P, P, P]),
+    "gnnsaft_bn_finalize": (c_int32, [P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, c_int32, P, P, P]),
+    "gnnsaft_bn_relu_residual": (c_int32, [P, P, P, P, P, c_int64, c_int32, P]),
+    "gnnsaft_add_pool": (c_int32, [P, P, c_int64, c_int64, c_int32, P, P]),
+    "gnnsaft_mape": (c_int32, [P, P, c_int64, P, P]),
+    "gnnsaft_num_weights": (c_int32, [POINTER(ModelDesc)]),
+    "gnnsaft_forward_workspace_bytes": (c_size_t, [POINTER(ModelDesc), c_int64, c_int64, c_int64]),
+    "gnnsaft_forward_workspace_map": (c_int32, [POINTER(ModelDesc), c_int64, c_int64, c_int64, POINTER(WorkspaceMap)]),
+    "gnnsaft_forward": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), c_int32, P, P, P, P, c_int64, c_int64,
+                                  c_int64, P, P, P, P, P, c_size_t, P]),
+}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the MI355X library has not been built. Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C gnn-epc-saft_amd/csrc`). "
+            f"This package has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gnnsaft_abi_version() != 1:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.gnnsaft_abi_version()} != 1; rebuild the library")
+    return lib
+
+
+lib = _load()
+
+
+class GnnsaftError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib.gnnsaft_error_string(code)
+        raise GnnsaftError(f"{what} failed: {msg.decode() if msg else code} (code {code})")

@@ -1,0 +1,144 @@
+// K4 -- PNA multi-aggregator segmented reduction (the "scatter-add" kernel of
+// BASELINE.json): mean | min | max | std over the in-edges of every node, PyG
+// MultiAggregation([mean,min,max,std]) as configured at
+// /root/reference/gnnepcsaft/train/models.py:59,69-80 (semantics: SURVEY.md
+// Appendix A.2 step 3).
+//
+// PyG runs 8 scatter passes with atomics over the unsorted edge list; here the
+// rows are destination-sorted once per batch (csr.hip), so one thread owns a
+// float4 column slice of one node and walks the node's in-edges with the
+// running sum / sum of squares / min / max in registers: every message row is
+// read exactly once, every output written exactly once, no atomics, edge order
+// fixed => bitwise reproducible.  A message row is [T*F] = 2H floats: 64 lanes
+// x float4 = one full 1 KiB wave load at H = 128 (two waves per node at 256,
+// two nodes per wave at 64).
+//
+// Two sources for the message row r of node i:
+//   fused (pre_layers == 1): m = pq[i, c] + pq[src_r, 2F + c] + rtab[combo_r, c]
+//   materialised (pre_layers >= 2): m = msgs[r, c]
+//
+// HBM-bound.  Algorithmic bytes per launch:
+//   4*2F*E' (each message row once) + 8*E' (ids) + 4*2F*4*N (four aggregates).
+#include "common.hpp"
+
+namespace gs {
+
+constexpr int kEdgeBatch = 4;  // gathers kept in flight per thread
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict__ rowptr,
+                                                       const int32_t *__restrict__ src,
+                                                       const int32_t *__restrict__ combo,
+                                                       const float *__restrict__ pq, const float *__restrict__ rtab,
+                                                       const float *__restrict__ msgs, float *__restrict__ agg,
+                                                       int64_t num_nodes, int f) {
+  const int lanes_per_node = f / 2;  // 2F floats / 4 per thread
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t node = slot / lanes_per_node;
+  if (node >= num_nodes) return;
+  const int c = (int)(slot - node * lanes_per_node) * 4;  // column in [0, 2F)
+  const int tower = c / f;
+  const int col = c - tower * f;
+
+  const int beg = rowptr[node];
+  const int end = rowptr[node + 1];
+
+  f32x4 p = {0.f, 0.f, 0.f, 0.f};
+  if (FUSED) p = gs_ld4(pq + node * (int64_t)(4 * f) + c);
+
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  const float inf = __builtin_huge_valf();
+  f32x4 mn = {inf, inf, inf, inf}, mx = {-inf, -inf, -inf, -inf};
+
+  for (int r0 = beg; r0 < end; r0 += kEdgeBatch) {
+    f32x4 mrow[kEdgeBatch];
+    if (FUSED) {
+      int sidx[kEdgeBatch], cidx[kEdgeBatch];
+#pragma unroll
+      for (int j = 0; j < kEdgeBatch; ++j) {
+        const int r = r0 + j < end ? r0 + j : end - 1;
+        sidx[j] = src[r];
+        cidx[j] = combo[r];
+      }
+      f32x4 q[kEdgeBatch], t[kEdgeBatch];
+#pragma unroll
+      for (int j = 0; j < kEdgeBatch; ++j) {
+        q[j] = gs_ld4(pq + (int64_t)sidx[j] * (4 * f) + 2 * f + c);
+        t[j] = gs_ld4(rtab + (int64_t)cidx[j] * (2 * f) + c);
+      }
+#pragma unroll
+      for (int j = 0; j < kEdgeBatch; ++j) mrow[j] = (p + q[j]) + t[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < kEdgeBatch; ++j) {
+        const int r = r0 + j < end ? r0 + j : end - 1;
+        mrow[j] = gs_ld4(msgs + (int64_t)r * (2 * f) + c);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kEdgeBatch; ++j) {
+      if (r0 + j < end) {
+        const f32x4 v = mrow[j];
+        s += v;
+        s2 += v * v;
+        mn.x = fminf(mn.x, v.x);
+        mn.y = fminf(mn.y, v.y);
+        mn.z = fminf(mn.z, v.z);
+        mn.w = fminf(mn.w, v.w);
+        mx.x = fmaxf(mx.x, v.x);
+        mx.y = fmaxf(mx.y, v.y);
+        mx.z = fmaxf(mx.z, v.z);
+        mx.w = fmaxf(mx.w, v.w);
+      }
+    }
+  }
+
+  const int cnt = end - beg;
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};
+  if (cnt > 0) {
+    const float fc = (float)cnt;
+    mean = s / fc;
+    const f32x4 var = s2 / fc - mean * mean;
+    // PyG StdAggregation: var.clamp(min=1e-5).sqrt(), then 0 where <= sqrt(1e-5)
+    const float thr = 0.0031622776601683794f;
+    float sv[4] = {var.x, var.y, var.z, var.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float o = sqrtf(fmaxf(sv[j], 1e-5f));
+      sv[j] = o <= thr ? 0.f : o;
+    }
+    sd = f32x4{sv[0], sv[1], sv[2], sv[3]};
+  } else {
+    mn = f32x4{0.f, 0.f, 0.f, 0.f};
+    mx = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float *o = agg + node * (int64_t)(8 * f) + tower * (4 * f) + col;
+  gs_st4(o, mean);
+  gs_st4(o + f, mn);
+  gs_st4(o + 2 * f, mx);
+  gs_st4(o + 3 * f, sd);
+}
+
+}  // namespace gs
+
+extern "C" int gnnsaft_pna_aggregate(const int32_t *rowptr, const int32_t *src, const int32_t *combo,
+                                     int64_t num_nodes, int32_t hidden, const float *pq, const float *rtab,
+                                     const float *msgs, float *agg, gnnsaft_stream_t stream) {
+  GS_REQUIRE(rowptr != nullptr && agg != nullptr, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(num_nodes >= 0 && num_nodes * (int64_t)(hidden / 2) < ((int64_t)1 << 40), GNNSAFT_ERR_SHAPE);
+  if (num_nodes == 0) return GNNSAFT_OK;
+  const int64_t threads = num_nodes * (hidden / 2);
+  const dim3 grid((unsigned)gs_ceil_div(threads, 256)), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (msgs == nullptr) {
+    GS_REQUIRE(src && combo && pq && rtab, GNNSAFT_ERR_NULL);
+    hipLaunchKernelGGL((gs::k_pna_aggregate<true>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
+                       num_nodes, hidden);
+  } else {
+    hipLaunchKernelGGL((gs::k_pna_aggregate<false>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
+                       num_nodes, hidden);
+  }
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}

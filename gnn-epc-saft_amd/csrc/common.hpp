@@ -1,0 +1,65 @@
+// Shared helpers for the gfx950 kernels of libgnnsaft.  CDNA4 only: wave = 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gnnsaft.h"
+
+#define GS_WAVE 64
+
+#define GS_CHECK_LAUNCH()                         \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+#define GS_REQUIRE(cond, code) \
+  do {                         \
+    if (!(cond)) return (code); \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int64_t gs_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t gs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+__device__ __forceinline__ f32x4 gs_ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void gs_st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+namespace gs {
+
+// ---- internal launchers shared between the C ABI wrappers and gnnsaft_forward
+
+struct GemmBatchEntry {
+  const float *w;     // [n_out, ldw]
+  const float *bias;  // [n_out] or null
+  float *out;         // out + column offset already applied
+  int64_t a_off;      // provider-specific offset (e.g. tower offset into agg)
+};
+
+constexpr int kMaxGemmBatch = 4;
+constexpr int kBnRowsPerGroup = 64;  // rows covered by one wave's accumulator tile
+
+struct LinearEpilogue {
+  const float *scale = nullptr;   // eval-mode BN folded
+  const float *shift = nullptr;
+  int relu_out = 0;
+  const float *residual = nullptr;
+  int64_t ldr = 0;
+  float *stats = nullptr;         // [groups, 2, n_out] (mean, M2) partials
+};
+
+int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const GemmBatchEntry *entries,
+                  int64_t ldw, int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi,
+                  hipStream_t stream);
+
+int launch_pna_update(const float *x, const float *agg, const float *log_amp, const float *log_att,
+                      const float *avg_deg_log, int64_t n, int hidden, const GemmBatchEntry *entries /*2*/,
+                      int64_t ldo, hipStream_t stream);
+
+int launch_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *combo, int64_t rows, int hidden,
+                        const float *pq, const float *rtab, const GemmBatchEntry *entries /*2*/, int64_t ldo,
+                        hipStream_t stream);
+
+}  // namespace gs

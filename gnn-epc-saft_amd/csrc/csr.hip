@@ -1,0 +1,276 @@
+// K0 -- destination-sorted CSR of a PyG edge list, built once per batch and
+// reused by every layer.  Replaces add_self_loops
+// (/root/reference/gnnepcsaft/train/models.py:118-121) and the index plumbing
+// PyG re-derives per layer from the unsorted `edge_index` (index_select for
+// x_i / x_j, scatter index, degree()).  Self-loops are implicit: row
+// rowptr[i+1]-1 of every node is (src=i, combo=0), i.e. the loop PyG appends
+// after all real edges with attributes [0,0,0].
+//
+// histogram (int atomics) -> 3-phase exclusive scan -> atomic fill -> per-node
+// ascending sort of the segment's edge ids (segments are molecular in-degrees,
+// 1..5) so that the row order, hence every floating-point sum downstream, is
+// independent of atomic arrival order.
+#include "common.hpp"
+
+namespace gs {
+
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanBlock * kScanItems;  // 2048 counts per workgroup
+
+__global__ void k_zero_i32(int32_t *p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
+__global__ void k_count_in_degree(const int64_t *__restrict__ edge_index, int64_t n, int64_t e,
+                                  int32_t *__restrict__ counts, int32_t *err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= e) return;
+  const int64_t s = edge_index[i];
+  const int64_t d = edge_index[e + i];
+  if (s < 0 || s >= n || d < 0 || d >= n) {
+    if (err) atomicOr(err, GNNSAFT_FLAG_BAD_EDGE);
+    return;  // dropped
+  }
+  atomicAdd(&counts[d], 1);
+}
+
+// block-level exclusive scan of (counts[i] + extra), tile sums to `tile_sums`
+__device__ __forceinline__ int block_exclusive_scan(int v, int *lds, int &total) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  int wave_off = 0;
+  int tot = 0;
+#pragma unroll
+  for (int w = 0; w < kScanBlock / 64; ++w) {
+    const int t = lds[w];
+    if (w < wave) wave_off += t;
+    tot += t;
+  }
+  __syncthreads();
+  total = tot;
+  return wave_off + inc - v;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const int32_t *__restrict__ counts, int64_t n, int extra,
+                                                           int32_t *__restrict__ rowptr,
+                                                           int32_t *__restrict__ tile_sums) {
+  __shared__ int lds[kScanBlock / 64];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int v[kScanItems];
+  int local = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    const int64_t i = base + j;
+    v[j] = i < n ? counts[i] + extra : 0;
+    local += v[j];
+  }
+  int total;
+  int off = block_exclusive_scan(local, lds, total);
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    const int64_t i = base + j;
+    if (i < n) rowptr[i] = off;  // tile-local; tile offset added by k_scan_add
+    off += v[j];
+  }
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// single workgroup: exclusive scan of the tile sums, in place; writes the grand total to rowptr[n]
+__global__ __launch_bounds__(kScanBlock) void k_scan_tile_sums(int32_t *__restrict__ tile_sums, int64_t num_tiles,
+                                                               int32_t *__restrict__ rowptr, int64_t n) {
+  __shared__ int lds[kScanBlock / 64];
+  int carry = 0;
+  for (int64_t b = 0; b < num_tiles; b += kScanBlock) {
+    const int64_t i = b + threadIdx.x;
+    const int v = i < num_tiles ? tile_sums[i] : 0;
+    int total;
+    const int off = block_exclusive_scan(v, lds, total);
+    if (i < num_tiles) tile_sums[i] = carry + off;
+    carry += total;
+  }
+  if (threadIdx.x == 0) rowptr[n] = carry;
+}
+
+__global__ void k_scan_add(int32_t *__restrict__ rowptr, const int32_t *__restrict__ tile_sums, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rowptr[i] += tile_sums[i / kScanTile];
+}
+
+__global__ void k_fill_edge_ids(const int64_t *__restrict__ edge_index, int64_t n, int64_t e,
+                                const int32_t *__restrict__ rowptr, int32_t *__restrict__ cursor,
+                                int32_t *__restrict__ eid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= e) return;
+  const int64_t s = edge_index[i];
+  const int64_t d = edge_index[e + i];
+  if (s < 0 || s >= n || d < 0 || d >= n) return;
+  const int pos = rowptr[d] + atomicAdd(&cursor[d], 1);
+  eid[pos] = (int32_t)i;
+}
+
+struct BondDims {
+  int32_t n;
+  int32_t dims[GNNSAFT_MAX_TABLES];
+};
+
+// one thread per node: order the segment, emit src / dst / combo rows and the degree scaler logs
+__global__ void k_finish_rows(const int64_t *__restrict__ edge_index, const int64_t *__restrict__ edge_attr,
+                              int64_t n, int64_t e, BondDims bd, int self_loops,
+                              const int32_t *__restrict__ rowptr, const int32_t *__restrict__ counts,
+                              int32_t *__restrict__ eid, int32_t *__restrict__ src, int32_t *__restrict__ dst,
+                              int32_t *__restrict__ combo, float *__restrict__ log_amp,
+                              float *__restrict__ log_att, int32_t *err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int beg = rowptr[i];
+  const int cnt = counts[i];
+  // insertion sort, ascending edge id (stable wrt. the edge list)
+  for (int a = 1; a < cnt; ++a) {
+    const int key = eid[beg + a];
+    int b = a - 1;
+    while (b >= 0 && eid[beg + b] > key) {
+      eid[beg + b + 1] = eid[beg + b];
+      --b;
+    }
+    eid[beg + b + 1] = key;
+  }
+  for (int a = 0; a < cnt; ++a) {
+    const int64_t id = eid[beg + a];
+    int cid = 0;
+    for (int k = 0; k < bd.n; ++k) {
+      int64_t v = edge_attr[id * bd.n + k];
+      if (v < 0 || v >= bd.dims[k]) {
+        if (err) atomicOr(err, GNNSAFT_FLAG_BAD_ATTR);
+        v = 0;
+      }
+      cid = cid * bd.dims[k] + (int)v;
+    }
+    src[beg + a] = (int32_t)edge_index[id];
+    dst[beg + a] = (int32_t)i;
+    combo[beg + a] = cid;
+  }
+  int deg = cnt;
+  if (self_loops) {
+    src[beg + cnt] = (int32_t)i;
+    dst[beg + cnt] = (int32_t)i;
+    combo[beg + cnt] = 0;
+    deg += 1;
+  }
+  log_amp[i] = logf((float)deg + 1.f);
+  log_att[i] = logf(fmaxf((float)deg, 1.f) + 1.f);
+}
+
+__global__ void k_batch_to_ptr(const int64_t *__restrict__ batch, int64_t n, int64_t g, int32_t *__restrict__ ptr,
+                               int32_t *err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  // thread i in [0,n) closes the gap between batch[i-1] and batch[i]; thread n closes the tail
+  int64_t prev = i == 0 ? -1 : batch[i - 1];
+  int64_t cur = i == n ? g : batch[i];
+  if (i < n && (cur < 0 || cur >= g || cur < prev)) {
+    if (err) atomicOr(err, GNNSAFT_FLAG_BAD_BATCH);
+    return;
+  }
+  if (prev < -1) prev = -1;
+  if (prev >= g) return;
+  for (int64_t q = prev + 1; q <= cur && q <= g; ++q) ptr[q] = (int32_t)i;
+}
+
+__global__ void k_single_graph_ptr(int32_t *ptr, int32_t n) {
+  ptr[0] = 0;
+  ptr[1] = n;
+}
+
+}  // namespace gs
+
+extern "C" size_t gnnsaft_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges) {
+  // counts[N] + cursor[N] + tile_sums[tiles] + eid[E]
+  const size_t tiles = (size_t)gs_ceil_div(num_nodes > 0 ? num_nodes : 1, gs::kScanTile);
+  return gs_align_up((size_t)num_nodes * 4, 256) * 2 + gs_align_up(tiles * 4, 256) +
+         gs_align_up((size_t)(num_edges > 0 ? num_edges : 1) * 4, 256);
+}
+
+extern "C" int gnnsaft_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_t num_nodes,
+                                 int64_t num_edges, int32_t num_bond_cols, const int32_t *bond_dims_host,
+                                 int32_t self_loops, int32_t *rowptr, int32_t *src, int32_t *dst, int32_t *combo,
+                                 float *log_amp, float *log_att, int32_t *err_flag, void *workspace,
+                                 size_t workspace_bytes, gnnsaft_stream_t stream) {
+  GS_REQUIRE(rowptr && src && dst && combo && log_amp && log_att && workspace, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(num_edges == 0 || (edge_index != nullptr && edge_attr != nullptr), GNNSAFT_ERR_NULL);
+  GS_REQUIRE(num_nodes >= 0 && num_edges >= 0, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(num_nodes + num_edges < ((int64_t)1 << 31) - 1, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(num_bond_cols >= 0 && num_bond_cols <= GNNSAFT_MAX_TABLES, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(workspace_bytes >= gnnsaft_csr_workspace_bytes(num_nodes, num_edges), GNNSAFT_ERR_WORKSPACE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n = num_nodes, e = num_edges;
+  const int64_t tiles = gs_ceil_div(n > 0 ? n : 1, gs::kScanTile);
+  char *ws = static_cast<char *>(workspace);
+  int32_t *counts = reinterpret_cast<int32_t *>(ws);
+  ws += gs_align_up((size_t)n * 4, 256);
+  int32_t *cursor = reinterpret_cast<int32_t *>(ws);
+  ws += gs_align_up((size_t)n * 4, 256);
+  int32_t *tile_sums = reinterpret_cast<int32_t *>(ws);
+  ws += gs_align_up((size_t)tiles * 4, 256);
+  int32_t *eid = reinterpret_cast<int32_t *>(ws);
+
+  gs::BondDims bd;
+  bd.n = num_bond_cols;
+  int64_t combos = 1;
+  for (int k = 0; k < GNNSAFT_MAX_TABLES; ++k) {
+    bd.dims[k] = k < num_bond_cols ? bond_dims_host[k] : 1;
+    GS_REQUIRE(bd.dims[k] >= 1, GNNSAFT_ERR_SHAPE);
+    combos *= bd.dims[k];
+    GS_REQUIRE(combos <= (1 << 20), GNNSAFT_ERR_UNSUPPORTED);
+  }
+
+  const int tb = 256;
+  if (n > 0) {
+    // counts and cursor are adjacent up to alignment: zero both
+    hipLaunchKernelGGL(gs::k_zero_i32, dim3((unsigned)gs_ceil_div(2 * (int64_t)gs_align_up((size_t)n * 4, 256) / 4, tb)),
+                       dim3(tb), 0, st, counts, 2 * (int64_t)gs_align_up((size_t)n * 4, 256) / 4);
+  }
+  if (e > 0 && n > 0)
+    hipLaunchKernelGGL(gs::k_count_in_degree, dim3((unsigned)gs_ceil_div(e, tb)), dim3(tb), 0, st, edge_index, n, e,
+                       counts, err_flag);
+  hipLaunchKernelGGL(gs::k_scan_tiles, dim3((unsigned)tiles), dim3(gs::kScanBlock), 0, st, counts, n,
+                     self_loops ? 1 : 0, rowptr, tile_sums);
+  hipLaunchKernelGGL(gs::k_scan_tile_sums, dim3(1), dim3(gs::kScanBlock), 0, st, tile_sums, tiles, rowptr, n);
+  if (n > 0) {
+    hipLaunchKernelGGL(gs::k_scan_add, dim3((unsigned)gs_ceil_div(n, tb)), dim3(tb), 0, st, rowptr, tile_sums, n);
+    if (e > 0)
+      hipLaunchKernelGGL(gs::k_fill_edge_ids, dim3((unsigned)gs_ceil_div(e, tb)), dim3(tb), 0, st, edge_index, n, e,
+                         rowptr, cursor, eid);
+    hipLaunchKernelGGL(gs::k_finish_rows, dim3((unsigned)gs_ceil_div(n, tb)), dim3(tb), 0, st, edge_index, edge_attr,
+                       n, e, bd, self_loops ? 1 : 0, rowptr, counts, eid, src, dst, combo, log_amp, log_att,
+                       err_flag);
+  }
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_batch_to_ptr(const int64_t *batch, int64_t num_nodes, int64_t num_graphs, int32_t *graph_ptr,
+                                    int32_t *err_flag, gnnsaft_stream_t stream) {
+  GS_REQUIRE(graph_ptr != nullptr, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(num_graphs >= 0 && num_nodes >= 0 && num_nodes < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (batch == nullptr) {  // un-batched Data: a single graph spanning every node
+    GS_REQUIRE(num_graphs == 1, GNNSAFT_ERR_SHAPE);
+    hipLaunchKernelGGL(gs::k_single_graph_ptr, dim3(1), dim3(1), 0, st, graph_ptr, (int32_t)num_nodes);
+    GS_CHECK_LAUNCH();
+    return GNNSAFT_OK;
+  }
+  hipLaunchKernelGGL(gs::k_batch_to_ptr, dim3((unsigned)gs_ceil_div(num_nodes + 1, 256)), dim3(256), 0, st, batch,
+                     num_nodes, num_graphs, graph_ptr, err_flag);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}

@@ -1,0 +1,280 @@
+// HBM-bound row kernels of the PNAPCSAFT forward: categorical embedding sums
+// (ogb AtomEncoder / BondEncoder, /root/reference/gnnepcsaft/train/models.py:65-66,
+// 122-123), BatchNorm finalize / apply (models.py:82,128-131), global_add_pool
+// (models.py:133) and the MAPE loss (models.py:194).  All float4 per lane.
+#include "common.hpp"
+
+namespace gs {
+
+struct TableSet {
+  int32_t n;
+  int32_t dims[GNNSAFT_MAX_TABLES];
+  const float *tab[GNNSAFT_MAX_TABLES];
+};
+
+// out[i, :] = sum_k tab_k[idx[i,k], :]   (left-to-right, as ogb's encoder loop)
+__global__ __launch_bounds__(256) void k_embed_sum(const int64_t *__restrict__ idx, int64_t rows, TableSet ts, int h,
+                                                   float *__restrict__ out, int32_t *err) {
+  const int per_row = h / 4;
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = slot / per_row;
+  if (i >= rows) return;
+  const int c = (int)(slot - i * per_row) * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < ts.n; ++k) {
+    int64_t v = idx[i * ts.n + k];
+    if (v < 0 || v >= ts.dims[k]) {
+      if (err) atomicOr(err, GNNSAFT_FLAG_BAD_ATTR);
+      v = 0;
+    }
+    acc += gs_ld4(ts.tab[k] + v * h + c);
+  }
+  gs_st4(out + i * h + c, acc);
+}
+
+// out[c, :] = sum_k tab_k[digit_k(c), :] for every attribute combination c
+__global__ __launch_bounds__(256) void k_combo_embed(TableSet ts, int64_t combos, int h, float *__restrict__ out) {
+  const int per_row = h / 4;
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t cid = slot / per_row;
+  if (cid >= combos) return;
+  const int c = (int)(slot - cid * per_row) * 4;
+  int digit[GNNSAFT_MAX_TABLES];
+  int64_t rem = cid;
+  for (int k = ts.n - 1; k >= 0; --k) {
+    digit[k] = (int)(rem % ts.dims[k]);
+    rem /= ts.dims[k];
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < ts.n; ++k) acc += gs_ld4(ts.tab[k] + (int64_t)digit[k] * h + c);
+  gs_st4(out + cid * h + c, acc);
+}
+
+// ---- BatchNorm: one workgroup per channel, Chan combine of (mean, M2) partials in f64
+__global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ stats, int64_t rows, int ch,
+                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                     float *__restrict__ running_mean,
+                                                     float *__restrict__ running_var, int64_t *nbt, float momentum,
+                                                     float eps, int training, float *__restrict__ scale,
+                                                     float *__restrict__ shift) {
+  const int c = blockIdx.x;
+  __shared__ double s_n[256], s_mean[256], s_m2[256];
+  float mean_f, var_f;
+  if (training) {
+    const int64_t groups = (rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int64_t g = threadIdx.x; g < groups; g += blockDim.x) {
+      const int64_t left = rows - g * kBnRowsPerGroup;
+      const double gn = (double)(left < kBnRowsPerGroup ? left : kBnRowsPerGroup);
+      const double gm = (double)stats[(g * 2 + 0) * ch + c];
+      const double g2 = (double)stats[(g * 2 + 1) * ch + c];
+      const double tot = n + gn;
+      const double delta = gm - mean;
+      mean += delta * (gn / tot);
+      m2 += g2 + delta * delta * (n * gn / tot);
+      n = tot;
+    }
+    s_n[threadIdx.x] = n;
+    s_mean[threadIdx.x] = mean;
+    s_m2[threadIdx.x] = m2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        const double na = s_n[threadIdx.x], nb = s_n[threadIdx.x + o];
+        const double tot = na + nb;
+        if (tot > 0.0) {
+          const double delta = s_mean[threadIdx.x + o] - s_mean[threadIdx.x];
+          s_mean[threadIdx.x] += delta * (nb / tot);
+          s_m2[threadIdx.x] += s_m2[threadIdx.x + o] + delta * delta * (na * nb / tot);
+          s_n[threadIdx.x] = tot;
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const double tot = s_n[0];
+    mean_f = (float)s_mean[0];
+    var_f = (float)(s_m2[0] / tot);  // biased, used for normalisation
+    if (running_mean != nullptr) {
+      const float unbiased = (float)(tot > 1.0 ? s_m2[0] / (tot - 1.0) : s_m2[0]);
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean_f;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+    if (nbt != nullptr && c == 0) nbt[0] += 1;
+  } else {
+    if (threadIdx.x != 0) return;
+    mean_f = running_mean[c];
+    var_f = running_var[c];
+  }
+  const float rstd = 1.f / sqrtf(var_f + eps);
+  const float sc = rstd * (gamma != nullptr ? gamma[c] : 1.f);
+  scale[c] = sc;
+  shift[c] = (beta != nullptr ? beta[c] : 0.f) - mean_f * sc;
+}
+
+__global__ __launch_bounds__(256) void k_bn_relu_residual(const float *__restrict__ y, const float *__restrict__ scale,
+                                                          const float *__restrict__ shift,
+                                                          const float *__restrict__ residual, float *__restrict__ out,
+                                                          int64_t total4, int ch) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+    const int c = (int)((i * 4) % ch);
+    const f32x4 v = gs_ld4(y + i * 4);
+    const f32x4 sc = gs_ld4(scale + c), sh = gs_ld4(shift + c);
+    f32x4 o = v * sc + sh;
+    o.x = fmaxf(o.x, 0.f);
+    o.y = fmaxf(o.y, 0.f);
+    o.z = fmaxf(o.z, 0.f);
+    o.w = fmaxf(o.w, 0.f);
+    if (residual != nullptr) o += gs_ld4(residual + i * 4);
+    gs_st4(out + i * 4, o);
+  }
+}
+
+// out[g, :] = sum over rows ptr[g] .. ptr[g+1]-1, sequential (graph-contiguous rows)
+__global__ __launch_bounds__(256) void k_add_pool(const float *__restrict__ x, const int32_t *__restrict__ ptr,
+                                                  int64_t graphs, int64_t nodes, int h, float *__restrict__ out) {
+  const int per_row = h / 4;
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t g = slot / per_row;
+  if (g >= graphs) return;
+  const int c = (int)(slot - g * per_row) * 4;
+  int64_t beg = ptr[g], end = ptr[g + 1];
+  beg = beg < 0 ? 0 : (beg > nodes ? nodes : beg);
+  end = end < beg ? beg : (end > nodes ? nodes : end);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int64_t r = beg;
+  for (; r + 4 <= end; r += 4) {
+    const f32x4 a = gs_ld4(x + (r + 0) * h + c), b = gs_ld4(x + (r + 1) * h + c);
+    const f32x4 d = gs_ld4(x + (r + 2) * h + c), e = gs_ld4(x + (r + 3) * h + c);
+    acc += a;
+    acc += b;
+    acc += d;
+    acc += e;
+  }
+  for (; r < end; ++r) acc += gs_ld4(x + r * h + c);
+  gs_st4(out + g * h + c, acc);
+}
+
+__global__ __launch_bounds__(1024) void k_mape(const float *__restrict__ pred, const float *__restrict__ target,
+                                               int64_t n, float *__restrict__ out3) {
+  __shared__ float part[1024 / 64];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const float t = target[i];
+    acc += fabsf(pred[i] - t) / fmaxf(fabsf(t), 1.17e-06f);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int w = 0; w < 1024 / 64; ++w) tot += part[w];
+    out3[0] = tot / (float)n;
+    out3[1] = tot;
+    out3[2] = (float)n;
+  }
+}
+
+static int make_tables(int32_t num_cols, const float *const *tables_host, const int32_t *dims_host, TableSet &ts) {
+  GS_REQUIRE(num_cols >= 1 && num_cols <= GNNSAFT_MAX_TABLES, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(tables_host != nullptr && dims_host != nullptr, GNNSAFT_ERR_NULL);
+  ts.n = num_cols;
+  for (int k = 0; k < GNNSAFT_MAX_TABLES; ++k) {
+    ts.dims[k] = k < num_cols ? dims_host[k] : 1;
+    ts.tab[k] = k < num_cols ? tables_host[k] : nullptr;
+    if (k < num_cols) GS_REQUIRE(ts.tab[k] != nullptr && ts.dims[k] >= 1, GNNSAFT_ERR_NULL);
+  }
+  return GNNSAFT_OK;
+}
+
+}  // namespace gs
+
+extern "C" int gnnsaft_embed_sum(const int64_t *idx, int64_t num_rows, int32_t num_cols,
+                                 const float *const *tables_host, const int32_t *dims_host, int32_t hidden,
+                                 float *out, int32_t *err_flag, gnnsaft_stream_t stream) {
+  GS_REQUIRE(out != nullptr && (idx != nullptr || num_rows == 0), GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 4 && (hidden % 4) == 0 && num_rows >= 0, GNNSAFT_ERR_SHAPE);
+  gs::TableSet ts;
+  const int rc = gs::make_tables(num_cols, tables_host, dims_host, ts);
+  if (rc != GNNSAFT_OK) return rc;
+  if (num_rows == 0) return GNNSAFT_OK;
+  const int64_t threads = num_rows * (hidden / 4);
+  hipLaunchKernelGGL(gs::k_embed_sum, dim3((unsigned)gs_ceil_div(threads, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), idx, num_rows, ts, hidden, out, err_flag);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_bond_combo_embed(int32_t num_cols, const float *const *tables_host,
+                                        const int32_t *dims_host, int32_t hidden, float *out,
+                                        gnnsaft_stream_t stream) {
+  GS_REQUIRE(out != nullptr, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 4 && (hidden % 4) == 0, GNNSAFT_ERR_SHAPE);
+  gs::TableSet ts;
+  const int rc = gs::make_tables(num_cols, tables_host, dims_host, ts);
+  if (rc != GNNSAFT_OK) return rc;
+  int64_t combos = 1;
+  for (int k = 0; k < num_cols; ++k) combos *= ts.dims[k];
+  GS_REQUIRE(combos <= (1 << 20), GNNSAFT_ERR_UNSUPPORTED);
+  const int64_t threads = combos * (hidden / 4);
+  hipLaunchKernelGGL(gs::k_combo_embed, dim3((unsigned)gs_ceil_div(threads, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), ts, combos, hidden, out);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_bn_finalize(const float *stats, int64_t num_rows, int32_t channels, const float *gamma,
+                                   const float *beta, float *running_mean, float *running_var,
+                                   int64_t *num_batches_tracked, float momentum, float eps, int32_t training,
+                                   float *scale, float *shift, gnnsaft_stream_t stream) {
+  GS_REQUIRE(scale != nullptr && shift != nullptr && channels >= 1, GNNSAFT_ERR_NULL);
+  if (training) {
+    GS_REQUIRE(stats != nullptr, GNNSAFT_ERR_NULL);
+    GS_REQUIRE(num_rows >= 2, GNNSAFT_ERR_SHAPE);  // torch: "Expected more than 1 value per channel"
+  } else {
+    GS_REQUIRE(running_mean != nullptr && running_var != nullptr, GNNSAFT_ERR_NULL);
+  }
+  hipLaunchKernelGGL(gs::k_bn_finalize, dim3((unsigned)channels), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     stats, num_rows, channels, gamma, beta, running_mean, running_var, num_batches_tracked, momentum,
+                     eps, training, scale, shift);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_bn_relu_residual(const float *y, const float *scale, const float *shift,
+                                        const float *residual, float *out, int64_t num_rows, int32_t channels,
+                                        gnnsaft_stream_t stream) {
+  GS_REQUIRE(y && scale && shift && out, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(channels >= 4 && (channels % 4) == 0 && num_rows >= 0, GNNSAFT_ERR_SHAPE);
+  if (num_rows == 0) return GNNSAFT_OK;
+  const int64_t total4 = num_rows * channels / 4;
+  int64_t blocks = gs_ceil_div(total4, 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(gs::k_bn_relu_residual, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     y, scale, shift, residual, out, total4, channels);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_add_pool(const float *x, const int32_t *graph_ptr, int64_t num_graphs, int64_t num_nodes,
+                                int32_t hidden, float *out, gnnsaft_stream_t stream) {
+  GS_REQUIRE(graph_ptr && out && (x != nullptr || num_nodes == 0), GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 4 && (hidden % 4) == 0 && num_graphs >= 0, GNNSAFT_ERR_SHAPE);
+  if (num_graphs == 0) return GNNSAFT_OK;
+  const int64_t threads = num_graphs * (hidden / 4);
+  hipLaunchKernelGGL(gs::k_add_pool, dim3((unsigned)gs_ceil_div(threads, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, graph_ptr, num_graphs, num_nodes, hidden, out);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_mape(const float *pred, const float *target, int64_t numel, float *out3,
+                            gnnsaft_stream_t stream) {
+  GS_REQUIRE(pred && target && out3, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(numel >= 1, GNNSAFT_ERR_SHAPE);
+  hipLaunchKernelGGL(gs::k_mape, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), pred, target, numel, out3);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}

@@ -1,0 +1,417 @@
+// Whole-network orchestration: PNAPCSAFT.forward
+// (/root/reference/gnnepcsaft/train/models.py:105-135) + MAPE loss
+// (models.py:191-194) as one C call that enqueues every kernel on the caller's
+// stream.  No allocation, no synchronisation: capturable into a hipGraph.
+//
+// Canonical weight table (HOST array of device pointers), in order:
+//   atom tables [num_atom_cols], bond tables [num_bond_cols]
+//   per conv layer l:
+//     aggr_module.avg_deg_log
+//     edge_encoder.weight, edge_encoder.bias
+//     pre_nns[0]: (weight, bias) x pre_layers ; pre_nns[1]: (weight, bias) x pre_layers
+//     post_nns[0]: (weight, bias) x post_layers ; post_nns[1]: (weight, bias) x post_layers
+//     lin.weight, lin.bias
+//     batch_norms[l].module: weight, bias, running_mean, running_var, num_batches_tracked
+//   readout: num_mlp_layers x (Linear weight, bias, BN x5)
+//            Linear(H,H/2) w,b, BN x5, Linear(H/2,H/4) w,b, BN x5, Linear(H/4,P) w,b
+#include "common.hpp"
+
+namespace gs {
+
+struct Plan {
+  // sizes
+  int64_t n, e, ep, g, combos;
+  int h;
+  // byte offsets into the workspace
+  size_t csr_ws, rowptr, src, dst, combo, log_amp, log_att, graph_ptr;
+  size_t x0, x1, pq, agg, u0, u1, y, msg0, msg1, cemb, cenc, rtab, stats, scale, shift, pooled, m0, m1, m2;
+  size_t total;
+};
+
+static int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, int64_t g, Plan &p) {
+  GS_REQUIRE(d != nullptr, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(d->hidden >= 32 && (d->hidden % 32) == 0 && d->hidden <= 1024, GNNSAFT_ERR_UNSUPPORTED);
+  GS_REQUIRE(d->num_layers >= 0 && d->pre_layers >= 1 && d->post_layers >= 1 && d->num_mlp_layers >= 0 &&
+                 d->num_para >= 1,
+             GNNSAFT_ERR_UNSUPPORTED);
+  GS_REQUIRE(d->num_atom_cols >= 1 && d->num_atom_cols <= GNNSAFT_MAX_TABLES && d->num_bond_cols >= 1 &&
+                 d->num_bond_cols <= GNNSAFT_MAX_TABLES,
+             GNNSAFT_ERR_UNSUPPORTED);
+  GS_REQUIRE(n >= 0 && e >= 0 && g >= 0, GNNSAFT_ERR_SHAPE);
+  p.n = n;
+  p.e = e;
+  p.g = g;
+  p.h = d->hidden;
+  p.ep = e + (d->self_loops ? n : 0);
+  GS_REQUIRE(p.ep + n < ((int64_t)1 << 31) - 1, GNNSAFT_ERR_SHAPE);
+  p.combos = 1;
+  for (int k = 0; k < d->num_bond_cols; ++k) {
+    GS_REQUIRE(d->bond_dims[k] >= 1, GNNSAFT_ERR_SHAPE);
+    p.combos *= d->bond_dims[k];
+    GS_REQUIRE(p.combos <= (1 << 20), GNNSAFT_ERR_UNSUPPORTED);
+  }
+  const size_t h = (size_t)d->hidden;
+  const size_t nn = (size_t)(n > 0 ? n : 1), ee = (size_t)(p.ep > 0 ? p.ep : 1), gg = (size_t)(g > 0 ? g : 1);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += gs_align_up(bytes, 256);
+    return o;
+  };
+  p.csr_ws = take(gnnsaft_csr_workspace_bytes(n, e));
+  p.rowptr = take((nn + 1) * 4);
+  p.src = take(ee * 4);
+  p.dst = take(ee * 4);
+  p.combo = take(ee * 4);
+  p.log_amp = take(nn * 4);
+  p.log_att = take(nn * 4);
+  p.graph_ptr = take((gg + 1) * 4);
+  p.x0 = take(nn * h * 4);
+  p.x1 = take(nn * h * 4);
+  p.pq = take(nn * 4 * h * 4);
+  p.agg = take(nn * 8 * h * 4);
+  p.u0 = take(nn * h * 4);
+  p.u1 = d->post_layers > 1 ? take(nn * h * 4) : p.u0;
+  p.y = take(nn * h * 4);
+  p.msg0 = d->pre_layers > 1 ? take(ee * 2 * h * 4) : 0;
+  p.msg1 = d->pre_layers > 2 ? take(ee * 2 * h * 4) : p.msg0;
+  p.cemb = take((size_t)p.combos * h * 4);
+  p.cenc = take((size_t)p.combos * h * 4);
+  p.rtab = take((size_t)p.combos * 2 * h * 4);
+  const size_t max_rows = nn > gg ? nn : gg;
+  p.stats = take(((max_rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup) * 2 * h * 4);
+  p.scale = take(h * 4);
+  p.shift = take(h * 4);
+  p.pooled = take(gg * h * 4);
+  p.m0 = take(gg * h * 4);
+  p.m1 = take(gg * h * 4);
+  p.m2 = take(gg * h * 4);
+  p.total = off;
+  return GNNSAFT_OK;
+}
+
+struct BnPtrs {
+  const float *gamma, *beta;
+  float *rmean, *rvar;
+  int64_t *nbt;
+};
+
+struct WeightCursor {
+  const void *const *w;
+  int n;
+  int i = 0;
+  bool ok = true;
+  const float *f() {
+    if (i >= n || w[i] == nullptr) {
+      ok = false;
+      ++i;
+      return nullptr;
+    }
+    return static_cast<const float *>(w[i++]);
+  }
+  BnPtrs bn() {
+    BnPtrs b;
+    b.gamma = f();
+    b.beta = f();
+    b.rmean = const_cast<float *>(f());
+    b.rvar = const_cast<float *>(f());
+    b.nbt = reinterpret_cast<int64_t *>(const_cast<float *>(f()));
+    return b;
+  }
+};
+
+#define GS_TRY(expr)                  \
+  do {                                \
+    const int rc__ = (expr);          \
+    if (rc__ != GNNSAFT_OK) return rc__; \
+  } while (0)
+
+// Linear -> BatchNorm -> ReLU (-> + residual): eval folds BN into the GEMM epilogue,
+// train writes y with (mean, M2) partials, finalises the statistics and applies them.
+static int linear_bn_relu(const float *a, int64_t lda, const float *w, const float *b, int64_t rows, int n_out, int k,
+                          const BnPtrs &bn, const gnnsaft_model_desc *d, char *ws, const Plan &p, float *y_tmp,
+                          const float *residual, float *out, hipStream_t st) {
+  float *scale = reinterpret_cast<float *>(ws + p.scale);
+  float *shift = reinterpret_cast<float *>(ws + p.shift);
+  float *stats = reinterpret_cast<float *>(ws + p.stats);
+  GemmBatchEntry ent{w, b, nullptr, 0};
+  if (d->training) {
+    GS_REQUIRE(rows >= 2, GNNSAFT_ERR_SHAPE);
+    ent.out = y_tmp;
+    LinearEpilogue epi;
+    epi.stats = stats;
+    GS_TRY(launch_linear(a, lda, 0, 1, &ent, k, n_out, rows, n_out, k, epi, st));
+    GS_TRY(gnnsaft_bn_finalize(stats, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt, d->bn_momentum,
+                               d->bn_eps, 1, scale, shift, st));
+    GS_TRY(gnnsaft_bn_relu_residual(y_tmp, scale, shift, residual, out, rows, n_out, st));
+  } else {
+    GS_TRY(gnnsaft_bn_finalize(nullptr, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, nullptr, d->bn_momentum,
+                               d->bn_eps, 0, scale, shift, st));
+    ent.out = out;
+    LinearEpilogue epi;
+    epi.scale = scale;
+    epi.shift = shift;
+    epi.relu_out = 1;
+    epi.residual = residual;
+    epi.ldr = n_out;
+    GS_TRY(launch_linear(a, lda, 0, 1, &ent, k, n_out, rows, n_out, k, epi, st));
+  }
+  return GNNSAFT_OK;
+}
+
+static int node_terms(const float *x, int64_t n, int h, const float *w0, const float *w1, float *pq, hipStream_t st) {
+  GemmBatchEntry e[4] = {{w0, nullptr, pq, 0}, {w1, nullptr, pq + h, 0}, {w0 + h, nullptr, pq + 2 * h, 0},
+                         {w1 + h, nullptr, pq + 3 * h, 0}};
+  LinearEpilogue epi;
+  return launch_linear(x, h, 0, 4, e, 3 * (int64_t)h, 4 * (int64_t)h, n, h, h, epi, st);
+}
+
+static int edge_table(const float *cemb, int64_t combos, int h, const float *we, const float *be, const float *w0,
+                      const float *b0, const float *w1, const float *b1, float *cenc, float *rtab, hipStream_t st) {
+  LinearEpilogue epi;
+  GemmBatchEntry e1{we, be, cenc, 0};
+  GS_TRY(launch_linear(cemb, h, 0, 1, &e1, h, h, combos, h, h, epi, st));
+  GemmBatchEntry e2[2] = {{w0 + 2 * h, b0, rtab, 0}, {w1 + 2 * h, b1, rtab + h, 0}};
+  return launch_linear(cenc, h, 0, 2, e2, 3 * (int64_t)h, 2 * (int64_t)h, combos, h, h, epi, st);
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" int gnnsaft_abi_version(void) { return GNNSAFT_ABI_VERSION; }
+
+extern "C" const char *gnnsaft_error_string(int code) {
+  if (code == GNNSAFT_OK) return "ok";
+  if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+  switch (code) {
+    case GNNSAFT_ERR_SHAPE: return "unsupported or inconsistent sizes";
+    case GNNSAFT_ERR_WORKSPACE: return "workspace too small";
+    case GNNSAFT_ERR_NULL: return "required pointer is NULL";
+    case GNNSAFT_ERR_UNSUPPORTED: return "configuration outside the supported shape envelope";
+    default: return "unknown gnnsaft error";
+  }
+}
+
+extern "C" int32_t gnnsaft_bn_rows_per_group(void) { return kBnRowsPerGroup; }
+
+extern "C" int gnnsaft_linear(const float *a, int64_t lda, int32_t relu_in, const float *w, int64_t ldw,
+                              const float *bias, float *out, int64_t ldo, int64_t m, int32_t n_out, int32_t k,
+                              const float *scale, const float *shift, int32_t relu_out, const float *residual,
+                              int64_t ldr, float *stats, gnnsaft_stream_t stream) {
+  GemmBatchEntry ent{w, bias, out, 0};
+  LinearEpilogue epi;
+  epi.scale = scale;
+  epi.shift = shift;
+  epi.relu_out = relu_out;
+  epi.residual = residual;
+  epi.ldr = ldr;
+  epi.stats = stats;
+  GS_REQUIRE(stats == nullptr || ldo == n_out, GNNSAFT_ERR_SHAPE);
+  return launch_linear(a, lda, relu_in, 1, &ent, ldw, ldo, m, n_out, k, epi, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gnnsaft_pna_node_terms(const float *x, int64_t num_nodes, int32_t hidden, const float *w_pre0,
+                                      const float *w_pre1, float *pq, gnnsaft_stream_t stream) {
+  GS_REQUIRE(x && w_pre0 && w_pre1 && pq, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
+  return node_terms(x, num_nodes, hidden, w_pre0, w_pre1, pq, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gnnsaft_pna_edge_table(const float *combo_emb, int32_t num_combos, int32_t hidden,
+                                      const float *w_edge, const float *b_edge, const float *w_pre0,
+                                      const float *b_pre0, const float *w_pre1, const float *b_pre1, float *enc_tmp,
+                                      float *rtab, gnnsaft_stream_t stream) {
+  GS_REQUIRE(combo_emb && w_edge && b_edge && w_pre0 && b_pre0 && w_pre1 && b_pre1 && enc_tmp && rtab,
+             GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0 && num_combos >= 1, GNNSAFT_ERR_SHAPE);
+  return edge_table(combo_emb, num_combos, hidden, w_edge, b_edge, w_pre0, b_pre0, w_pre1, b_pre1, enc_tmp, rtab,
+                    static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gnnsaft_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *combo, int64_t num_rows,
+                                    int32_t hidden, const float *pq, const float *rtab, const float *w2_t0,
+                                    const float *b2_t0, const float *w2_t1, const float *b2_t1, float *msgs,
+                                    gnnsaft_stream_t stream) {
+  GS_REQUIRE(w2_t0 && b2_t0 && w2_t1 && b2_t1 && msgs, GNNSAFT_ERR_NULL);
+  GemmBatchEntry e[2] = {{w2_t0, b2_t0, msgs, 0}, {w2_t1, b2_t1, msgs + hidden, 0}};
+  return launch_pna_edge_mlp(src, dst, combo, num_rows, hidden, pq, rtab, e, 2 * (int64_t)hidden,
+                             static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gnnsaft_pna_update(const float *x, const float *agg, const float *log_amp, const float *log_att,
+                                  const float *avg_deg_log, int64_t num_nodes, int32_t hidden, const float *w_post0,
+                                  const float *b_post0, const float *w_post1, const float *b_post1, float *u,
+                                  gnnsaft_stream_t stream) {
+  GS_REQUIRE(w_post0 && b_post0 && w_post1 && b_post1 && u, GNNSAFT_ERR_NULL);
+  GemmBatchEntry e[2] = {{w_post0, b_post0, u, 0}, {w_post1, b_post1, u + hidden / 2, 0}};
+  return launch_pna_update(x, agg, log_amp, log_att, avg_deg_log, num_nodes, hidden, e, hidden,
+                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t gnnsaft_num_weights(const gnnsaft_model_desc *d) {
+  if (d == nullptr) return -1;
+  const int per_layer = 1 + 2 + 4 * d->pre_layers + 4 * d->post_layers + 2 + 5;
+  return d->num_atom_cols + d->num_bond_cols + d->num_layers * per_layer + d->num_mlp_layers * 7 + (2 + 5 + 2 + 5 + 2);
+}
+
+extern "C" size_t gnnsaft_forward_workspace_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes,
+                                                  int64_t num_edges, int64_t num_graphs) {
+  Plan p;
+  if (make_plan(desc, num_nodes, num_edges, num_graphs, p) != GNNSAFT_OK) return 0;
+  return p.total;
+}
+
+extern "C" int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int64_t num_nodes, int64_t num_edges,
+                                             int64_t num_graphs, gnnsaft_workspace_map *map) {
+  GS_REQUIRE(map != nullptr, GNNSAFT_ERR_NULL);
+  Plan p;
+  GS_TRY(make_plan(desc, num_nodes, num_edges, num_graphs, p));
+  map->rowptr = p.rowptr;
+  map->src = p.src;
+  map->dst = p.dst;
+  map->combo = p.combo;
+  map->log_amp = p.log_amp;
+  map->log_att = p.log_att;
+  map->graph_ptr = p.graph_ptr;
+  map->x_embed = p.x0;
+  map->x_final = (desc->num_layers % 2) ? p.x1 : p.x0;
+  map->pq = p.pq;
+  map->agg = p.agg;
+  map->u = p.u0;
+  map->y = p.y;
+  map->rtab = p.rtab;
+  map->pooled = p.pooled;
+  map->total = p.total;
+  return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *weights_host, int32_t num_weights,
+                               const int64_t *x_idx, const int64_t *edge_index, const int64_t *edge_attr,
+                               const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
+                               const float *target, float *out, float *loss3, int32_t *err_flag, void *workspace,
+                               size_t workspace_bytes, gnnsaft_stream_t stream) {
+  GS_REQUIRE(d && weights_host && out && workspace, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(num_weights == gnnsaft_num_weights(d), GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(num_nodes >= 1 && num_graphs >= 1 && x_idx != nullptr, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, GNNSAFT_ERR_WORKSPACE);
+  Plan p;
+  GS_TRY(make_plan(d, num_nodes, num_edges, num_graphs, p));
+  GS_REQUIRE(workspace_bytes >= p.total, GNNSAFT_ERR_WORKSPACE);
+  if (d->training) GS_REQUIRE(num_nodes >= 2 && num_graphs >= 2, GNNSAFT_ERR_SHAPE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char *ws = static_cast<char *>(workspace);
+  const int h = d->hidden;
+  const int64_t n = num_nodes, g = num_graphs;
+  auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+  auto I = [&](size_t off) { return reinterpret_cast<int32_t *>(ws + off); };
+
+  WeightCursor wc{weights_host, num_weights};
+  const float *atom_tab[GNNSAFT_MAX_TABLES], *bond_tab[GNNSAFT_MAX_TABLES];
+  for (int k = 0; k < d->num_atom_cols; ++k) atom_tab[k] = wc.f();
+  for (int k = 0; k < d->num_bond_cols; ++k) bond_tab[k] = wc.f();
+  GS_REQUIRE(wc.ok, GNNSAFT_ERR_NULL);
+
+  // ---- K0 structure, K1 embeddings
+  GS_TRY(gnnsaft_csr_build(edge_index, edge_attr, n, num_edges, d->num_bond_cols, d->bond_dims, d->self_loops,
+                           I(p.rowptr), I(p.src), I(p.dst), I(p.combo), F(p.log_amp), F(p.log_att), err_flag,
+                           ws + p.csr_ws, gnnsaft_csr_workspace_bytes(n, num_edges), st));
+  // batch == NULL (un-batched Data, models.py:116): one graph spanning all nodes
+  GS_TRY(gnnsaft_batch_to_ptr(batch, n, g, I(p.graph_ptr), err_flag, st));
+  GS_TRY(gnnsaft_embed_sum(x_idx, n, d->num_atom_cols, atom_tab, d->atom_dims, h, F(p.x0), err_flag, st));
+  GS_TRY(gnnsaft_bond_combo_embed(d->num_bond_cols, bond_tab, d->bond_dims, h, F(p.cemb), st));
+
+  float *xc = F(p.x0), *xn = F(p.x1);
+  for (int l = 0; l < d->num_layers; ++l) {
+    const float *avg = wc.f();
+    const float *we = wc.f(), *be = wc.f();
+    const float *wpre[2][8], *bpre[2][8], *wpost[2][8], *bpost[2][8];
+    GS_REQUIRE(d->pre_layers <= 8 && d->post_layers <= 8, GNNSAFT_ERR_UNSUPPORTED);
+    for (int t = 0; t < 2; ++t)
+      for (int j = 0; j < d->pre_layers; ++j) {
+        wpre[t][j] = wc.f();
+        bpre[t][j] = wc.f();
+      }
+    for (int t = 0; t < 2; ++t)
+      for (int j = 0; j < d->post_layers; ++j) {
+        wpost[t][j] = wc.f();
+        bpost[t][j] = wc.f();
+      }
+    const float *wlin = wc.f(), *blin = wc.f();
+    BnPtrs bn = wc.bn();
+    GS_REQUIRE(wc.ok, GNNSAFT_ERR_NULL);
+
+    // message: node terms + edge-class table (+ extra pre-layers on edge rows)
+    GS_TRY(edge_table(F(p.cemb), p.combos, h, we, be, wpre[0][0], bpre[0][0], wpre[1][0], bpre[1][0], F(p.cenc),
+                      F(p.rtab), st));
+    GS_TRY(node_terms(xc, n, h, wpre[0][0], wpre[1][0], F(p.pq), st));
+    const float *msgs = nullptr;
+    if (d->pre_layers > 1) {
+      float *ma = F(p.msg0), *mb = F(p.msg1);
+      GemmBatchEntry e[2] = {{wpre[0][1], bpre[0][1], ma, 0}, {wpre[1][1], bpre[1][1], ma + h, 0}};
+      GS_TRY(launch_pna_edge_mlp(I(p.src), I(p.dst), I(p.combo), p.ep, h, F(p.pq), F(p.rtab), e, 2 * (int64_t)h, st));
+      for (int j = 2; j < d->pre_layers; ++j) {
+        GemmBatchEntry e2[2] = {{wpre[0][j], bpre[0][j], mb, 0}, {wpre[1][j], bpre[1][j], mb + h, h}};
+        LinearEpilogue epi;
+        GS_TRY(launch_linear(ma, 2 * (int64_t)h, 1, 2, e2, h, 2 * (int64_t)h, p.ep, h, h, epi, st));
+        float *t = ma;
+        ma = mb;
+        mb = t;
+      }
+      msgs = ma;
+    }
+    // K4 aggregation
+    GS_TRY(gnnsaft_pna_aggregate(I(p.rowptr), I(p.src), I(p.combo), n, h, F(p.pq), F(p.rtab), msgs, F(p.agg), st));
+    // update: first post-layer with scalers on load, then extra post-layers
+    float *ua = F(p.u0), *ub = F(p.u1);
+    {
+      GemmBatchEntry e[2] = {{wpost[0][0], bpost[0][0], ua, 0}, {wpost[1][0], bpost[1][0], ua + h / 2, 0}};
+      GS_TRY(launch_pna_update(xc, F(p.agg), F(p.log_amp), F(p.log_att), avg, n, h, e, h, st));
+    }
+    for (int j = 1; j < d->post_layers; ++j) {
+      GemmBatchEntry e2[2] = {{wpost[0][j], bpost[0][j], ub, 0}, {wpost[1][j], bpost[1][j], ub + h / 2, h / 2}};
+      LinearEpilogue epi;
+      GS_TRY(launch_linear(ua, h, 1, 2, e2, h / 2, h, n, h / 2, h / 2, epi, st));
+      float *t = ua;
+      ua = ub;
+      ub = t;
+    }
+    // lin -> BatchNorm -> ReLU -> (+ x)
+    GS_TRY(linear_bn_relu(ua, h, wlin, blin, n, h, h, bn, d, ws, p, F(p.y), d->skip_connections ? xc : nullptr, xn,
+                          st));
+    float *t = xc;
+    xc = xn;
+    xn = t;
+  }
+
+  // ---- readout
+  GS_TRY(gnnsaft_add_pool(xc, I(p.graph_ptr), g, n, h, F(p.pooled), st));
+  const float *cur = F(p.pooled);
+  float *rot[3] = {F(p.m0), F(p.m1), F(p.m2)};
+  int ci = 2;  // index of `cur` in rot (pooled counts as slot 2 for the first block)
+  int width = h;
+  auto block = [&](int n_out) -> int {
+    const float *w = wc.f(), *b = wc.f();
+    BnPtrs bn = wc.bn();
+    GS_REQUIRE(wc.ok, GNNSAFT_ERR_NULL);
+    // pre-BN scratch and output are the two rotating buffers that are not the input
+    float *y_tmp = rot[(ci + 1) % 3], *o = rot[(ci + 2) % 3];
+    GS_TRY(linear_bn_relu(cur, width, w, b, g, n_out, width, bn, d, ws, p, y_tmp, nullptr, o, st));
+    cur = o;
+    ci = (ci + 2) % 3;
+    width = n_out;
+    return GNNSAFT_OK;
+  };
+  for (int i = 0; i < d->num_mlp_layers; ++i) GS_TRY(block(h));
+  GS_TRY(block(h / 2));
+  GS_TRY(block(h / 4));
+  {
+    const float *w = wc.f(), *b = wc.f();
+    GS_REQUIRE(wc.ok && wc.i == num_weights, GNNSAFT_ERR_SHAPE);
+    GemmBatchEntry ent{w, b, out, 0};
+    LinearEpilogue epi;
+    GS_TRY(launch_linear(cur, width, 0, 1, &ent, width, d->num_para, g, d->num_para, width, epi, st));
+  }
+  if (target != nullptr && loss3 != nullptr) GS_TRY(gnnsaft_mape(out, target, g * d->num_para, loss3, st));
+  return GNNSAFT_OK;
+}

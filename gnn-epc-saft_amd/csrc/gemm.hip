@@ -1,0 +1,396 @@
+// f32 matrix-core GEMM for gfx950:  out = epilogue( A_virtual  x  W^T + b ).
+//
+// One kernel template serves every dense op of the PNAPCSAFT forward
+// (/root/reference/gnnepcsaft/train/models.py:84-103,128 and PyG PNAConv's
+// pre_nns / post_nns / edge_encoder / lin).  The A operand is produced by a
+// "provider" while it is staged global -> registers -> LDS, so the tensors
+// PyG materialises ([E',T,3F] message input, [N,T,13F] update input) never
+// exist in HBM:
+//   PlainA : a row-major matrix, optional ReLU on load (extra pre/post layers)
+//   PostA  : cat[x_i, A, A*amp_i, A*att_i]   (PNAConv update, scalers on load)
+//   EdgeA  : relu(pq[dst_r] + pq[src_r] + rtab[combo_r])  (2nd pre-layer input)
+//
+// Arithmetic: __builtin_amdgcn_mfma_f32_32x32x2f32 (v_mfma_f32_32x32x2_f32),
+// exact f32 fma chains -- bf16 MFMA is not admissible under the 1e-5 parity
+// bar.  256 threads = 4 waves, every wave owns a 64 x (32|64) accumulator
+// tile; BK = 32; LDS rows are padded to 36 floats so that the ds_read_b128
+// fragment reads and the ds_write_b128 staging writes are conflict-free.
+// K order inside a BK tile is permuted identically for A and B (lane half h
+// reads k = 8g+4h .. 8g+4h+3), which only changes the (unspecified) summation
+// order of the dot product.
+#include "common.hpp"
+
+namespace gs {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+// --------------------------------------------------------------------------
+// A operand providers
+// --------------------------------------------------------------------------
+struct PlainA {
+  const float *a;
+  int64_t lda;
+  int relu;
+  int64_t m;
+  int k;
+  struct Row {
+    const float *p;
+  };
+  __device__ __forceinline__ Row row(int64_t r, int64_t a_off) const {
+    return Row{r < m ? a + r * lda + a_off : nullptr};
+  }
+  __device__ __forceinline__ f32x4 load(const Row &r, int kk) const {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r.p != nullptr && kk < k) {
+      v = gs_ld4(r.p + kk);
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f);
+        v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f);
+        v.w = fmaxf(v.w, 0.f);
+      }
+    }
+    return v;
+  }
+};
+
+struct PostA {
+  const float *x;        // [N,F]
+  const float *agg;      // [N,2,4F]
+  const float *log_amp;  // [N]
+  const float *log_att;  // [N]
+  const float *avg;      // device [1]
+  int64_t n;
+  int f;
+  struct Row {
+    const float *px;
+    const float *pa;
+    float amp, att;
+  };
+  __device__ __forceinline__ Row row(int64_t r, int64_t a_off) const {
+    Row o{nullptr, nullptr, 0.f, 0.f};
+    if (r < n) {
+      const float avgv = avg[0];
+      o.px = x + r * f;
+      o.pa = agg + r * (int64_t)(8 * f) + a_off;
+      o.amp = log_amp[r] / avgv;
+      o.att = avgv / log_att[r];
+    }
+    return o;
+  }
+  __device__ __forceinline__ f32x4 load(const Row &r, int kk) const {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r.px != nullptr) {
+      if (kk < f) {
+        v = gs_ld4(r.px + kk);
+      } else {
+        const int j = kk - f;
+        const int seg = j / (4 * f);
+        const int off = j - seg * 4 * f;
+        v = gs_ld4(r.pa + off);
+        const float s = seg == 0 ? 1.f : (seg == 1 ? r.amp : r.att);
+        if (seg != 0) {
+          v.x *= s;
+          v.y *= s;
+          v.z *= s;
+          v.w *= s;
+        }
+      }
+    }
+    return v;
+  }
+};
+
+struct EdgeA {
+  const int32_t *src;
+  const int32_t *dst;
+  const int32_t *combo;
+  const float *pq;    // [N,4F]
+  const float *rtab;  // [C,2F]
+  int64_t rows;
+  int f;
+  struct Row {
+    const float *p;
+    const float *q;
+    const float *r;
+  };
+  __device__ __forceinline__ Row row(int64_t r, int64_t a_off) const {
+    Row o{nullptr, nullptr, nullptr};
+    if (r < rows) {
+      o.p = pq + (int64_t)dst[r] * (4 * f) + a_off;
+      o.q = pq + (int64_t)src[r] * (4 * f) + 2 * f + a_off;
+      o.r = rtab + (int64_t)combo[r] * (2 * f) + a_off;
+    }
+    return o;
+  }
+  __device__ __forceinline__ f32x4 load(const Row &r, int kk) const {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r.p != nullptr) {
+      const f32x4 a = gs_ld4(r.p + kk), b = gs_ld4(r.q + kk), c = gs_ld4(r.r + kk);
+      v.x = fmaxf(a.x + b.x + c.x, 0.f);
+      v.y = fmaxf(a.y + b.y + c.y, 0.f);
+      v.z = fmaxf(a.z + b.z + c.z, 0.f);
+      v.w = fmaxf(a.w + b.w + c.w, 0.f);
+    }
+    return v;
+  }
+};
+
+struct GemmBatch {
+  GemmBatchEntry e[kMaxGemmBatch];
+};
+
+struct EpiArgs {
+  const float *scale;
+  const float *shift;
+  int relu_out;
+  const float *residual;
+  int64_t ldr;
+  float *stats;
+};
+
+// --------------------------------------------------------------------------
+// kernel
+// --------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, class AProv>
+__global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int64_t ldw, int64_t ldo, int64_t m,
+                                                   int n_out, int k, EpiArgs epi) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int WTM = BM / WAVES_M;
+  constexpr int WTN = BN / WAVES_N;
+  static_assert(WTM == kBnRowsPerGroup, "BatchNorm partials assume 64 rows per wave");
+  constexpr int TM = WTM / 32;
+  constexpr int TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile is a multiple of the 32x32 MFMA");
+  constexpr int A_LD4 = BM * (BK / 4) / 256;
+  constexpr int B_LD4 = (BN * (BK / 4) + 255) / 256;
+  constexpr int STAGE = (BM + BN) * LDS_LD;
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const GemmBatchEntry ent = batch.e[blockIdx.z];
+
+  // staging map: 8 float4 per 32-float row; thread -> (row r0 + 32 j, float4 column c4)
+  const int c4 = tid & 7;
+  const int r0 = tid >> 3;
+
+  typename AProv::Row arow[A_LD4];
+#pragma unroll
+  for (int j = 0; j < A_LD4; ++j) arow[j] = ap.row(m0 + r0 + 32 * j, ent.a_off);
+  const float *wrow[B_LD4];
+#pragma unroll
+  for (int j = 0; j < B_LD4; ++j) {
+    const int n = n0 + r0 + 32 * j;
+    wrow[j] = (r0 + 32 * j < BN && n < n_out) ? ent.w + (int64_t)n * ldw : nullptr;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[A_LD4], rb[B_LD4];
+  const int nk = (k + BK - 1) / BK;
+
+  auto fetch = [&](int kt) {
+    const int kk = kt * BK + c4 * 4;
+#pragma unroll
+    for (int j = 0; j < A_LD4; ++j) ra[j] = ap.load(arow[j], kk);
+#pragma unroll
+    for (int j = 0; j < B_LD4; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (wrow[j] != nullptr && kk < k) v = gs_ld4(wrow[j] + kk);
+      rb[j] = v;
+    }
+  };
+  auto stash = [&](int buf) {
+    float *as = lds + buf * STAGE;
+    float *bs = as + BM * LDS_LD;
+#pragma unroll
+    for (int j = 0; j < A_LD4; ++j) gs_st4(as + (r0 + 32 * j) * LDS_LD + c4 * 4, ra[j]);
+#pragma unroll
+    for (int j = 0; j < B_LD4; ++j)
+      if (r0 + 32 * j < BN) gs_st4(bs + (r0 + 32 * j) * LDS_LD + c4 * 4, rb[j]);
+  };
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 4;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) fetch(kt + 1);
+    const float *as = lds + (kt & 1) * STAGE + (wm * WTM + frag_row) * LDS_LD + frag_k;
+    const float *bs = lds + (kt & 1) * STAGE + BM * LDS_LD + (wn * WTN + frag_row) * LDS_LD + frag_k;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = gs_ld4(as + i * 32 * LDS_LD + g * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = gs_ld4(bs + j * 32 * LDS_LD + g * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) stash((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31,
+  //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int half = lane >> 5;
+  const int64_t wrow0 = m0 + wm * WTM;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + (lane & 31);
+    const bool col_ok = col < n_out;
+    const float bias = (col_ok && ent.bias != nullptr) ? ent.bias[col] : 0.f;
+
+    if (epi.stats != nullptr) {
+      // (mean, M2) of this wave's 64 rows for column `col`: two in-register
+      // passes per lane half, then Chan's pairwise combine across the halves.
+      float sum = 0.f;
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < m) {
+            sum += acc[i][j][r] + bias;
+            ++cnt;
+          }
+        }
+      const float mean = cnt > 0 ? sum / (float)cnt : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < m) {
+            const float d = (acc[i][j][r] + bias) - mean;
+            m2 += d * d;
+          }
+        }
+      const float o_mean = __shfl_xor(mean, 32);
+      const float o_m2 = __shfl_xor(m2, 32);
+      const int o_cnt = __shfl_xor(cnt, 32);
+      const int tot = cnt + o_cnt;
+      if (half == 0 && col_ok && tot > 0) {
+        const float delta = o_mean - mean;
+        const float cmean = mean + delta * ((float)o_cnt / (float)tot);
+        const float cm2 = m2 + o_m2 + delta * delta * ((float)cnt * (float)o_cnt / (float)tot);
+        const int64_t group = (int64_t)blockIdx.x * WAVES_M + wm;
+        epi.stats[(group * 2 + 0) * n_out + col] = cmean;
+        epi.stats[(group * 2 + 1) * n_out + col] = cm2;
+      }
+    }
+
+    float sc = 1.f, sh = 0.f;
+    if (epi.scale != nullptr && col_ok) {
+      sc = epi.scale[col];
+      sh = epi.shift[col];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < m && col_ok) {
+          float v = acc[i][j][r] + bias;
+          if (epi.scale != nullptr) v = v * sc + sh;
+          if (epi.relu_out) v = fmaxf(v, 0.f);
+          if (epi.residual != nullptr) v += epi.residual[row * epi.ldr + col];
+          ent.out[row * ldo + col] = v;
+        }
+      }
+  }
+}
+
+// --------------------------------------------------------------------------
+// host-side dispatch
+// --------------------------------------------------------------------------
+template <class AProv>
+static int dispatch(const AProv &ap, int nbatch, const GemmBatchEntry *entries, int64_t ldw, int64_t ldo, int64_t m,
+                    int n_out, int k, const LinearEpilogue &epi, hipStream_t stream) {
+  GS_REQUIRE(nbatch >= 1 && nbatch <= kMaxGemmBatch, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(m >= 0 && n_out >= 1 && k >= 4 && (k % 4) == 0 && (ldw % 4) == 0, GNNSAFT_ERR_SHAPE);
+  if (m == 0) return GNNSAFT_OK;
+  GemmBatch b;
+  for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entries[i < nbatch ? i : 0];
+  for (int i = 0; i < nbatch; ++i) {
+    GS_REQUIRE(entries[i].w != nullptr && entries[i].out != nullptr, GNNSAFT_ERR_NULL);
+    GS_REQUIRE((reinterpret_cast<uintptr_t>(entries[i].w) & 15) == 0, GNNSAFT_ERR_SHAPE);
+  }
+  EpiArgs ea{epi.scale, epi.shift, epi.relu_out, epi.residual, epi.ldr, epi.stats};
+  GS_REQUIRE((epi.scale == nullptr) == (epi.shift == nullptr), GNNSAFT_ERR_NULL);
+  GS_REQUIRE(epi.stats == nullptr || nbatch == 1, GNNSAFT_ERR_SHAPE);
+  const dim3 block(256);
+  if (n_out <= 32) {
+    const dim3 grid((unsigned)gs_ceil_div(m, 256), (unsigned)gs_ceil_div(n_out, 32), (unsigned)nbatch);
+    hipLaunchKernelGGL((k_gemm_f32<256, 32, 4, 1, AProv>), grid, block, 0, stream, ap, b, ldw, ldo, m, n_out, k, ea);
+  } else if (n_out <= 64 || (n_out % 128) == 64) {
+    const dim3 grid((unsigned)gs_ceil_div(m, 128), (unsigned)gs_ceil_div(n_out, 64), (unsigned)nbatch);
+    hipLaunchKernelGGL((k_gemm_f32<128, 64, 2, 2, AProv>), grid, block, 0, stream, ap, b, ldw, ldo, m, n_out, k, ea);
+  } else {
+    const dim3 grid((unsigned)gs_ceil_div(m, 128), (unsigned)gs_ceil_div(n_out, 128), (unsigned)nbatch);
+    hipLaunchKernelGGL((k_gemm_f32<128, 128, 2, 2, AProv>), grid, block, 0, stream, ap, b, ldw, ldo, m, n_out, k, ea);
+  }
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const GemmBatchEntry *entries, int64_t ldw,
+                  int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi, hipStream_t stream) {
+  GS_REQUIRE(a != nullptr, GNNSAFT_ERR_NULL);
+  GS_REQUIRE((lda % 4) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0, GNNSAFT_ERR_SHAPE);
+  PlainA ap{a, lda, relu_in, m, k};
+  return dispatch(ap, nbatch, entries, ldw, ldo, m, n_out, k, epi, stream);
+}
+
+int launch_pna_update(const float *x, const float *agg, const float *log_amp, const float *log_att,
+                      const float *avg_deg_log, int64_t n, int hidden, const GemmBatchEntry *entries, int64_t ldo,
+                      hipStream_t stream) {
+  GS_REQUIRE(x && agg && log_amp && log_att && avg_deg_log, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
+  PostA ap{x, agg, log_amp, log_att, avg_deg_log, n, hidden};
+  GemmBatchEntry e[2] = {entries[0], entries[1]};
+  e[0].a_off = 0;
+  e[1].a_off = 4 * (int64_t)hidden;
+  LinearEpilogue epi;
+  return dispatch(ap, 2, e, 13 * (int64_t)hidden, ldo, n, hidden / 2, 13 * hidden, epi, stream);
+}
+
+int launch_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *combo, int64_t rows, int hidden,
+                        const float *pq, const float *rtab, const GemmBatchEntry *entries, int64_t ldo,
+                        hipStream_t stream) {
+  GS_REQUIRE(src && dst && combo && pq && rtab, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
+  EdgeA ap{src, dst, combo, pq, rtab, rows, hidden};
+  GemmBatchEntry e[2] = {entries[0], entries[1]};
+  e[0].a_off = 0;
+  e[1].a_off = hidden;
+  LinearEpilogue epi;
+  return dispatch(ap, 2, e, hidden, ldo, rows, hidden, hidden, epi, stream);
+}
+
+}  // namespace gs

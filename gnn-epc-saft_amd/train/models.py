@@ -1,0 +1,345 @@
+"""MI355X-native ``PNAPCSAFT``: same constructor, ``forward(data)`` signature,
+duck-typed PyG ``Data`` / ``Batch`` input and ``state_dict`` keys as
+``/root/reference/gnnepcsaft/train/models.py:48-135``, but the arithmetic runs
+in hand-written gfx950 kernels behind the C ABI of ``include/gnnsaft.h``.
+
+The sub-modules below are parameter containers only (they reproduce the
+attribute names PyG / ogb give their parameters -- SURVEY.md Appendix C -- so
+reference checkpoints load with ``load_state_dict``); none of them computes
+anything.  There is no CPU, fp64 or PyTorch-eager fallback: tensors that are
+not float32 on a HIP device raise.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from .. import _native
+from .._native import ModelDesc, check, lib
+
+ATOM_FEATURE_DIMS = (119, 5, 12, 12, 10, 6, 6, 2, 2)  # ogb >= 1.3
+BOND_FEATURE_DIMS = (5, 6, 2)
+TOWERS = 2  # models.py:76
+
+
+@dataclasses.dataclass
+class PnaconvsParams:
+    """models.py:28-37"""
+    propagation_depth: int
+    pre_layers: int
+    post_layers: int
+    deg: torch.Tensor
+    dropout: float = 0.0
+    skip_connections: bool = False
+    self_loops: bool = False
+
+
+@dataclasses.dataclass
+class ReadoutMLPParams:
+    """models.py:40-45"""
+    num_mlp_layers: int
+    num_para: int
+    dropout: float = 0.0
+
+
+# --------------------------------------------------------------------------
+# parameter containers (names only)
+# --------------------------------------------------------------------------
+class _ParamsOnly(nn.Module):
+    def forward(self, *args, **kwargs):  # pragma: no cover - never part of the compute path
+        raise RuntimeError(f"{type(self).__name__} only stores parameters; the arithmetic lives in libgnnsaft.so")
+
+
+class _CategoricalTables(_ParamsOnly):
+    def __init__(self, list_name: str, dims: Sequence[int], width: int):
+        super().__init__()
+        tables = nn.ModuleList()
+        for d in dims:
+            table = nn.Embedding(int(d), width)
+            nn.init.xavier_uniform_(table.weight.data)  # ogb initialisation
+            tables.append(table)
+        setattr(self, list_name, tables)
+        self._list_name = list_name
+
+    def tables(self) -> List[nn.Embedding]:
+        return list(getattr(self, self._list_name))
+
+
+class _DegreeStatistics(_ParamsOnly):
+    def __init__(self, deg: torch.Tensor):
+        super().__init__()
+        hist = deg.detach().to("cpu", torch.float)
+        total = int(hist.sum())
+        if total <= 0:
+            raise ValueError("deg histogram must contain at least one node")
+        bins = torch.arange(hist.numel())
+        self.register_buffer("avg_deg_lin", torch.full((1,), float((bins * hist).sum()) / total))
+        self.register_buffer("avg_deg_log", torch.full((1,), float(((bins + 1).log() * hist).sum()) / total))
+
+
+def _tower_stack(n_in: int, width: int, depth: int) -> nn.Sequential:
+    layers: List[nn.Module] = [nn.Linear(n_in, width)]
+    for _ in range(depth - 1):
+        layers.append(nn.ReLU())
+        layers.append(nn.Linear(width, width))
+    return nn.Sequential(*layers)
+
+
+class _PNAConvWeights(_ParamsOnly):
+    """Parameters of PyG ``PNAConv`` as built at models.py:69-80."""
+
+    def __init__(self, hidden: int, deg: torch.Tensor, pre_layers: int, post_layers: int):
+        super().__init__()
+        self.aggr_module = _DegreeStatistics(deg)
+        self.edge_encoder = nn.Linear(hidden, hidden)
+        self.pre_nns = nn.ModuleList([_tower_stack(3 * hidden, hidden, pre_layers) for _ in range(TOWERS)])
+        self.post_nns = nn.ModuleList(
+            [_tower_stack(13 * hidden, hidden // TOWERS, post_layers) for _ in range(TOWERS)])
+        self.lin = nn.Linear(hidden, hidden)
+
+
+class _NodeBatchNormWeights(_ParamsOnly):
+    """PyG ``BatchNorm`` keeps its BatchNorm1d under the attribute ``module``."""
+
+    def __init__(self, hidden: int):
+        super().__init__()
+        self.module = nn.BatchNorm1d(hidden)
+
+
+def _bn_tensors(bn: nn.BatchNorm1d) -> List[torch.Tensor]:
+    if not (bn.affine and bn.track_running_stats):
+        raise NotImplementedError("BatchNorm1d must be affine with running statistics (reference default)")
+    return [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
+
+
+class PNAPCSAFT(nn.Module):
+    """Graph neural network predicting ePC-SAFT parameters (models.py:48-135), MI355X kernels."""
+
+    def __init__(self, hidden_dim: int, pna_params: PnaconvsParams, mlp_params: ReadoutMLPParams,
+                 atom_feature_dims: Sequence[int] = ATOM_FEATURE_DIMS,
+                 bond_feature_dims: Sequence[int] = BOND_FEATURE_DIMS):
+        super().__init__()
+        if hidden_dim % 32 != 0 or hidden_dim < 32:
+            raise ValueError("hidden_dim must be a positive multiple of 32 (reference envelope: 64, 128, 256)")
+        self.hidden_dim = int(hidden_dim)
+        self.pna_params = pna_params
+        self.mlp_params = mlp_params
+        self.node_embed = _CategoricalTables("atom_embedding_list", atom_feature_dims, hidden_dim)
+        self.edge_embed = _CategoricalTables("bond_embedding_list", bond_feature_dims, hidden_dim)
+        self.convs = nn.ModuleList()
+        self.batch_norms = nn.ModuleList()
+        for _ in range(pna_params.propagation_depth):
+            self.convs.append(_PNAConvWeights(hidden_dim, pna_params.deg, pna_params.pre_layers,
+                                              pna_params.post_layers))
+            self.batch_norms.append(_NodeBatchNormWeights(hidden_dim))
+        h = hidden_dim
+        self.mlp = nn.Sequential()
+        for _ in range(mlp_params.num_mlp_layers):
+            for mod in (nn.Linear(h, h), nn.BatchNorm1d(h), nn.ReLU(), nn.Dropout(p=mlp_params.dropout)):
+                self.mlp.append(mod)
+        tail: List[nn.Module] = []
+        for n_in, n_out in ((h, h // 2), (h // 2, h // 4)):
+            tail += [nn.Linear(n_in, n_out), nn.BatchNorm1d(n_out), nn.ReLU(), nn.Dropout(p=mlp_params.dropout)]
+        tail.append(nn.Linear(h // 4, mlp_params.num_para))
+        self.mlp.append(nn.Sequential(*tail))
+        self._workspace: Optional[torch.Tensor] = None
+        self._err_flag: Optional[torch.Tensor] = None
+        self._loss_buf: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ host glue
+    def _weight_tensors(self) -> List[torch.Tensor]:
+        """Canonical weight table order (csrc/forward.hip header)."""
+        out: List[torch.Tensor] = [t.weight for t in self.node_embed.tables()]
+        out += [t.weight for t in self.edge_embed.tables()]
+        for conv, bn in zip(self.convs, self.batch_norms):
+            out.append(conv.aggr_module.avg_deg_log)
+            out += [conv.edge_encoder.weight, conv.edge_encoder.bias]
+            for stack in list(conv.pre_nns) + list(conv.post_nns):
+                for layer in stack:
+                    if isinstance(layer, nn.Linear):
+                        out += [layer.weight, layer.bias]
+            out += [conv.lin.weight, conv.lin.bias]
+            out += _bn_tensors(bn.module)
+        m = self.mlp_params.num_mlp_layers
+        for i in range(m):
+            out += [self.mlp[4 * i].weight, self.mlp[4 * i].bias]
+            out += _bn_tensors(self.mlp[4 * i + 1])
+        tail = self.mlp[4 * m]
+        out += [tail[0].weight, tail[0].bias] + _bn_tensors(tail[1])
+        out += [tail[4].weight, tail[4].bias] + _bn_tensors(tail[5])
+        out += [tail[8].weight, tail[8].bias]
+        return out
+
+    def _model_desc(self) -> ModelDesc:
+        d = ModelDesc()
+        d.hidden = self.hidden_dim
+        d.num_layers = len(self.convs)
+        d.pre_layers = self.pna_params.pre_layers
+        d.post_layers = self.pna_params.post_layers
+        d.num_mlp_layers = self.mlp_params.num_mlp_layers
+        d.num_para = self.mlp_params.num_para
+        d.skip_connections = int(bool(self.pna_params.skip_connections))
+        d.self_loops = int(bool(self.pna_params.self_loops))
+        d.training = int(self.training)
+        atom, bond = self.node_embed.tables(), self.edge_embed.tables()
+        d.num_atom_cols, d.num_bond_cols = len(atom), len(bond)
+        for k, t in enumerate(atom):
+            d.atom_dims[k] = t.num_embeddings
+        for k, t in enumerate(bond):
+            d.bond_dims[k] = t.num_embeddings
+        bn0 = self.batch_norms[0].module if len(self.batch_norms) else self.mlp[4 * d.num_mlp_layers][1]
+        d.bn_eps = bn0.eps
+        d.bn_momentum = 0.1 if bn0.momentum is None else bn0.momentum
+        return d
+
+    def _check_mode(self, x: torch.Tensor) -> None:
+        if not x.is_cuda:
+            raise RuntimeError("PNAPCSAFT (MI355X build) has no CPU path: move the module and the batch to a HIP "
+                               "device (`.to('cuda')`)")
+        if self.training and (self.pna_params.dropout > 0 or self.mlp_params.dropout > 0):
+            raise NotImplementedError("dropout > 0 in training mode is not implemented (the reference always "
+                                      "trains with dropout 0.0: train/utils.py:57-69, configs/default.py:41)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "the backward pass is not implemented yet (SURVEY.md section 8(f) rank 1): run the forward under "
+                "torch.no_grad() / torch.inference_mode()")
+
+    def run(self, data, target: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """Forward (+ MAPE loss when ``target`` [G,P] is given).  Returns
+        ``(pred [G,P], loss3)`` with ``loss3 = [mape, sum(ape), numel]`` on device."""
+        x = data.x
+        edge_index = data.edge_index
+        edge_attr = data.edge_attr
+        batch = getattr(data, "batch", None)
+        self._check_mode(x)
+        dev = x.device
+        if x.dtype != torch.int64 or edge_index.dtype != torch.int64 or edge_attr.dtype != torch.int64:
+            raise TypeError("x, edge_index and edge_attr must be int64 categorical indices (data/graph.py:28-37)")
+        x = x.contiguous()
+        edge_index = edge_index.contiguous()
+        edge_attr = edge_attr.contiguous()
+        n, e = int(x.shape[0]), int(edge_index.shape[1])
+        if batch is None:
+            g = 1
+        else:
+            batch = batch.contiguous()
+            g = getattr(data, "num_graphs", None)
+            if g is None:
+                g = int(batch[-1]) + 1  # sorted by PyG collate; the reference syncs here too (batch.max())
+            g = int(g)
+        desc = self._model_desc()
+        if x.shape[1] != desc.num_atom_cols or edge_attr.shape[1] != desc.num_bond_cols:
+            raise ValueError("x / edge_attr column counts do not match the embedding tables")
+        if self.training and (n < 2 or g < 2):
+            raise ValueError("Expected more than 1 value per channel when training")  # torch BatchNorm1d
+        weights = self._weight_tensors()
+        for t in weights:
+            if t.device != dev or not t.is_contiguous():
+                raise RuntimeError("all parameters and buffers must be contiguous and on the input's device")
+        for t in weights:
+            if t.dtype not in (torch.float32, torch.int64):
+                raise NotImplementedError("only float32 parameters are supported on the MI355X path "
+                                          "(fp64 callers such as evaluate_ensemble.py:68 are out of scope)")
+        nw = len(weights)
+        if nw != lib.gnnsaft_num_weights(ctypes.byref(desc)):
+            raise RuntimeError("internal error: weight table length mismatch")
+        wtab = (ctypes.c_void_p * nw)(*[t.data_ptr() for t in weights])
+
+        need = lib.gnnsaft_forward_workspace_bytes(ctypes.byref(desc), n, e, g)
+        if need == 0:
+            raise _native.GnnsaftError("configuration outside the supported shape envelope")
+        if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need:
+            self._workspace = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=dev)
+            self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._loss_buf = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._err_flag.zero_()
+        out = torch.empty((g, desc.num_para), dtype=torch.float32, device=dev)
+        tgt_ptr, loss_ptr, loss = None, None, None
+        if target is not None:
+            target = target.reshape(-1, desc.num_para).to(torch.float32).contiguous()
+            if target.shape[0] != g or target.device != dev:
+                raise ValueError("target must be [num_graphs, num_para] on the input's device")
+            loss = torch.empty(3, dtype=torch.float32, device=dev)
+            tgt_ptr, loss_ptr = target.data_ptr(), loss.data_ptr()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ws = self._workspace
+        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        with torch.cuda.device(dev):
+            rc = lib.gnnsaft_forward(ctypes.byref(desc), wtab, nw, x.data_ptr(), edge_index.data_ptr() if e else None,
+                                     edge_attr.data_ptr() if e else None,
+                                     None if batch is None else batch.data_ptr(), n, e, g, tgt_ptr, out.data_ptr(),
+                                     loss_ptr, self._err_flag.data_ptr(), ws_ptr,
+                                     ws.numel() - (ws_ptr - ws.data_ptr()), stream)
+        check(rc, "gnnsaft_forward")
+        return out, loss
+
+    def forward(self, data) -> torch.Tensor:
+        """models.py:105-135.  ``data``: anything with ``x``, ``edge_index``, ``edge_attr`` and optionally
+        ``batch`` / ``num_graphs`` attributes (PyG ``Data`` / ``Batch``)."""
+        return self.run(data)[0]
+
+    def input_error_flags(self) -> int:
+        """Synchronises and returns the OR of GNNSAFT_FLAG_* bits raised by the last forward
+        (out-of-range indices are clamped, never dereferenced)."""
+        return 0 if self._err_flag is None else int(self._err_flag.item())
+
+    def _apply(self, fn, *args, **kwargs):
+        self._workspace = None
+        return super()._apply(fn, *args, **kwargs)
+
+
+class PNApcsaftL(nn.Module):
+    """Host-side mirror of the LightningModule at models.py:138-251, limited to the
+    hot path: ``forward`` (:155-160) and the MAPE loss of ``training_step``
+    (:191-202).  Lightning itself is absent from the image; validation needs
+    ``feos`` and is out of scope (component 2)."""
+
+    def __init__(self, pna_params: PnaconvsParams, mlp_params: ReadoutMLPParams, config):
+        super().__init__()
+        self.config = config
+        self.model = PNAPCSAFT(_cfg(config, "hidden_dim"), pna_params=pna_params, mlp_params=mlp_params)
+
+    def forward(self, data) -> torch.Tensor:
+        return self.model(data)
+
+    def training_step(self, graphs, batch_idx=None) -> torch.Tensor:
+        """target = graphs.para.view(-1, num_para); returns mean |pred - target| / max(|target|, 1.17e-6)."""
+        _, loss = self.model.run(graphs, target=graphs.para.view(-1, _cfg(self.config, "num_para")))
+        return loss[0]
+
+    def training_step_parts(self, graphs) -> torch.Tensor:
+        """[mape, sum of absolute percentage errors, element count] -- the pair that is all-reduced
+        across ranks (``sync_dist=True`` at models.py:195-201)."""
+        return self.model.run(graphs, target=graphs.para.view(-1, _cfg(self.config, "num_para")))[1]
+
+    def configure_optimizers(self):
+        """models.py:162-188."""
+        opt_name = _cfg(self.config, "optimizer")
+        if opt_name == "adam":
+            opt = torch.optim.AdamW(self.parameters(), lr=_cfg(self.config, "learning_rate"),
+                                    weight_decay=_cfg(self.config, "weight_decay"), amsgrad=True, eps=1e-5)
+        elif opt_name == "sgd":
+            opt = torch.optim.SGD(self.parameters(), lr=_cfg(self.config, "learning_rate"),
+                                  momentum=_cfg(self.config, "momentum"),
+                                  weight_decay=_cfg(self.config, "weight_decay"), nesterov=True)
+        else:
+            raise ValueError(f"Unsupported optimizer: {opt_name}.")
+        sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, _cfg(self.config, "warmup_steps"))
+        return {"optimizer": opt, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}
+
+    def validation_step(self, graphs, batch_idx=None):
+        raise NotImplementedError("validation scores predictions with feos on the CPU (models.py:204-248); "
+                                  "out of scope for the MI355X hot path")
+
+
+def _cfg(config, name: str):
+    """ml_collections.ConfigDict, dict or attribute bag."""
+    if isinstance(config, dict):
+        return config[name]
+    return getattr(config, name)

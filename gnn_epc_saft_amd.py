@@ -1,0 +1,13 @@
+"""Import shim: ``import gnn_epc_saft_amd`` resolves to the package stored in the
+hyphenated directory ``gnn-epc-saft_amd/`` next to this file."""
+
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gnn-epc-saft_amd")
+_spec = importlib.util.spec_from_file_location(__name__, os.path.join(_dir, "__init__.py"),
+                                               submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

@@ -1,0 +1,261 @@
+/*
+ * gnnsaft.h -- C ABI of the MI355X (gfx950) implementation of the GNN-ePC-SAFT
+ * message-passing forward (PNAPCSAFT.forward + MAPE training loss).
+ *
+ * Reference interface this library replaces (all paths relative to
+ * /root/reference): the reference has NO native code; the seam is the Python
+ * method gnnepcsaft/train/models.py:105-135 (PNAPCSAFT.forward) and the loss
+ * at models.py:191-194, whose arithmetic is executed by third-party ATen
+ * kernels issued by PyG / ogb / torchmetrics ("implicit
+ * device ops" table).  Every entry point below names the reference line(s)
+ * whose arithmetic it performs.  A maintainer binds this file with ctypes
+ * (see INTEGRATION.md); no torch type appears in any signature.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter says "host";
+ *   - float tensors are row-major f32, index tensors are int64 exactly as PyG
+ *     delivers them (x [N,C], edge_index [2,E], edge_attr [E,B], batch [N]);
+ *   - all work is enqueued on `stream` (a hipStream_t); no entry point
+ *     synchronises, allocates or frees device memory (graph-capture safe);
+ *   - return value: 0 = ok, >0 = hipError_t, <0 = GNNSAFT_ERR_*;
+ *   - invalid indices never fault: they are clamped and bit(s) are OR-ed into
+ *     the int32 word `err_flag` (may be NULL), see GNNSAFT_FLAG_*.
+ */
+#ifndef GNNSAFT_H
+#define GNNSAFT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNSAFT_ABI_VERSION 1
+
+#define GNNSAFT_OK 0
+#define GNNSAFT_ERR_SHAPE (-1)      /* unsupported / inconsistent sizes          */
+#define GNNSAFT_ERR_WORKSPACE (-2)  /* workspace too small                       */
+#define GNNSAFT_ERR_NULL (-3)       /* required pointer is NULL                  */
+#define GNNSAFT_ERR_UNSUPPORTED (-4)/* configuration outside the shape envelope  */
+
+#define GNNSAFT_FLAG_BAD_EDGE 1     /* edge_index value outside [0,N)            */
+#define GNNSAFT_FLAG_BAD_ATTR 2     /* categorical index outside its vocabulary  */
+#define GNNSAFT_FLAG_BAD_BATCH 4    /* batch not sorted / outside [0,G)          */
+
+#define GNNSAFT_MAX_TABLES 16
+#define GNNSAFT_TOWERS 2            /* models.py:76 towers=2                      */
+
+typedef void *gnnsaft_stream_t;     /* hipStream_t */
+
+int gnnsaft_abi_version(void);
+const char *gnnsaft_error_string(int code);
+
+/* ------------------------------------------------------------------------ */
+/* K0: graph structure.  Replaces add_self_loops (models.py:118-121) and the  */
+/* per-layer index_select / scatter index plumbing PyG re-derives from the    */
+/* unsorted edge list: builds ONE destination-sorted CSR per batch, reused by */
+/* all layers.  Edges of a node keep their edge_index order; the self-loop    */
+/* (if enabled) is the LAST in-edge of every node, as the reference appends   */
+/* loops after all real edges.  combo[r] is the mixed-radix id of the edge's   */
+/* categorical attributes (self-loop = all-zero attributes = id 0).           */
+/* log_amp[i] = log(deg_i + 1), log_att[i] = log(max(deg_i,1) + 1) with deg_i  */
+/* the run-time in-degree INCLUDING the self-loop (PyG DegreeScalerAggregation).*/
+/* ------------------------------------------------------------------------ */
+size_t gnnsaft_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges);
+
+int gnnsaft_csr_build(const int64_t *edge_index, const int64_t *edge_attr,
+                      int64_t num_nodes, int64_t num_edges,
+                      int32_t num_bond_cols, const int32_t *bond_dims_host,
+                      int32_t self_loops,
+                      int32_t *rowptr,   /* [N+1]            */
+                      int32_t *src,      /* [E'] E'=E+N*loops */
+                      int32_t *dst,      /* [E'] destination of CSR row r */
+                      int32_t *combo,    /* [E']             */
+                      float *log_amp,    /* [N]              */
+                      float *log_att,    /* [N]              */
+                      int32_t *err_flag, void *workspace, size_t workspace_bytes,
+                      gnnsaft_stream_t stream);
+
+/* graph pointer from PyG's sorted `batch` vector (global_add_pool, models.py:133) */
+int gnnsaft_batch_to_ptr(const int64_t *batch, int64_t num_nodes, int64_t num_graphs,
+                         int32_t *graph_ptr /* [G+1] */, int32_t *err_flag,
+                         gnnsaft_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* K1: ogb AtomEncoder / BondEncoder (models.py:65-66,122-123): out[i,:] =     */
+/* sum_k table_k[idx[i,k], :], left-to-right.  `tables_host` is a HOST array   */
+/* of `num_cols` device pointers, `dims_host` the vocabulary sizes.            */
+/* ------------------------------------------------------------------------ */
+int gnnsaft_embed_sum(const int64_t *idx, int64_t num_rows, int32_t num_cols,
+                      const float *const *tables_host, const int32_t *dims_host,
+                      int32_t hidden, float *out, int32_t *err_flag,
+                      gnnsaft_stream_t stream);
+
+/* BondEncoder evaluated once per attribute combination instead of once per   */
+/* edge: out[c,:] = sum_k table_k[digit_k(c), :], c in [0, prod(dims)).        */
+int gnnsaft_bond_combo_embed(int32_t num_cols, const float *const *tables_host,
+                             const int32_t *dims_host, int32_t hidden, float *out,
+                             gnnsaft_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* Dense layer on the f32 matrix cores: out = act_out(act_in(A) W^T + b).     */
+/* torch.nn.Linear / PyG Linear as used at models.py:84-103 and inside        */
+/* PNAConv (edge_encoder, lin, extra pre/post layers).  W is [n_out, ldw]     */
+/* row-major (torch layout), columns [0,k) are used.  `stats` (may be NULL)   */
+/* receives per-row-group (mean, M2) column partials for train-mode BatchNorm */
+/* ([ceil(M/rows_per_group), 2, n_out], rows_per_group from                   */
+/* gnnsaft_bn_rows_per_group()).  If scale/shift are non-NULL the epilogue    */
+/* applies y*scale[c]+shift[c] (eval-mode BatchNorm folded), then ReLU if     */
+/* relu_out, then adds residual[row,c] if non-NULL.                           */
+/* ------------------------------------------------------------------------ */
+int gnnsaft_linear(const float *a, int64_t lda, int32_t relu_in,
+                   const float *w, int64_t ldw, const float *bias,
+                   float *out, int64_t ldo,
+                   int64_t m, int32_t n_out, int32_t k,
+                   const float *scale, const float *shift, int32_t relu_out,
+                   const float *residual, int64_t ldr,
+                   float *stats, gnnsaft_stream_t stream);
+
+int32_t gnnsaft_bn_rows_per_group(void);
+
+/* ------------------------------------------------------------------------ */
+/* PNAConv message, first pre-layer (PyG PNAConv.message; models.py:69-80,128):*/
+/* pre_nns[t][0](cat[x_dst, x_src, edge_encoder(e)]) split by linearity into   */
+/*   pq[i, 0:2F]  = [W_t[:,0:F]   x_i]_t   (destination term, per node)        */
+/*   pq[i, 2F:4F] = [W_t[:,F:2F]  x_i]_t   (source term, per node)             */
+/*   rtab[c, 0:2F] = [W_t[:,2F:3F] (W_e emb_c + b_e) + b_t]_t  (per edge class) */
+/* so that msg[e,t,:] = pq[dst,tF:(t+1)F] + pq[src,2F+tF:...] + rtab[c(e),...]. */
+/* ------------------------------------------------------------------------ */
+int gnnsaft_pna_node_terms(const float *x, int64_t num_nodes, int32_t hidden,
+                           const float *w_pre0, const float *w_pre1, /* [F,3F] each */
+                           float *pq /* [N,4F] */, gnnsaft_stream_t stream);
+
+int gnnsaft_pna_edge_table(const float *combo_emb, int32_t num_combos, int32_t hidden,
+                           const float *w_edge, const float *b_edge,   /* edge_encoder */
+                           const float *w_pre0, const float *b_pre0,
+                           const float *w_pre1, const float *b_pre1,
+                           float *enc_tmp /* [C,F] scratch */, float *rtab /* [C,2F] */,
+                           gnnsaft_stream_t stream);
+
+/* remaining pre-layers (pre_layers >= 2): msgs[r,t,:] =                       */
+/*   W2_t relu(pq[dst_r] + pq[src_r] + rtab[combo_r]) + b2_t  in CSR row order. */
+int gnnsaft_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *combo,
+                         int64_t num_rows, int32_t hidden,
+                         const float *pq, const float *rtab,
+                         const float *w2_t0, const float *b2_t0,
+                         const float *w2_t1, const float *b2_t1,
+                         float *msgs /* [E',2F] */, gnnsaft_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* K4 (the measured "scatter-add" kernel): PyG MultiAggregation               */
+/* [mean,min,max,std] over the in-edges of every node (models.py:59,128):      */
+/* one pass over the destination-sorted rows, sum / sum-of-squares / min / max */
+/* kept in registers, no atomics, bitwise reproducible.                        */
+/*   agg[i,t,:] = [mean | min | max | std]  ([N, 2, 4F])                       */
+/* std = sqrt(clamp(mean(m^2) - mean(m)^2, 1e-5)), zeroed where <= sqrt(1e-5). */
+/* Exactly one of (pq,rtab) / msgs is used: msgs == NULL selects the fused     */
+/* gather form for pre_layers == 1.                                            */
+/* ------------------------------------------------------------------------ */
+int gnnsaft_pna_aggregate(const int32_t *rowptr, const int32_t *src, const int32_t *combo,
+                          int64_t num_nodes, int32_t hidden,
+                          const float *pq, const float *rtab, const float *msgs,
+                          float *agg, gnnsaft_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* PNAConv update, first post-layer (PyG PNAConv.forward; models.py:128):      */
+/* u[i, tF/2:(t+1)F/2] = post_nns[t][0](cat[x_i, A, A*amp_i, A*att_i]) with    */
+/* A = agg[i,t,:], amp_i = log_amp[i]/avg_deg_log, att_i = avg_deg_log/log_att[i];*/
+/* the [N,T,13F] input is never materialised (scalers applied on operand load).*/
+/* ------------------------------------------------------------------------ */
+int gnnsaft_pna_update(const float *x, const float *agg, const float *log_amp,
+                       const float *log_att, const float *avg_deg_log /* device, [1] */,
+                       int64_t num_nodes, int32_t hidden,
+                       const float *w_post0, const float *b_post0, /* [F/2,13F] */
+                       const float *w_post1, const float *b_post1,
+                       float *u /* [N,F] */, gnnsaft_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* BatchNorm (PyG BatchNorm -> torch BatchNorm1d, models.py:82,87,94,98,128).  */
+/* training != 0: combine the (mean, M2) partials written by gnnsaft_linear    */
+/* into batch statistics, update running_mean / running_var (unbiased) /       */
+/* num_batches_tracked, and emit scale = gamma*rstd, shift = beta - mean*scale.*/
+/* training == 0: scale / shift from the running statistics.                   */
+/* ------------------------------------------------------------------------ */
+int gnnsaft_bn_finalize(const float *stats, int64_t num_rows, int32_t channels,
+                        const float *gamma, const float *beta,
+                        float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                        float momentum, float eps, int32_t training,
+                        float *scale, float *shift, gnnsaft_stream_t stream);
+
+/* out = relu(y*scale + shift) (+ residual)   (models.py:128-131) */
+int gnnsaft_bn_relu_residual(const float *y, const float *scale, const float *shift,
+                             const float *residual, float *out,
+                             int64_t num_rows, int32_t channels, gnnsaft_stream_t stream);
+
+/* global_add_pool (models.py:133): out[g,:] = sum of rows graph_ptr[g]..graph_ptr[g+1]-1 */
+int gnnsaft_add_pool(const float *x, const int32_t *graph_ptr, int64_t num_graphs,
+                     int64_t num_nodes, int32_t hidden, float *out, gnnsaft_stream_t stream);
+
+/* torchmetrics MAPE (models.py:194): out[0] = sum(|p-t| / max(|t|,1.17e-6)) / n, */
+/* out[1] = the sum, out[2] = n (for the cross-rank all-reduce).                 */
+int gnnsaft_mape(const float *pred, const float *target, int64_t numel, float *out3,
+                 gnnsaft_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* Whole network: PNAPCSAFT.forward (models.py:105-135) + optional MAPE loss   */
+/* (models.py:191-194) enqueued as one call.                                   */
+/* `weights_host`: HOST array of device pointers in the canonical order        */
+/* documented in DESIGN.md ("weight table"); `num_weights` guards it.          */
+/* ------------------------------------------------------------------------ */
+typedef struct gnnsaft_model_desc {
+  int32_t hidden;            /* H in {64,128,256}; must be a multiple of 32    */
+  int32_t num_layers;        /* propagation_depth                              */
+  int32_t pre_layers;        /* >= 1                                           */
+  int32_t post_layers;       /* >= 1                                           */
+  int32_t num_mlp_layers;    /* >= 0                                           */
+  int32_t num_para;          /* P                                              */
+  int32_t skip_connections;
+  int32_t self_loops;
+  int32_t training;          /* BatchNorm mode                                 */
+  int32_t num_atom_cols;
+  int32_t num_bond_cols;
+  int32_t atom_dims[GNNSAFT_MAX_TABLES];
+  int32_t bond_dims[GNNSAFT_MAX_TABLES];
+  float bn_eps;
+  float bn_momentum;
+} gnnsaft_model_desc;
+
+int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);
+
+size_t gnnsaft_forward_workspace_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes,
+                                       int64_t num_edges, int64_t num_graphs);
+
+int gnnsaft_forward(const gnnsaft_model_desc *desc,
+                    const void *const *weights_host, int32_t num_weights,
+                    const int64_t *x, const int64_t *edge_index, const int64_t *edge_attr,
+                    const int64_t *batch /* NULL => single graph */,
+                    int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
+                    const float *target /* [G,P] or NULL */,
+                    float *out /* [G,P] */, float *loss3 /* [3] or NULL */,
+                    int32_t *err_flag /* device int32, zeroed by the caller, or NULL */,
+                    void *workspace, size_t workspace_bytes, gnnsaft_stream_t stream);
+
+/* Debug / test taps: after gnnsaft_forward, byte offsets of intermediate      */
+/* tensors inside the workspace (node state after each layer etc.).            */
+typedef struct gnnsaft_workspace_map {
+  size_t rowptr, src, dst, combo, log_amp, log_att, graph_ptr;
+  size_t x_embed;   /* [N,H] node embedding                                    */
+  size_t x_final;   /* [N,H] node state after the last layer                   */
+  size_t pq, agg, u, y, rtab, pooled;
+  size_t total;
+} gnnsaft_workspace_map;
+
+int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int64_t num_nodes,
+                                  int64_t num_edges, int64_t num_graphs,
+                                  gnnsaft_workspace_map *map);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNSAFT_H */

@@ -1,0 +1,74 @@
+"""Shared test plumbing: model pairs (HIP module + CPU oracle with one state_dict),
+the parity metric, and small hand-built graphs."""
+
+from __future__ import annotations
+
+import copy
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from gnn_epc_saft_amd.data.synthetic import (GraphData, collate, degree_histogram, ethanol_all_atom, ethanol_heavy,
+                                             make_synthetic_batch)
+from oracle.pna_torch import OracleMlpParams, OraclePNAPCSAFT, OraclePnaParams
+
+
+def oracle_model(hidden, depth, pre, post, mlp, num_para, skip, loops, deg, seed=0, dtype=torch.float32):
+    torch.manual_seed(seed)
+    m = OraclePNAPCSAFT(hidden, OraclePnaParams(depth, pre, post, deg, skip_connections=skip, self_loops=loops),
+                        OracleMlpParams(mlp, num_para))
+    randomize_norm_state(m, seed)
+    return m.to(dtype)
+
+
+def randomize_norm_state(model: torch.nn.Module, seed: int) -> None:
+    """Default BatchNorm state (gamma=1, beta=0, mean=0, var=1) hides bugs in the affine /
+    running-statistics plumbing: perturb it deterministically."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            with torch.no_grad():
+                mod.weight.copy_(1.0 + 0.2 * torch.randn(mod.weight.shape, generator=g))
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+                mod.running_mean.copy_(0.3 * torch.randn(mod.running_mean.shape, generator=g))
+                mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max |a-b| / max|b|: error relative to the scale of the reference tensor."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    scale = float(b.abs().max())
+    if scale == 0.0:
+        return float((a - b).abs().max())
+    return float((a - b).abs().max()) / scale
+
+
+def mini4() -> GraphData:
+    """4 graphs: a ring of 5, a single isolated atom (0 edges), a 2-atom molecule, a branched 6-atom tree."""
+    g = torch.Generator().manual_seed(7)
+
+    def feats(n):
+        return torch.stack([torch.randint(0, d, (n,), generator=g) for d in (119, 5, 12, 12, 10, 6, 6, 2, 2)], 1)
+
+    def graph(n, bonds):
+        src, dst, attr = [], [], []
+        for a, b in bonds:
+            t = [int(torch.randint(0, d, (1,), generator=g)) for d in (5, 6, 2)]
+            src += [a, b]
+            dst += [b, a]
+            attr += [t, t]
+        ei = torch.tensor([src, dst], dtype=torch.int64).reshape(2, -1)
+        ea = torch.tensor(attr, dtype=torch.int64).reshape(-1, 3)
+        return GraphData(feats(n), ei, ea, para=torch.rand(5, generator=g) * 4.5 + 0.5)
+
+    ring = graph(5, [(0, 1), (1, 2), (2, 3), (3, 4), (4, 0)])
+    lone = graph(1, [])
+    pair = graph(2, [(0, 1)])
+    tree = graph(6, [(0, 1), (0, 2), (0, 3), (3, 4), (3, 5)])
+    return collate([ring, lone, pair, tree])
+
+
+def to_numpy_state(model: torch.nn.Module) -> Dict[str, np.ndarray]:
+    return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}

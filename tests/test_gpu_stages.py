@@ -1,0 +1,298 @@
+"""Stage-level parity: every C-ABI kernel against the matching piece of the CPU oracle on
+identical inputs.  Tolerances (written next to each assert) are relative to the scale of the
+reference tensor; integer / index work is bit-exact."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import mini4, rel_err  # noqa: E402
+from oracle import pna_torch as O  # noqa: E402
+
+DEV = "cuda:0"
+BOND_DIMS = (5, 6, 2)
+ATOM_DIMS = (119, 5, 12, 12, 10, 6, 6, 2, 2)
+
+
+def K():
+    import gnn_epc_saft_amd.kernels as k
+    return k
+
+
+def synth(g, seed):
+    from gnn_epc_saft_amd.data.synthetic import make_synthetic_batch
+    return make_synthetic_batch(g, seed)
+
+
+def ref_csr(edge_index, edge_attr, n, loops):
+    """Destination-sorted rows, edge order kept, loop last (python, CPU)."""
+    e = edge_index.shape[1]
+    rows = [[] for _ in range(n)]
+    for i in range(e):
+        rows[int(edge_index[1, i])].append(i)
+    rowptr, src, dst, combo = [0], [], [], []
+    for v in range(n):
+        for i in rows[v]:
+            a = edge_attr[i].tolist()
+            src.append(int(edge_index[0, i]))
+            dst.append(v)
+            combo.append((a[0] * BOND_DIMS[1] + a[1]) * BOND_DIMS[2] + a[2])
+        if loops:
+            src.append(v)
+            dst.append(v)
+            combo.append(0)
+        rowptr.append(len(src))
+    return rowptr, src, dst, combo
+
+
+@pytest.mark.parametrize("loops", [True, False])
+@pytest.mark.parametrize("case", ["mini4", "synth64", "noedges"])
+def test_csr_build_bit_exact(case, loops):
+    if case == "mini4":
+        d = mini4()
+    elif case == "synth64":
+        d = synth(64, 5)
+    else:
+        d = mini4()
+        d.edge_index = d.edge_index[:, :0]
+        d.edge_attr = d.edge_attr[:0]
+    n = d.x.shape[0]
+    rowptr, src, dst, combo, la, lt, err = K().csr_build(d.edge_index.to(DEV), d.edge_attr.to(DEV), n, BOND_DIMS, loops)
+    r_rowptr, r_src, r_dst, r_combo = ref_csr(d.edge_index, d.edge_attr, n, loops)
+    assert int(err.item()) == 0
+    assert rowptr.cpu().tolist() == r_rowptr
+    assert src.cpu().tolist() == r_src
+    assert dst.cpu().tolist() == r_dst
+    assert combo.cpu().tolist() == r_combo
+    deg = torch.tensor(r_rowptr[1:]) - torch.tensor(r_rowptr[:-1])
+    degf = deg.float()
+    # logf: 2 ulp
+    assert torch.allclose(la.cpu(), torch.log(degf + 1), rtol=3e-7, atol=0)
+    assert torch.allclose(lt.cpu(), torch.log(degf.clamp(min=1) + 1), rtol=3e-7, atol=0)
+
+
+def test_csr_large_scan_and_determinism():
+    d = synth(3000, 11)  # ~60k nodes: several scan tiles
+    n = d.x.shape[0]
+    a = K().csr_build(d.edge_index.to(DEV), d.edge_attr.to(DEV), n, BOND_DIMS, True)
+    b = K().csr_build(d.edge_index.to(DEV), d.edge_attr.to(DEV), n, BOND_DIMS, True)
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.equal(x, y)
+    dst = torch.cat([d.edge_index[1], torch.arange(n)])
+    assert torch.equal(a[0].cpu().long()[1:] - a[0].cpu().long()[:-1], torch.bincount(dst, minlength=n))
+    # rows of a node keep edge-list order: sources of real edges appear in ascending edge id
+    order = torch.argsort(d.edge_index[1], stable=True)
+    real = a[1].cpu()[a[1].cpu() != a[2].cpu()]  # drop self-loop rows (src == dst)
+    assert torch.equal(real.long(), d.edge_index[0][order])
+
+
+def test_csr_flags_bad_indices_without_faulting():
+    d = mini4()
+    ei = d.edge_index.clone()
+    ei[0, 1] = 10_000
+    ea = d.edge_attr.clone()
+    ea[2, 0] = 77
+    *_, err = K().csr_build(ei.to(DEV), ea.to(DEV), d.x.shape[0], BOND_DIMS, True)
+    assert int(err.item()) & 1 and int(err.item()) & 2
+
+
+def test_batch_to_ptr():
+    batch = torch.tensor([0, 0, 0, 2, 2, 5, 5, 5, 5])  # graphs 1, 3, 4, 6 empty
+    ptr, err = K().batch_to_ptr(batch.to(DEV), batch.numel(), 7, DEV)
+    assert ptr.cpu().tolist() == [0, 3, 3, 5, 5, 5, 9, 9] and int(err.item()) == 0
+    ptr, err = K().batch_to_ptr(None, 9, 1, DEV)
+    assert ptr.cpu().tolist() == [0, 9]
+    _, err = K().batch_to_ptr(torch.tensor([0, 2, 1]).to(DEV), 3, 3, DEV)
+    assert int(err.item()) & 4
+
+
+def test_embed_sum_bit_exact():
+    torch.manual_seed(0)
+    d = synth(32, 3)
+    tables = [torch.randn(v, 128) for v in ATOM_DIMS]
+    out, err = K().embed_sum(d.x.to(DEV), [t.to(DEV) for t in tables])
+    ref = 0
+    for k, t in enumerate(tables):
+        ref = ref + t[d.x[:, k]]
+    assert int(err.item()) == 0
+    assert torch.equal(out.cpu(), ref)  # same left-to-right f32 adds: bit-exact
+    btabs = [torch.randn(v, 64) for v in BOND_DIMS]
+    combo = K().bond_combo_embed([t.to(DEV) for t in btabs]).cpu()
+    for c in (0, 1, 17, 59):
+        a, b, cc = c // 12, (c // 2) % 6, c % 2
+        assert torch.equal(combo[c], btabs[0][a] + btabs[1][b] + btabs[2][cc])
+
+
+@pytest.mark.parametrize("m,n_out,k", [(1, 3, 16), (60, 64, 64), (333, 32, 32), (1000, 128, 128), (257, 256, 256),
+                                       (4100, 5, 64), (129, 64, 832), (130, 128, 3328)])
+def test_linear_matches_f64(m, n_out, k):
+    torch.manual_seed(m + n_out + k)
+    a, w, b = torch.randn(m, k), torch.randn(n_out, k) / math.sqrt(k), torch.randn(n_out)
+    out = K().linear(a.to(DEV), w.to(DEV), b.to(DEV)).cpu()
+    ref = a.double() @ w.double().t() + b.double()
+    assert rel_err(out, ref) < 2e-6  # f32 fma chain over k <= 3328 terms
+    out = K().linear(a.to(DEV), w.to(DEV), None, relu_in=True, relu_out=True).cpu()
+    ref = torch.relu(torch.relu(a.double()) @ w.double().t())
+    assert rel_err(out, ref) < 2e-6
+
+
+def test_linear_epilogue_affine_residual_and_stats():
+    torch.manual_seed(1)
+    m, n_out, k = 1000, 128, 128
+    a, w, b = torch.randn(m, k), torch.randn(n_out, k) / math.sqrt(k), torch.randn(n_out)
+    sc, sh, res = torch.rand(n_out) + 0.5, torch.randn(n_out), torch.randn(m, n_out)
+    out = K().linear(a.to(DEV), w.to(DEV), b.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV), relu_out=True,
+                     residual=res.to(DEV)).cpu()
+    y = a.double() @ w.double().t() + b.double()
+    ref = torch.relu(y * sc.double() + sh.double()) + res.double()
+    assert rel_err(out, ref) < 2e-6
+    out, stats = K().linear(a.to(DEV), w.to(DEV), b.to(DEV), want_stats=True)
+    rpg = K().bn_rows_per_group()
+    stats = stats.cpu().double()
+    assert not torch.isnan(stats).any()
+    for g in range(stats.shape[0]):
+        rows = y[g * rpg:(g + 1) * rpg]
+        assert rel_err(stats[g, 0], rows.mean(0)) < 2e-6
+        assert rel_err(stats[g, 1], ((rows - rows.mean(0)) ** 2).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("rows,ch", [(1000, 128), (63, 64), (20480, 256), (2, 32)])
+def test_batchnorm_train_and_eval(rows, ch):
+    torch.manual_seed(rows)
+    a = torch.randn(rows, ch) * 2 + 3  # mean^2/var > 1: stresses the variance formula
+    w = torch.eye(ch)
+    bn = torch.nn.BatchNorm1d(ch).double()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2)
+    res = torch.randn(rows, ch)
+    g = lambda t: t.detach().float().to(DEV)
+    rm, rv, nbt = g(bn.running_mean), g(bn.running_var), torch.tensor(5, device=DEV)
+    y, stats = K().linear(a.to(DEV), w.to(DEV), None, want_stats=True)
+    scale, shift = K().bn_finalize(stats, rows, g(bn.weight), g(bn.bias), rm, rv, nbt, 0.1, 1e-5, True)
+    out = K().bn_relu_residual(y, scale, shift, res.to(DEV)).cpu()
+    bn.train()
+    ref = torch.relu(bn(a.double())) + res.double()
+    assert rel_err(out, ref) < 2e-6
+    assert rel_err(rm.cpu(), bn.running_mean) < 1e-6 and rel_err(rv.cpu(), bn.running_var) < 1e-6
+    assert int(nbt.item()) == 6
+    bn.eval()
+    scale, shift = K().bn_finalize(None, rows, g(bn.weight), g(bn.bias), g(bn.running_mean), g(bn.running_var), None,
+                                   0.1, 1e-5, False)
+    out = K().bn_relu_residual(y, scale, shift, None).cpu()
+    assert rel_err(out, torch.relu(bn(a.double()))) < 2e-6
+
+
+def conv_pieces(hidden, pre, post, d, loops, seed=0):
+    torch.manual_seed(seed)
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram
+    conv = O.OraclePNAConv(hidden, degree_histogram(d), pre, post)
+    x = torch.randn(d.x.shape[0], hidden)
+    btabs = [torch.randn(v, hidden) * 0.5 for v in BOND_DIMS]
+    ei, ea = d.edge_index, d.edge_attr
+    if loops:
+        ei, ea = O.add_self_loops(ei, ea, d.x.shape[0])
+    edge_emb = btabs[0][ea[:, 0]] + btabs[1][ea[:, 1]] + btabs[2][ea[:, 2]]
+    return conv, x, btabs, ei, edge_emb
+
+
+@pytest.mark.parametrize("hidden", [64, 128, 256])
+@pytest.mark.parametrize("pre", [1, 2, 3])
+@pytest.mark.parametrize("loops", [True, False])
+def test_message_and_aggregate(hidden, pre, loops):
+    """K2/K3/K4: node terms + edge-class table (+ edge MLP) + segmented mean|min|max|std
+    against PyG-style messages + 8 scatter passes."""
+    d = mini4() if hidden == 256 else synth(48, hidden + pre)
+    conv, x, btabs, ei, edge_emb = conv_pieces(hidden, pre, 1, d, loops)
+    n = x.shape[0]
+    with torch.no_grad():
+        msgs64 = conv.double().messages(x.double(), ei, edge_emb.double())
+        agg64 = O.pna_aggregate(msgs64, ei[1], n)
+        conv.float()
+    k = K()
+    g = lambda t: t.detach().float().contiguous().to(DEV)
+    rowptr, src, dst, combo, la, lt, err = k.csr_build(d.edge_index.to(DEV), d.edge_attr.to(DEV), n, BOND_DIMS, loops)
+    cemb = k.bond_combo_embed([g(t) for t in btabs])
+    p0, p1 = conv.pre_nns[0], conv.pre_nns[1]
+    rtab = k.pna_edge_table(cemb, g(conv.edge_encoder.weight), g(conv.edge_encoder.bias), g(p0[0].weight),
+                            g(p0[0].bias), g(p1[0].weight), g(p1[0].bias))
+    pq = k.pna_node_terms(g(x), g(p0[0].weight), g(p1[0].weight))
+    msgs = None
+    if pre >= 2:
+        msgs = k.pna_edge_mlp(src, dst, combo, pq, rtab, g(p0[2].weight), g(p0[2].bias), g(p1[2].weight),
+                              g(p1[2].bias))
+        for j in range(2, pre):
+            nxt = torch.empty_like(msgs)
+            for t, net in enumerate((p0, p1)):
+                nxt[:, t * hidden:(t + 1) * hidden] = k.linear(msgs[:, t * hidden:(t + 1) * hidden],
+                                                               g(net[2 * j].weight), g(net[2 * j].bias), relu_in=True)
+            msgs = nxt
+        # CSR-ordered messages vs oracle messages (edge-list order): compare through the row permutation
+        order = torch.argsort(ei[1], stable=True)
+        assert rel_err(msgs.cpu().view(-1, 2, hidden), msgs64[order]) < 3e-6
+    agg = k.pna_aggregate(rowptr, src, combo, hidden, pq=pq, rtab=rtab, msgs=msgs).cpu().double()
+    f = hidden
+    for i, name in enumerate(["mean", "min", "max"]):
+        assert rel_err(agg[..., i * f:(i + 1) * f], agg64[..., i * f:(i + 1) * f]) < 3e-6, name
+    # std: compare variances away from the reference's own discontinuity at var = 1e-5
+    mean64 = agg64[..., :f]
+    msq64 = O.scatter_mean(msgs64 * msgs64, ei[1], n)
+    var64 = msq64 - mean64 * mean64
+    noise = 8 * 6e-8 * msq64 + 1e-12
+    away = (var64 - 1e-5).abs() > 4 * noise
+    std, std64 = agg[..., 3 * f:], agg64[..., 3 * f:]
+    assert torch.equal((std == 0)[away], (std64 == 0)[away])
+    assert ((std * std - std64 * std64).abs()[away] <= (4 * noise + 3e-6 * var64.abs())[away]).all()
+    assert away.float().mean() > 0.99
+
+
+@pytest.mark.parametrize("hidden", [64, 128, 256])
+@pytest.mark.parametrize("post", [1, 2, 3])
+def test_update_scalers_on_load(hidden, post):
+    """K5: post_nns on cat[x, A, A*amp, A*att] without materialising [N,T,13F]."""
+    d = synth(40, hidden + post)
+    conv, x, btabs, ei, edge_emb = conv_pieces(hidden, 1, post, d, True, seed=3)
+    n = x.shape[0]
+    stages = {}
+    with torch.no_grad():
+        conv.double()(x.double(), ei, edge_emb.double(), stages)
+        conv.float()
+    k = K()
+    g = lambda t: t.detach().float().contiguous().to(DEV)
+    rowptr, src, dst, combo, la, lt, err = k.csr_build(d.edge_index.to(DEV), d.edge_attr.to(DEV), n, BOND_DIMS, True)
+    agg = g(stages["agg"])  # identical aggregation input for both sides
+    q0, q1 = conv.post_nns[0], conv.post_nns[1]
+    u = k.pna_update(g(x), agg, la, lt, g(conv.aggr_module.avg_deg_log), g(q0[0].weight), g(q0[0].bias),
+                     g(q1[0].weight), g(q1[0].bias))
+    for j in range(1, post):
+        nxt = torch.empty_like(u)
+        half = hidden // 2
+        for t, net in enumerate((q0, q1)):
+            nxt[:, t * half:(t + 1) * half] = k.linear(u[:, t * half:(t + 1) * half], g(net[2 * j].weight),
+                                                       g(net[2 * j].bias), relu_in=True)
+        u = nxt
+    assert rel_err(u.cpu(), stages["post"]) < 3e-6
+    out = k.linear(u, g(conv.lin.weight), g(conv.lin.bias)).cpu()
+    assert rel_err(out, stages["conv"]) < 5e-6
+
+
+def test_add_pool_and_mape():
+    torch.manual_seed(2)
+    d = synth(100, 8)
+    x = torch.randn(d.x.shape[0], 128)
+    ptr, _ = K().batch_to_ptr(d.batch.to(DEV), d.x.shape[0], d.num_graphs, DEV)
+    out = K().add_pool(x.to(DEV), ptr).cpu()
+    ref = O.global_add_pool(x, d.batch)
+    assert torch.equal(out, ref)  # same sequential row order: bit-exact
+    pred, tgt = torch.randn(100, 3), torch.rand(100, 3) * 4.5 + 0.5
+    tgt[3, 1] = 0.0  # exercises the 1.17e-6 clamp
+    got = K().mape(pred.to(DEV), tgt.to(DEV)).cpu()
+    ref = O.mape(pred.double(), tgt.double())
+    assert abs(float(got[0]) - float(ref)) / float(ref) < 1e-6
+    assert float(got[2]) == 300.0
