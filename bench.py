@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: molecular graphs/s for PNAPCSAFT forward + MAPE loss (train-mode
+BatchNorm, no backward) on synthetic molecular graphs, one process per MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (gnnsaft_forward: CSR build, embeddings, L PNA layers,
+add-pool, readout MLP, MAPE) over one HBM-resident batch, plus -- for N > 1 -- the RCCL
+all-reduce of [sum(ape), count] that the reference performs for its `sync_dist=True` loss
+metric.  Weak scaling: every rank owns its own G graphs; there is no data-path collective.
+Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[1] (the configuration the metric is quoted on) and configs[2]
+    2: dict(graphs=1024, hidden=128, depth=3, name="C2"),
+    3: dict(graphs=8192, hidden=256, depth=5, name="C3"),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA
+
+
+def k4_algorithmic_bytes(n: int, e_prime: int, hidden: int) -> int:
+    """each [T*F] message row read once, int64 destination ids as
+    delivered, the four aggregates written once."""
+    return 8 * hidden * (e_prime + 4 * n) + 8 * e_prime
+
+
+def gemm_reference_flops(n: int, e_prime: int, hidden: int) -> float:
+    """reference formulation, per layer, pre = post = 1."""
+    return (14.0 * e_prime + 28.0 * n) * hidden * hidden
+
+
+def cpu_baseline(cfg, data, deg, budget_s: float):
+    """The oracle (CPU restatement, PyG-equivalent op sequence) timed on the host cores."""
+    from oracle.pna_torch import OracleMlpParams, OraclePNAPCSAFT, OraclePnaParams, training_loss
+    torch.manual_seed(0)
+    model = OraclePNAPCSAFT(cfg["hidden"], OraclePnaParams(cfg["depth"], 1, 1, deg, skip_connections=True,
+                                                           self_loops=True), OracleMlpParams(1, 3)).train()
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        training_loss(model, data, 3)  # warm-up
+        times = []
+        t_end = time.perf_counter() + budget_s
+        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 50):
+            t0 = time.perf_counter()
+            training_loss(model, data, 3)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": data.num_graphs / med, "unit": "graphs/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} timed forward+loss passes (median) of the oracle (CPU restatement, PyG-equivalent "
+                      f"op sequence, torch {torch.__version__}, {threads} threads) over the same {data.num_graphs}"
+                      f"-graph batch"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph (1) or launch eagerly (0)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import gnn_epc_saft_amd as G
+    from gnn_epc_saft_amd import _native, parallel
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+
+    rank, local_rank, world = parallel.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    cfg = CONFIGS[args.config]
+
+    # synthetic workload: every rank its own G graphs (weak scaling), same model everywhere
+    data = make_synthetic_batch(cfg["graphs"], 1234 + args.config + 1000 * rank, num_para=3)
+    deg = degree_histogram(make_synthetic_batch(cfg["graphs"], 1234 + args.config, num_para=3))
+    torch.manual_seed(0)
+    model = G.PNApcsaftL(G.PnaconvsParams(cfg["depth"], 1, 1, deg, skip_connections=True, self_loops=True),
+                         G.ReadoutMLPParams(1, 3), dict(hidden_dim=cfg["hidden"], num_para=3)).to(dev).train()
+    ddev = data.to(dev)
+    n, e = data.x.shape[0], data.edge_index.shape[1]
+    e_prime = e + n
+
+    import torch.distributed as dist
+
+    def step():
+        parts = model.training_step_parts(ddev)        # [mape, sum(ape), count] on device
+        return parallel.global_mape(parts)             # all-reduce(sum) over ranks when world > 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    stream = torch.cuda.Stream(dev)
+    use_graph = bool(args.graph) and world == 1  # RCCL inside a captured graph is not exercised here
+    with torch.no_grad(), torch.cuda.stream(stream):
+        for _ in range(max(args.warmup, 1) if use_graph else args.warmup):
+            loss = step()
+        graph = None
+        if use_graph:
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                loss = step()
+            graph.replay()
+        run = graph.replay if graph is not None else step
+
+        # ---- timed region 1: K steps, nothing else on the stream -> `value`
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r = run()
+            if graph is None:
+                loss = r
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+        # ---- the same K steps launched eagerly (one C call per step), for the record
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        barrier()
+        elapsed_eager = time.perf_counter() - t0
+
+        # ---- timed region 2: the same K steps launched eagerly with HIP events recorded on the
+        # launch stream around the K4 / GEMM launches -> per-kernel durations for the roofline
+        mask = _native.PROF_AGGREGATE | _native.PROF_UPDATE | _native.PROF_NODE_TERMS | _native.PROF_LIN
+        handle = ctypes.c_void_p()
+        _native.check(_native.lib.gnnsaft_profile_create(args.steps * cfg["depth"] * 4, mask, ctypes.byref(handle)),
+                      "gnnsaft_profile_create")
+        model.model._profile = handle
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        barrier()
+        elapsed_instr = time.perf_counter() - t1
+        model.model._profile = None
+
+    def kernel_ms(bit):
+        cnt, tot = ctypes.c_int32(), ctypes.c_float()
+        _native.check(_native.lib.gnnsaft_profile_summary(handle, bit, ctypes.byref(cnt), ctypes.byref(tot)),
+                      "gnnsaft_profile_summary")
+        return cnt.value, (tot.value / cnt.value if cnt.value else float("nan"))
+
+    k4_n, k4_ms = kernel_ms(_native.PROF_AGGREGATE)
+    up_n, up_ms = kernel_ms(_native.PROF_UPDATE)
+    nt_n, nt_ms = kernel_ms(_native.PROF_NODE_TERMS)
+    lin_n, lin_ms = kernel_ms(_native.PROF_LIN)
+    _native.lib.gnnsaft_profile_destroy(handle)
+
+    t = torch.tensor([elapsed, elapsed_instr, elapsed_eager], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, elapsed_instr, elapsed_eager = float(t[0]), float(t[1]), float(t[2])
+
+    if rank == 0:
+        total_graphs = cfg["graphs"] * world * args.steps
+        k4_bytes = k4_algorithmic_bytes(n, e_prime, cfg["hidden"])
+        k4_gbs = k4_bytes / (k4_ms * 1e-3) / 1e9
+        gemm_ms = up_ms + nt_ms + lin_ms
+        gemm_tf = gemm_reference_flops(n, e_prime, cfg["hidden"]) / (gemm_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"k4_hbm_traffic_{cfg['name']}.json")
+        if os.path.exists(tpath):  # PMC-measured HBM bytes per K4 launch (rocprofv3 --pmc passes, profiles/)
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "molecular graphs/sec (forward+loss)",
+            "value": total_graphs / elapsed,
+            "unit": "graphs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{cfg['name']}: {cfg['graphs']} synthetic molecular graphs per GPU (|V|~U[12,28], |E|~2|V|, "
+                            f"9 int64 node / 3 int64 edge categorical features), PNAPCSAFT H={cfg['hidden']} "
+                            f"L={cfg['depth']} pre=post=1 mlp=1 P=3 skip+self-loops, train-mode BatchNorm forward + "
+                            f"MAPE loss, no backward",
+                "graphs_per_gpu": cfg["graphs"], "nodes": n, "edges": e, "edges_with_self_loops": e_prime,
+                "launch": "hipGraph replay" if graph is not None else "eager (one C call per step)",
+                "loss_exchange": "RCCL all-reduce of [sum(ape), count]" if world > 1 else "none (1 GPU)",
+            },
+            "roofline": {
+                "kernel": "k_pna_aggregate<fused> (K4 segmented mean|min|max|std)",
+                "bound": "hbm", "achieved": k4_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": k4_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": k4_bytes, "avg_launch_ms": k4_ms, "launches_timed": k4_n,
+                "how": "HIP events on the launch stream around every K4 launch of an instrumented repeat of the "
+                       "timed steps",
+            },
+            "roofline_gemm": {
+                "kernels": "k_gemm_f32 (node terms + update + lin), per layer", "bound": "mfma",
+                "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF,
+                "flops_basis": "reference formulation (14E'+28N)H^2 per layer (SURVEY.md 8(d))",
+                "avg_ms": {"node_terms": nt_ms, "update": up_ms, "lin": lin_ms},
+            },
+            "eager_ms_per_step": elapsed_eager / args.steps * 1e3,
+            "instrumented_ms_per_step": elapsed_instr / args.steps * 1e3,
+            "final_loss": float(loss),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, data, deg, args.cpu_budget)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

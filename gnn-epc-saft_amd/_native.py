@@ -64,8 +64,14 @@ SIGNATURES = {
     "gnnsaft_forward_workspace_bytes": (c_size_t, [POINTER(ModelDesc), c_int64, c_int64, c_int64]),
     "gnnsaft_forward_workspace_map": (c_int32, [POINTER(ModelDesc), c_int64, c_int64, c_int64, POINTER(WorkspaceMap)]),
     "gnnsaft_forward": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), c_int32, P, P, P, P, c_int64, c_int64,
-                                  c_int64, P, P, P, P, P, c_size_t, P]),
+                                  c_int64, P, P, P, P, P, c_size_t, P, P]),
+    "gnnsaft_profile_create": (c_int32, [c_int32, ctypes.c_uint32, POINTER(c_void_p)]),
+    "gnnsaft_profile_destroy": (None, [P]),
+    "gnnsaft_profile_reset": (c_int32, [P]),
+    "gnnsaft_profile_summary": (c_int32, [P, ctypes.c_uint32, POINTER(c_int32), POINTER(c_float)]),
 }
+
+PROF_AGGREGATE, PROF_UPDATE, PROF_NODE_TERMS, PROF_LIN = 1, 2, 4, 8
 
 
 def _load() -> ctypes.CDLL:

@@ -194,10 +194,10 @@ __global__ void k_single_graph_ptr(int32_t *ptr, int32_t n) {
 }  // namespace gs
 
 extern "C" size_t gnnsaft_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges) {
-  // counts[N] + cursor[N] + tile_sums[tiles] + eid[E]
+  // counts[N] + cursor[N] + tile_sums[tiles] + eid[E + N]
   const size_t tiles = (size_t)gs_ceil_div(num_nodes > 0 ? num_nodes : 1, gs::kScanTile);
   return gs_align_up((size_t)num_nodes * 4, 256) * 2 + gs_align_up(tiles * 4, 256) +
-         gs_align_up((size_t)(num_edges > 0 ? num_edges : 1) * 4, 256);
+         gs_align_up((size_t)(num_edges + num_nodes + 1) * 4, 256);  // eid lives in the loop-padded row space
 }
 
 extern "C" int gnnsaft_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_t num_nodes,

@@ -14,9 +14,35 @@
 //     batch_norms[l].module: weight, bias, running_mean, running_var, num_batches_tracked
 //   readout: num_mlp_layers x (Linear weight, bias, BN x5)
 //            Linear(H,H/2) w,b, BN x5, Linear(H/2,H/4) w,b, BN x5, Linear(H/4,P) w,b
+#include <vector>
+
 #include "common.hpp"
 
+// Event pairs recorded on the launch stream around selected launches (bench.py roofline).
+struct gnnsaft_profile {
+  uint32_t mask = 0;
+  int used = 0;
+  std::vector<hipEvent_t> start, stop;
+  std::vector<uint32_t> kind;
+};
+
 namespace gs {
+
+struct ProfScope {
+  gnnsaft_profile *p;
+  int slot = -1;
+  hipStream_t st;
+  ProfScope(gnnsaft_profile *prof, uint32_t bit, hipStream_t stream) : p(prof), st(stream) {
+    if (p != nullptr && (p->mask & bit) != 0 && p->used < (int)p->start.size()) {
+      slot = p->used++;
+      p->kind[slot] = bit;
+      (void)hipEventRecord(p->start[slot], st);
+    }
+  }
+  ~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(p->stop[slot], st);
+  }
+};
 
 struct Plan {
   // sizes
@@ -130,7 +156,7 @@ struct WeightCursor {
 // train writes y with (mean, M2) partials, finalises the statistics and applies them.
 static int linear_bn_relu(const float *a, int64_t lda, const float *w, const float *b, int64_t rows, int n_out, int k,
                           const BnPtrs &bn, const gnnsaft_model_desc *d, char *ws, const Plan &p, float *y_tmp,
-                          const float *residual, float *out, hipStream_t st) {
+                          const float *residual, float *out, hipStream_t st, gnnsaft_profile *prof = nullptr) {
   float *scale = reinterpret_cast<float *>(ws + p.scale);
   float *shift = reinterpret_cast<float *>(ws + p.shift);
   float *stats = reinterpret_cast<float *>(ws + p.stats);
@@ -140,7 +166,10 @@ static int linear_bn_relu(const float *a, int64_t lda, const float *w, const flo
     ent.out = y_tmp;
     LinearEpilogue epi;
     epi.stats = stats;
-    GS_TRY(launch_linear(a, lda, 0, 1, &ent, k, n_out, rows, n_out, k, epi, st));
+    {
+      ProfScope ps(prof, GNNSAFT_PROF_LIN, st);
+      GS_TRY(launch_linear(a, lda, 0, 1, &ent, k, n_out, rows, n_out, k, epi, st));
+    }
     GS_TRY(gnnsaft_bn_finalize(stats, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt, d->bn_momentum,
                                d->bn_eps, 1, scale, shift, st));
     GS_TRY(gnnsaft_bn_relu_residual(y_tmp, scale, shift, residual, out, rows, n_out, st));
@@ -154,6 +183,7 @@ static int linear_bn_relu(const float *a, int64_t lda, const float *w, const flo
     epi.relu_out = 1;
     epi.residual = residual;
     epi.ldr = n_out;
+    ProfScope ps(prof, GNNSAFT_PROF_LIN, st);
     GS_TRY(launch_linear(a, lda, 0, 1, &ent, k, n_out, rows, n_out, k, epi, st));
   }
   return GNNSAFT_OK;
@@ -249,6 +279,60 @@ extern "C" int gnnsaft_pna_update(const float *x, const float *agg, const float 
                            static_cast<hipStream_t>(stream));
 }
 
+extern "C" int gnnsaft_profile_create(int32_t capacity, uint32_t mask, gnnsaft_profile **out) {
+  GS_REQUIRE(out != nullptr, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(capacity >= 1 && capacity <= (1 << 20), GNNSAFT_ERR_SHAPE);
+  gnnsaft_profile *p = new gnnsaft_profile();
+  p->mask = mask;
+  p->start.resize(capacity);
+  p->stop.resize(capacity);
+  p->kind.assign(capacity, 0);
+  for (int i = 0; i < capacity; ++i) {
+    hipError_t e1 = hipEventCreate(&p->start[i]);
+    hipError_t e2 = hipEventCreate(&p->stop[i]);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      delete p;
+      return (int)(e1 != hipSuccess ? e1 : e2);
+    }
+  }
+  *out = p;
+  return GNNSAFT_OK;
+}
+
+extern "C" void gnnsaft_profile_destroy(gnnsaft_profile *p) {
+  if (p == nullptr) return;
+  for (size_t i = 0; i < p->start.size(); ++i) {
+    (void)hipEventDestroy(p->start[i]);
+    (void)hipEventDestroy(p->stop[i]);
+  }
+  delete p;
+}
+
+extern "C" int gnnsaft_profile_reset(gnnsaft_profile *p) {
+  GS_REQUIRE(p != nullptr, GNNSAFT_ERR_NULL);
+  p->used = 0;
+  return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_profile_summary(gnnsaft_profile *p, uint32_t kernel_bit, int32_t *count, float *total_ms) {
+  GS_REQUIRE(p && count && total_ms, GNNSAFT_ERR_NULL);
+  int c = 0;
+  double tot = 0.0;
+  for (int i = 0; i < p->used; ++i) {
+    if (p->kind[i] != kernel_bit) continue;
+    hipError_t e = hipEventSynchronize(p->stop[i]);
+    if (e != hipSuccess) return (int)e;
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, p->start[i], p->stop[i]);
+    if (e != hipSuccess) return (int)e;
+    tot += ms;
+    ++c;
+  }
+  *count = c;
+  *total_ms = (float)tot;
+  return GNNSAFT_OK;
+}
+
 extern "C" int32_t gnnsaft_num_weights(const gnnsaft_model_desc *d) {
   if (d == nullptr) return -1;
   const int per_layer = 1 + 2 + 4 * d->pre_layers + 4 * d->post_layers + 2 + 5;
@@ -290,7 +374,7 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
                                const int64_t *x_idx, const int64_t *edge_index, const int64_t *edge_attr,
                                const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
                                const float *target, float *out, float *loss3, int32_t *err_flag, void *workspace,
-                               size_t workspace_bytes, gnnsaft_stream_t stream) {
+                               size_t workspace_bytes, gnnsaft_profile *prof, gnnsaft_stream_t stream) {
   GS_REQUIRE(d && weights_host && out && workspace, GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_weights == gnnsaft_num_weights(d), GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(num_nodes >= 1 && num_graphs >= 1 && x_idx != nullptr, GNNSAFT_ERR_SHAPE);
@@ -344,7 +428,10 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     // message: node terms + edge-class table (+ extra pre-layers on edge rows)
     GS_TRY(edge_table(F(p.cemb), p.combos, h, we, be, wpre[0][0], bpre[0][0], wpre[1][0], bpre[1][0], F(p.cenc),
                       F(p.rtab), st));
-    GS_TRY(node_terms(xc, n, h, wpre[0][0], wpre[1][0], F(p.pq), st));
+    {
+      ProfScope ps(prof, GNNSAFT_PROF_NODE_TERMS, st);
+      GS_TRY(node_terms(xc, n, h, wpre[0][0], wpre[1][0], F(p.pq), st));
+    }
     const float *msgs = nullptr;
     if (d->pre_layers > 1) {
       float *ma = F(p.msg0), *mb = F(p.msg1);
@@ -361,11 +448,15 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
       msgs = ma;
     }
     // K4 aggregation
-    GS_TRY(gnnsaft_pna_aggregate(I(p.rowptr), I(p.src), I(p.combo), n, h, F(p.pq), F(p.rtab), msgs, F(p.agg), st));
+    {
+      ProfScope ps(prof, GNNSAFT_PROF_AGGREGATE, st);
+      GS_TRY(gnnsaft_pna_aggregate(I(p.rowptr), I(p.src), I(p.combo), n, h, F(p.pq), F(p.rtab), msgs, F(p.agg), st));
+    }
     // update: first post-layer with scalers on load, then extra post-layers
     float *ua = F(p.u0), *ub = F(p.u1);
     {
       GemmBatchEntry e[2] = {{wpost[0][0], bpost[0][0], ua, 0}, {wpost[1][0], bpost[1][0], ua + h / 2, 0}};
+      ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
       GS_TRY(launch_pna_update(xc, F(p.agg), F(p.log_amp), F(p.log_att), avg, n, h, e, h, st));
     }
     for (int j = 1; j < d->post_layers; ++j) {
@@ -378,7 +469,7 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     }
     // lin -> BatchNorm -> ReLU -> (+ x)
     GS_TRY(linear_bn_relu(ua, h, wlin, blin, n, h, h, bn, d, ws, p, F(p.y), d->skip_connections ? xc : nullptr, xn,
-                          st));
+                          st, prof));
     float *t = xc;
     xc = xn;
     xn = t;

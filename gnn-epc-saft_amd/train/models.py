@@ -151,6 +151,7 @@ class PNAPCSAFT(nn.Module):
         self._workspace: Optional[torch.Tensor] = None
         self._err_flag: Optional[torch.Tensor] = None
         self._loss_buf: Optional[torch.Tensor] = None
+        self._profile = None  # gnnsaft_profile* (bench.py attaches one to time kernels with HIP events)
 
     # ------------------------------------------------------------------ host glue
     def _weight_tensors(self) -> List[torch.Tensor]:
@@ -275,7 +276,7 @@ class PNAPCSAFT(nn.Module):
                                      edge_attr.data_ptr() if e else None,
                                      None if batch is None else batch.data_ptr(), n, e, g, tgt_ptr, out.data_ptr(),
                                      loss_ptr, self._err_flag.data_ptr(), ws_ptr,
-                                     ws.numel() - (ws_ptr - ws.data_ptr()), stream)
+                                     ws.numel() - (ws_ptr - ws.data_ptr()), self._profile, stream)
         check(rc, "gnnsaft_forward")
         return out, loss
 

@@ -228,6 +228,22 @@ typedef struct gnnsaft_model_desc {
 
 int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);
 
+/* Optional per-kernel timing: HIP event pairs recorded on the launch stream  */
+/* around selected launches of gnnsaft_forward (bench.py's roofline figure).  */
+/* `mask` selects the instrumented kernels (GNNSAFT_PROF_*); each instrumented */
+/* launch consumes one of `capacity` event pairs.  summary() synchronises on   */
+/* the recorded events and returns launch count and summed milliseconds.       */
+#define GNNSAFT_PROF_AGGREGATE 1   /* K4 segmented multi-reduce               */
+#define GNNSAFT_PROF_UPDATE 2      /* PNAConv update GEMM (scalers on load)   */
+#define GNNSAFT_PROF_NODE_TERMS 4  /* message node-term GEMM                  */
+#define GNNSAFT_PROF_LIN 8         /* lin GEMM (+ BN partials / epilogue)     */
+#define GNNSAFT_PROF_NUM_KERNELS 4
+typedef struct gnnsaft_profile gnnsaft_profile;
+int gnnsaft_profile_create(int32_t capacity, uint32_t mask, gnnsaft_profile **out);
+void gnnsaft_profile_destroy(gnnsaft_profile *prof);
+int gnnsaft_profile_reset(gnnsaft_profile *prof);
+int gnnsaft_profile_summary(gnnsaft_profile *prof, uint32_t kernel_bit, int32_t *count, float *total_ms);
+
 size_t gnnsaft_forward_workspace_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes,
                                        int64_t num_edges, int64_t num_graphs);
 
@@ -239,7 +255,8 @@ int gnnsaft_forward(const gnnsaft_model_desc *desc,
                     const float *target /* [G,P] or NULL */,
                     float *out /* [G,P] */, float *loss3 /* [3] or NULL */,
                     int32_t *err_flag /* device int32, zeroed by the caller, or NULL */,
-                    void *workspace, size_t workspace_bytes, gnnsaft_stream_t stream);
+                    void *workspace, size_t workspace_bytes, gnnsaft_profile *profile /* or NULL */,
+                    gnnsaft_stream_t stream);
 
 /* Debug / test taps: after gnnsaft_forward, byte offsets of intermediate      */
 /* tensors inside the workspace (node state after each layer etc.).            */

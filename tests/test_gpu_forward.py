@@ -159,9 +159,15 @@ def check_population(out, want32, want64):
     scale = float(want64.abs().max())
     err_h = (out.double() - want64).abs().amax(dim=1) / scale   # per graph
     err_o = (want32.double() - want64).abs().amax(dim=1) / scale
-    frac_ok = float((err_h <= TOL).float().mean())
-    assert frac_ok >= 0.99, f"only {frac_ok:.4f} of graphs within {TOL}; worst {float(err_h.max()):.2e}"
-    assert float(err_h.max()) <= max(TOL, 3 * float(err_o.max())), (float(err_h.max()), float(err_o.max()))
+    qs = torch.tensor([0.5, 0.9, 0.99, 1.0], dtype=torch.float64)
+    qh, qo = torch.quantile(err_h, qs), torch.quantile(err_o, qs)
+    frac_h, frac_o = float((err_h <= TOL).float().mean()), float((err_o <= TOL).float().mean())
+    msg = (f"per-graph error quantiles (50/90/99/100%) hip {['%.1e' % v for v in qh.tolist()]} "
+           f"f32-oracle {['%.1e' % v for v in qo.tolist()]}; within {TOL}: hip {frac_h:.4f} f32-oracle {frac_o:.4f}")
+    print(msg)
+    # as close to the exact (f64) result as the reference arithmetic run in f32 is, quantile by quantile
+    assert bool((qh <= torch.clamp(3 * qo, min=TOL)).all()), msg
+    assert frac_h >= min(0.99, frac_o - 0.05), msg  # 96-graph batches: one graph = 1%
 
 
 def test_single_graph_unbatched_and_one_node_graphs():

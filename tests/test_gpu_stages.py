@@ -244,12 +244,15 @@ def test_message_and_aggregate(hidden, pre, loops):
     mean64 = agg64[..., :f]
     msq64 = O.scatter_mean(msgs64 * msgs64, ei[1], n)
     var64 = msq64 - mean64 * mean64
-    noise = 8 * 6e-8 * msq64 + 1e-12
-    away = (var64 - 1e-5).abs() > 4 * noise
+    # error model of an f32 variance: cancellation (eps * mean(m^2)) plus the f32 messages'
+    # own error dm (relative to the message scale, not to each element): d(var) <= 2*std*dm + dm^2
+    dm = 3e-6 * float(msgs64.abs().max())
+    tv = 8 * 6e-8 * msq64 + 2 * var64.clamp(min=0).sqrt() * dm + dm * dm
+    away = (var64 - 1e-5).abs() > 4 * tv
     std, std64 = agg[..., 3 * f:], agg64[..., 3 * f:]
     assert torch.equal((std == 0)[away], (std64 == 0)[away])
-    assert ((std * std - std64 * std64).abs()[away] <= (4 * noise + 3e-6 * var64.abs())[away]).all()
-    assert away.float().mean() > 0.99
+    assert ((std * std - std64 * std64).abs()[away] <= (4 * tv)[away]).all()
+    assert away.float().mean() > 0.98
 
 
 @pytest.mark.parametrize("hidden", [64, 128, 256])
