@@ -18,6 +18,11 @@
 // K order inside a BK tile is permuted identically for A and B (lane half h
 // reads k = 8g+4h .. 8g+4h+3), which only changes the (unspecified) summation
 // order of the dot product.
+//
+// Pipeline per BK tile: issue the raw global loads of tile t+1 (no consumer
+// before the MFMAs, so no s_waitcnt in front of them), run the 16 k-steps of
+// tile t out of LDS, then `finish` (scale / add / ReLU) the raw registers and
+// write them to the other LDS buffer; one barrier per tile.
 #include "common.hpp"
 
 namespace gs {
@@ -25,8 +30,21 @@ namespace gs {
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
+__device__ __forceinline__ f32x4 gs_relu4(f32x4 v) {
+  v.x = fmaxf(v.x, 0.f);
+  v.y = fmaxf(v.y, 0.f);
+  v.z = fmaxf(v.z, 0.f);
+  v.w = fmaxf(v.w, 0.f);
+  return v;
+}
+
 // --------------------------------------------------------------------------
-// A operand providers
+// A operand providers.  Every load is UNCONDITIONAL (hipcc branches around a
+// guarded load and waits for it on the spot, serialising one L2 round trip per
+// element): the kernel clamps row indices to the last valid row (rows past M
+// are computed on duplicate data and never stored) and the K tail is zeroed by
+// a select in finish().  `k0` is the wave-uniform base of the BK tile, `c` the
+// lane's column offset inside it.
 // --------------------------------------------------------------------------
 struct PlainA {
   const float *a;
@@ -37,21 +55,18 @@ struct PlainA {
   struct Row {
     const float *p;
   };
-  __device__ __forceinline__ Row row(int64_t r, int64_t a_off) const {
-    return Row{r < m ? a + r * lda + a_off : nullptr};
+  struct Raw {
+    f32x4 v;
+  };
+  __device__ __forceinline__ Row row(int64_t r, int64_t a_off) const { return Row{a + r * lda + a_off}; }
+  __device__ __forceinline__ Raw load(const Row &r, int k0, int c) const {
+    const int kk = k0 + c;
+    return Raw{gs_ld4(r.p + (kk < k ? kk : 0))};
   }
-  __device__ __forceinline__ f32x4 load(const Row &r, int kk) const {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r.p != nullptr && kk < k) {
-      v = gs_ld4(r.p + kk);
-      if (relu) {
-        v.x = fmaxf(v.x, 0.f);
-        v.y = fmaxf(v.y, 0.f);
-        v.z = fmaxf(v.z, 0.f);
-        v.w = fmaxf(v.w, 0.f);
-      }
-    }
-    return v;
+  __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &, int k0, int c) const {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v = relu ? gs_relu4(w.v) : w.v;
+    return (k0 + c < k) ? v : zero;
   }
 };
 
@@ -68,37 +83,24 @@ struct PostA {
     const float *pa;
     float amp, att;
   };
+  struct Raw {
+    f32x4 v;
+  };
   __device__ __forceinline__ Row row(int64_t r, int64_t a_off) const {
-    Row o{nullptr, nullptr, 0.f, 0.f};
-    if (r < n) {
-      const float avgv = avg[0];
-      o.px = x + r * f;
-      o.pa = agg + r * (int64_t)(8 * f) + a_off;
-      o.amp = log_amp[r] / avgv;
-      o.att = avgv / log_att[r];
-    }
-    return o;
+    const float avgv = avg[0];
+    return Row{x + r * f, agg + r * (int64_t)(8 * f) + a_off, log_amp[r] / avgv, avgv / log_att[r]};
   }
-  __device__ __forceinline__ f32x4 load(const Row &r, int kk) const {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r.px != nullptr) {
-      if (kk < f) {
-        v = gs_ld4(r.px + kk);
-      } else {
-        const int j = kk - f;
-        const int seg = j / (4 * f);
-        const int off = j - seg * 4 * f;
-        v = gs_ld4(r.pa + off);
-        const float s = seg == 0 ? 1.f : (seg == 1 ? r.amp : r.att);
-        if (seg != 0) {
-          v.x *= s;
-          v.y *= s;
-          v.z *= s;
-          v.w *= s;
-        }
-      }
-    }
-    return v;
+  // K = 13F = [x | A | A*amp | A*att]; F is a multiple of BK, so a BK tile never straddles segments
+  __device__ __forceinline__ Raw load(const Row &r, int k0, int c) const {
+    const int j = k0 - f;  // wave-uniform
+    const int seg = j < 4 * f ? 0 : (j < 8 * f ? 1 : 2);
+    const float *p = j < 0 ? r.px + k0 : r.pa + (j - seg * 4 * f);
+    return Raw{gs_ld4(p + c)};
+  }
+  __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &r, int k0, int) const {
+    const int j = k0 - f;
+    const float s = j < 4 * f ? 1.f : (j < 8 * f ? r.amp : r.att);  // identity | amplification | attenuation
+    return w.v * s;                                                 // x * 1.0f is exact
   }
 };
 
@@ -115,25 +117,19 @@ struct EdgeA {
     const float *q;
     const float *r;
   };
+  struct Raw {
+    f32x4 a, b, t;
+  };
   __device__ __forceinline__ Row row(int64_t r, int64_t a_off) const {
-    Row o{nullptr, nullptr, nullptr};
-    if (r < rows) {
-      o.p = pq + (int64_t)dst[r] * (4 * f) + a_off;
-      o.q = pq + (int64_t)src[r] * (4 * f) + 2 * f + a_off;
-      o.r = rtab + (int64_t)combo[r] * (2 * f) + a_off;
-    }
-    return o;
+    return Row{pq + (int64_t)dst[r] * (4 * f) + a_off, pq + (int64_t)src[r] * (4 * f) + 2 * f + a_off,
+               rtab + (int64_t)combo[r] * (2 * f) + a_off};
   }
-  __device__ __forceinline__ f32x4 load(const Row &r, int kk) const {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r.p != nullptr) {
-      const f32x4 a = gs_ld4(r.p + kk), b = gs_ld4(r.q + kk), c = gs_ld4(r.r + kk);
-      v.x = fmaxf(a.x + b.x + c.x, 0.f);
-      v.y = fmaxf(a.y + b.y + c.y, 0.f);
-      v.z = fmaxf(a.z + b.z + c.z, 0.f);
-      v.w = fmaxf(a.w + b.w + c.w, 0.f);
-    }
-    return v;
+  __device__ __forceinline__ Raw load(const Row &r, int k0, int c) const {
+    const int kk = k0 + c;
+    return Raw{gs_ld4(r.p + kk), gs_ld4(r.q + kk), gs_ld4(r.r + kk)};
+  }
+  __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &, int, int) const {
+    return gs_relu4((w.a + w.b) + w.t);
   }
 };
 
@@ -153,7 +149,7 @@ struct EpiArgs {
 // --------------------------------------------------------------------------
 // kernel
 // --------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, class AProv>
+template <int BM, int BN, int WAVES_M, int WAVES_N, class AProv, bool STATS, bool AFFINE, bool RESID>
 __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int64_t ldw, int64_t ldo, int64_t m,
                                                    int n_out, int k, EpiArgs epi) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -184,12 +180,15 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
 
   typename AProv::Row arow[A_LD4];
 #pragma unroll
-  for (int j = 0; j < A_LD4; ++j) arow[j] = ap.row(m0 + r0 + 32 * j, ent.a_off);
+  for (int j = 0; j < A_LD4; ++j) {
+    const int64_t r = m0 + r0 + 32 * j;
+    arow[j] = ap.row(r < m ? r : m - 1, ent.a_off);  // clamped: rows >= m are never stored
+  }
   const float *wrow[B_LD4];
 #pragma unroll
   for (int j = 0; j < B_LD4; ++j) {
     const int n = n0 + r0 + 32 * j;
-    wrow[j] = (r0 + 32 * j < BN && n < n_out) ? ent.w + (int64_t)n * ldw : nullptr;
+    wrow[j] = ent.w + (int64_t)(n < n_out ? n : n_out - 1) * ldw;  // clamped: columns >= n_out never stored
   }
 
   f32x16 acc[TM][TN];
@@ -200,28 +199,30 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[A_LD4], rb[B_LD4];
+  typename AProv::Raw ra[A_LD4];
+  f32x4 rb[B_LD4];
   const int nk = (k + BK - 1) / BK;
 
   auto fetch = [&](int kt) {
-    const int kk = kt * BK + c4 * 4;
+    const int k0 = kt * BK;
+    const int kk = k0 + c4 * 4;
 #pragma unroll
-    for (int j = 0; j < A_LD4; ++j) ra[j] = ap.load(arow[j], kk);
+    for (int j = 0; j < A_LD4; ++j) ra[j] = ap.load(arow[j], k0, c4 * 4);
 #pragma unroll
-    for (int j = 0; j < B_LD4; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (wrow[j] != nullptr && kk < k) v = gs_ld4(wrow[j] + kk);
-      rb[j] = v;
-    }
+    for (int j = 0; j < B_LD4; ++j) rb[j] = gs_ld4(wrow[j] + (kk < k ? kk : 0));
   };
-  auto stash = [&](int buf) {
-    float *as = lds + buf * STAGE;
+  auto stash = [&](int kt) {
+    float *as = lds + (kt & 1) * STAGE;
     float *bs = as + BM * LDS_LD;
+    const int k0 = kt * BK;
+    const bool kok = k0 + c4 * 4 < k;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < A_LD4; ++j) gs_st4(as + (r0 + 32 * j) * LDS_LD + c4 * 4, ra[j]);
+    for (int j = 0; j < A_LD4; ++j)
+      gs_st4(as + (r0 + 32 * j) * LDS_LD + c4 * 4, ap.finish(ra[j], arow[j], k0, c4 * 4));
 #pragma unroll
     for (int j = 0; j < B_LD4; ++j)
-      if (r0 + 32 * j < BN) gs_st4(bs + (r0 + 32 * j) * LDS_LD + c4 * 4, rb[j]);
+      if (r0 + 32 * j < BN) gs_st4(bs + (r0 + 32 * j) * LDS_LD + c4 * 4, kok ? rb[j] : zero);
   };
 
   fetch(0);
@@ -232,7 +233,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   const int frag_k = (lane >> 5) * 4;
 
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) fetch(kt + 1);
+    const bool more = kt + 1 < nk;
+    if (more) fetch(kt + 1);
     const float *as = lds + (kt & 1) * STAGE + (wm * WTM + frag_row) * LDS_LD + frag_k;
     const float *bs = lds + (kt & 1) * STAGE + BM * LDS_LD + (wn * WTN + frag_row) * LDS_LD + frag_k;
 #pragma unroll
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) stash((kt + 1) & 1);
+    if (more) stash(kt + 1);
     __syncthreads();
   }
 
@@ -262,9 +264,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * WTN + j * 32 + (lane & 31);
     const bool col_ok = col < n_out;
-    const float bias = (col_ok && ent.bias != nullptr) ? ent.bias[col] : 0.f;
+    const int colc = col_ok ? col : n_out - 1;
+    const float bias = ent.bias != nullptr ? ent.bias[colc] : 0.f;
 
-    if (epi.stats != nullptr) {
+    if (STATS) {
       // (mean, M2) of this wave's 64 rows for column `col`: two in-register
       // passes per lane half, then Chan's pairwise combine across the halves.
       float sum = 0.f;
@@ -274,10 +277,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < m) {
-            sum += acc[i][j][r] + bias;
-            ++cnt;
-          }
+          const bool ok = row < m;
+          sum += ok ? acc[i][j][r] + bias : 0.f;
+          cnt += ok ? 1 : 0;
         }
       const float mean = cnt > 0 ? sum / (float)cnt : 0.f;
       float m2 = 0.f;
@@ -286,10 +288,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < m) {
-            const float d = (acc[i][j][r] + bias) - mean;
-            m2 += d * d;
-          }
+          const float d = (acc[i][j][r] + bias) - mean;
+          m2 += row < m ? d * d : 0.f;
         }
       const float o_mean = __shfl_xor(mean, 32);
       const float o_m2 = __shfl_xor(m2, 32);
@@ -306,30 +306,59 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
     }
 
     float sc = 1.f, sh = 0.f;
-    if (epi.scale != nullptr && col_ok) {
-      sc = epi.scale[col];
-      sh = epi.shift[col];
+    if (AFFINE) {
+      sc = epi.scale[colc];
+      sh = epi.shift[colc];
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+      float res[16];
+      if (RESID) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int64_t row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          row = row < m ? row : m - 1;
+          res[r] = epi.residual[row * epi.ldr + colc];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < m && col_ok) {
-          float v = acc[i][j][r] + bias;
-          if (epi.scale != nullptr) v = v * sc + sh;
-          if (epi.relu_out) v = fmaxf(v, 0.f);
-          if (epi.residual != nullptr) v += epi.residual[row * epi.ldr + col];
-          ent.out[row * ldo + col] = v;
-        }
+        float v = acc[i][j][r] + bias;
+        if (AFFINE) v = v * sc + sh;
+        v = epi.relu_out ? fmaxf(v, 0.f) : v;
+        if (RESID) v += res[r];
+        if (row < m && col_ok) ent.out[row * ldo + col] = v;
       }
+    }
   }
 }
 
 // --------------------------------------------------------------------------
 // host-side dispatch
 // --------------------------------------------------------------------------
-template <class AProv>
+template <class AProv, bool STATS, bool AFFINE, bool RESID>
+static int launch_cfg(const AProv &ap, int nbatch, const GemmBatch &b, int64_t ldw, int64_t ldo, int64_t m, int n_out,
+                      int k, const EpiArgs &ea, hipStream_t stream) {
+  const dim3 block(256);
+  if (n_out <= 32) {
+    const dim3 grid((unsigned)gs_ceil_div(m, 256), (unsigned)gs_ceil_div(n_out, 32), (unsigned)nbatch);
+    hipLaunchKernelGGL((k_gemm_f32<256, 32, 4, 1, AProv, STATS, AFFINE, RESID>), grid, block, 0, stream, ap, b, ldw,
+                       ldo, m, n_out, k, ea);
+  } else if (n_out <= 64 || (n_out % 128) == 64) {
+    const dim3 grid((unsigned)gs_ceil_div(m, 128), (unsigned)gs_ceil_div(n_out, 64), (unsigned)nbatch);
+    hipLaunchKernelGGL((k_gemm_f32<128, 64, 2, 2, AProv, STATS, AFFINE, RESID>), grid, block, 0, stream, ap, b, ldw,
+                       ldo, m, n_out, k, ea);
+  } else {
+    const dim3 grid((unsigned)gs_ceil_div(m, 128), (unsigned)gs_ceil_div(n_out, 128), (unsigned)nbatch);
+    hipLaunchKernelGGL((k_gemm_f32<128, 128, 2, 2, AProv, STATS, AFFINE, RESID>), grid, block, 0, stream, ap, b, ldw,
+                       ldo, m, n_out, k, ea);
+  }
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+template <class AProv, bool FULL_EPILOGUES>
 static int dispatch(const AProv &ap, int nbatch, const GemmBatchEntry *entries, int64_t ldw, int64_t ldo, int64_t m,
                     int n_out, int k, const LinearEpilogue &epi, hipStream_t stream) {
   GS_REQUIRE(nbatch >= 1 && nbatch <= kMaxGemmBatch, GNNSAFT_ERR_SHAPE);
@@ -344,19 +373,19 @@ static int dispatch(const AProv &ap, int nbatch, const GemmBatchEntry *entries, 
   EpiArgs ea{epi.scale, epi.shift, epi.relu_out, epi.residual, epi.ldr, epi.stats};
   GS_REQUIRE((epi.scale == nullptr) == (epi.shift == nullptr), GNNSAFT_ERR_NULL);
   GS_REQUIRE(epi.stats == nullptr || nbatch == 1, GNNSAFT_ERR_SHAPE);
-  const dim3 block(256);
-  if (n_out <= 32) {
-    const dim3 grid((unsigned)gs_ceil_div(m, 256), (unsigned)gs_ceil_div(n_out, 32), (unsigned)nbatch);
-    hipLaunchKernelGGL((k_gemm_f32<256, 32, 4, 1, AProv>), grid, block, 0, stream, ap, b, ldw, ldo, m, n_out, k, ea);
-  } else if (n_out <= 64 || (n_out % 128) == 64) {
-    const dim3 grid((unsigned)gs_ceil_div(m, 128), (unsigned)gs_ceil_div(n_out, 64), (unsigned)nbatch);
-    hipLaunchKernelGGL((k_gemm_f32<128, 64, 2, 2, AProv>), grid, block, 0, stream, ap, b, ldw, ldo, m, n_out, k, ea);
-  } else {
-    const dim3 grid((unsigned)gs_ceil_div(m, 128), (unsigned)gs_ceil_div(n_out, 128), (unsigned)nbatch);
-    hipLaunchKernelGGL((k_gemm_f32<128, 128, 2, 2, AProv>), grid, block, 0, stream, ap, b, ldw, ldo, m, n_out, k, ea);
+  const bool st = epi.stats != nullptr, af = epi.scale != nullptr, rs = epi.residual != nullptr;
+  if (!FULL_EPILOGUES) {
+    GS_REQUIRE(!st && !af && !rs, GNNSAFT_ERR_UNSUPPORTED);
+    return launch_cfg<AProv, false, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
   }
-  GS_CHECK_LAUNCH();
-  return GNNSAFT_OK;
+  if (st) {
+    GS_REQUIRE(!af && !rs, GNNSAFT_ERR_UNSUPPORTED);  // train mode writes the pre-BN tensor
+    return launch_cfg<AProv, true, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
+  }
+  if (af && rs) return launch_cfg<AProv, false, true, true>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
+  if (af) return launch_cfg<AProv, false, true, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
+  if (rs) return launch_cfg<AProv, false, false, true>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
+  return launch_cfg<AProv, false, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
 }
 
 int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const GemmBatchEntry *entries, int64_t ldw,
@@ -364,7 +393,7 @@ int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const Ge
   GS_REQUIRE(a != nullptr, GNNSAFT_ERR_NULL);
   GS_REQUIRE((lda % 4) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0, GNNSAFT_ERR_SHAPE);
   PlainA ap{a, lda, relu_in, m, k};
-  return dispatch(ap, nbatch, entries, ldw, ldo, m, n_out, k, epi, stream);
+  return dispatch<PlainA, true>(ap, nbatch, entries, ldw, ldo, m, n_out, k, epi, stream);
 }
 
 int launch_pna_update(const float *x, const float *agg, const float *log_amp, const float *log_att,
@@ -377,7 +406,7 @@ int launch_pna_update(const float *x, const float *agg, const float *log_amp, co
   e[0].a_off = 0;
   e[1].a_off = 4 * (int64_t)hidden;
   LinearEpilogue epi;
-  return dispatch(ap, 2, e, 13 * (int64_t)hidden, ldo, n, hidden / 2, 13 * hidden, epi, stream);
+  return dispatch<PostA, false>(ap, 2, e, 13 * (int64_t)hidden, ldo, n, hidden / 2, 13 * hidden, epi, stream);
 }
 
 int launch_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *combo, int64_t rows, int hidden,
@@ -390,7 +419,7 @@ int launch_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *c
   e[0].a_off = 0;
   e[1].a_off = hidden;
   LinearEpilogue epi;
-  return dispatch(ap, 2, e, hidden, ldo, rows, hidden, hidden, epi, stream);
+  return dispatch<EdgeA, false>(ap, 2, e, hidden, ldo, rows, hidden, hidden, epi, stream);
 }
 
 }  // namespace gs
