@@ -25,7 +25,7 @@ class ModelDesc(ctypes.Structure):
         ("num_mlp_layers", c_int32), ("num_para", c_int32), ("skip_connections", c_int32),
         ("self_loops", c_int32), ("training", c_int32), ("num_atom_cols", c_int32), ("num_bond_cols", c_int32),
         ("atom_dims", c_int32 * MAX_TABLES), ("bond_dims", c_int32 * MAX_TABLES),
-        ("bn_eps", c_float), ("bn_momentum", c_float),
+        ("bn_eps", c_float), ("bn_momentum", c_float), ("fold_degree_scalers", c_int32),
     ]
 
 
@@ -56,6 +56,12 @@ SIGNATURES = {
     "gnnsaft_pna_edge_mlp": (c_int32, [P, P, P, c_int64, c_int32, P, P, P, P, P, P, P, P]),
     "gnnsaft_pna_aggregate": (c_int32, [P, P, P, c_int64, c_int32, P, P, P, P, P]),
     "gnnsaft_pna_update": (c_int32, [P, P, P, P, P, c_int64, c_int32, P, P, P, P, P, P]),
+    "gnnsaft_degree_buckets": (c_int32, []),
+    "gnnsaft_degree_tiles_capacity": (c_int64, [c_int64, c_int32]),
+    "gnnsaft_degree_tiles": (c_int32, [P, c_int64, c_int32, P, P, P, P, P, P]),
+    "gnnsaft_pna_fold_post_weights": (c_int32, [P, P, P, P, c_int32, P, P]),
+    "gnnsaft_pna_update_folded": (c_int32, [P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
+    "gnnsaft_debug_set_gemm_config": (None, [c_int32]),
     "gnnsaft_bn_finalize": (c_int32, [P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, c_int32, P, P, P]),
     "gnnsaft_bn_relu_residual": (c_int32, [P, P, P, P, P, c_int64, c_int32, P]),
     "gnnsaft_add_pool": (c_int32, [P, P, c_int64, c_int64, c_int32, P, P]),

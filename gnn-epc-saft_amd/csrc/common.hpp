@@ -62,4 +62,14 @@ int launch_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *c
                         const float *pq, const float *rtab, const GemmBatchEntry *entries /*2*/, int64_t ldo,
                         hipStream_t stream);
 
+int pna_fold_tile_rows(int hidden);
+
+int launch_pna_update_folded(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
+                             const int32_t *num_tiles, int64_t max_tiles, int64_t n, int hidden, const float *w_eff,
+                             const float *b_post0, const float *b_post1, float *u, hipStream_t stream);
+
+void debug_set_gemm_config(int cfg);
+
+constexpr int kDegreeBuckets = 32;  // folded update: exact in-degree buckets 0..31
+
 }  // namespace gs

@@ -51,6 +51,8 @@ struct Plan {
   // byte offsets into the workspace
   size_t csr_ws, rowptr, src, dst, combo, log_amp, log_att, graph_ptr;
   size_t x0, x1, pq, agg, u0, u1, y, msg0, msg1, cemb, cenc, rtab, stats, scale, shift, pooled, m0, m1, m2;
+  size_t perm, tiles, num_tiles, hist3, weff;
+  int64_t tile_cap;
   size_t total;
 };
 
@@ -112,6 +114,12 @@ static int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, int64_t 
   p.m0 = take(gg * h * 4);
   p.m1 = take(gg * h * 4);
   p.m2 = take(gg * h * 4);
+  p.tile_cap = gnnsaft_degree_tiles_capacity(n, d->hidden);
+  p.perm = take(nn * 4);
+  p.tiles = take((size_t)p.tile_cap * 16);
+  p.num_tiles = take(4);
+  p.hist3 = take(3 * kDegreeBuckets * 4);
+  p.weff = d->fold_degree_scalers ? take((size_t)kDegreeBuckets * 5 * h * h * 4) : 0;
   p.total = off;
   return GNNSAFT_OK;
 }
@@ -402,6 +410,8 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
                            ws + p.csr_ws, gnnsaft_csr_workspace_bytes(n, num_edges), st));
   // batch == NULL (un-batched Data, models.py:116): one graph spanning all nodes
   GS_TRY(gnnsaft_batch_to_ptr(batch, n, g, I(p.graph_ptr), err_flag, st));
+  if (d->fold_degree_scalers)
+    GS_TRY(gnnsaft_degree_tiles(I(p.rowptr), n, h, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3), err_flag, st));
   GS_TRY(gnnsaft_embed_sum(x_idx, n, d->num_atom_cols, atom_tab, d->atom_dims, h, F(p.x0), err_flag, st));
   GS_TRY(gnnsaft_bond_combo_embed(d->num_bond_cols, bond_tab, d->bond_dims, h, F(p.cemb), st));
 
@@ -454,7 +464,12 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     }
     // update: first post-layer with scalers on load, then extra post-layers
     float *ua = F(p.u0), *ub = F(p.u1);
-    {
+    if (d->fold_degree_scalers) {
+      GS_TRY(gnnsaft_pna_fold_post_weights(wpost[0][0], wpost[1][0], avg, I(p.hist3), h, F(p.weff), st));
+      ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
+      GS_TRY(launch_pna_update_folded(xc, F(p.agg), I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap, n, h,
+                                      F(p.weff), bpost[0][0], bpost[1][0], ua, st));
+    } else {
       GemmBatchEntry e[2] = {{wpost[0][0], bpost[0][0], ua, 0}, {wpost[1][0], bpost[1][0], ua + h / 2, 0}};
       ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
       GS_TRY(launch_pna_update(xc, F(p.agg), F(p.log_amp), F(p.log_att), avg, n, h, e, h, st));

@@ -46,6 +46,20 @@ __device__ __forceinline__ f32x4 gs_relu4(f32x4 v) {
 // a select in finish().  `k0` is the wave-uniform base of the BK tile, `c` the
 // lane's column offset inside it.
 // --------------------------------------------------------------------------
+// A block's rows: `count` valid rows starting at row0 (of the provider's row space); w_off is a
+// per-tile offset into the weight matrix (degree-folded update).  count <= 0: nothing to do.
+struct TileInfo {
+  int64_t row0;
+  int count;
+  int64_t w_off;
+};
+
+__device__ __forceinline__ TileInfo gs_plain_tile(int bx, int bm, int64_t m) {
+  const int64_t row0 = (int64_t)bx * bm;
+  const int64_t left = m - row0;
+  return TileInfo{row0, (int)(left < bm ? left : bm), 0};
+}
+
 struct PlainA {
   const float *a;
   int64_t lda;
@@ -58,6 +72,8 @@ struct PlainA {
   struct Raw {
     f32x4 v;
   };
+  __device__ __forceinline__ TileInfo tile(int bx, int bm) const { return gs_plain_tile(bx, bm, m); }
+  __device__ __forceinline__ int64_t out_row(const TileInfo &t, int lr) const { return t.row0 + lr; }
   __device__ __forceinline__ Row row(int64_t r, int64_t a_off) const { return Row{a + r * lda + a_off}; }
   __device__ __forceinline__ Raw load(const Row &r, int k0, int c) const {
     const int kk = k0 + c;
@@ -86,6 +102,8 @@ struct PostA {
   struct Raw {
     f32x4 v;
   };
+  __device__ __forceinline__ TileInfo tile(int bx, int bm) const { return gs_plain_tile(bx, bm, n); }
+  __device__ __forceinline__ int64_t out_row(const TileInfo &t, int lr) const { return t.row0 + lr; }
   __device__ __forceinline__ Row row(int64_t r, int64_t a_off) const {
     const float avgv = avg[0];
     return Row{x + r * f, agg + r * (int64_t)(8 * f) + a_off, log_amp[r] / avgv, avgv / log_att[r]};
@@ -120,6 +138,8 @@ struct EdgeA {
   struct Raw {
     f32x4 a, b, t;
   };
+  __device__ __forceinline__ TileInfo tile(int bx, int bm) const { return gs_plain_tile(bx, bm, rows); }
+  __device__ __forceinline__ int64_t out_row(const TileInfo &t, int lr) const { return t.row0 + lr; }
   __device__ __forceinline__ Row row(int64_t r, int64_t a_off) const {
     return Row{pq + (int64_t)dst[r] * (4 * f) + a_off, pq + (int64_t)src[r] * (4 * f) + 2 * f + a_off,
                rtab + (int64_t)combo[r] * (2 * f) + a_off};
@@ -131,6 +151,42 @@ struct EdgeA {
   __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &, int, int) const {
     return gs_relu4((w.a + w.b) + w.t);
   }
+};
+
+// Degree-folded PNAConv update: rows are grouped by in-degree (tile table from csr.hip), so
+// the three degree scalers are folded into per-degree weights and K shrinks from 13F to 5F:
+//   u_t[i] = [W_x | W_id + amp(d) W_amp + att(d) W_att]_t(d_i)  .  cat[x_i, A_t[i]]
+struct PostFoldA {
+  const float *x;          // [N,F]
+  const float *agg;        // [N,2,4F]
+  const int32_t *perm;     // [N] node ids grouped by degree
+  const int32_t *tiles;    // [max_tiles,4] = (degree, first slot, count, 0)
+  const int32_t *num_tiles;
+  int64_t w_stride;        // floats between two degrees' weight blocks
+  int f;
+  struct Row {
+    const float *px;
+    const float *pa;
+  };
+  struct Raw {
+    f32x4 v;
+  };
+  __device__ __forceinline__ TileInfo tile(int bx, int) const {
+    if (bx >= num_tiles[0]) return TileInfo{0, 0, 0};
+    const int32_t *t = tiles + 4 * (int64_t)bx;
+    return TileInfo{t[1], t[2], (int64_t)t[0] * w_stride};
+  }
+  __device__ __forceinline__ int64_t out_row(const TileInfo &t, int lr) const { return perm[t.row0 + lr]; }
+  __device__ __forceinline__ Row row(int64_t slot, int64_t a_off) const {
+    const int64_t node = perm[slot];
+    return Row{x + node * f, agg + node * (int64_t)(8 * f) + a_off};
+  }
+  __device__ __forceinline__ Raw load(const Row &r, int k0, int c) const {
+    const int j = k0 - f;  // wave-uniform; F is a multiple of BK
+    const float *p = j < 0 ? r.px + k0 : r.pa + j;
+    return Raw{gs_ld4(p + c)};
+  }
+  __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &, int, int) const { return w.v; }
 };
 
 struct GemmBatch {
@@ -155,7 +211,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   constexpr int WTM = BM / WAVES_M;
   constexpr int WTN = BN / WAVES_N;
-  static_assert(WTM == kBnRowsPerGroup, "BatchNorm partials assume 64 rows per wave");
+  static_assert(!STATS || WTM == kBnRowsPerGroup, "BatchNorm partials assume 64 rows per wave");
   constexpr int TM = WTM / 32;
   constexpr int TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile is a multiple of the 32x32 MFMA");
@@ -170,7 +226,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   const int wave = tid >> 6;
   const int wm = wave / WAVES_N;
   const int wn = wave % WAVES_N;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const TileInfo ti = ap.tile(blockIdx.x, BM);
+  if (ti.count <= 0) return;  // block-uniform, before any barrier
   const int n0 = blockIdx.y * BN;
   const GemmBatchEntry ent = batch.e[blockIdx.z];
 
@@ -181,14 +238,14 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   typename AProv::Row arow[A_LD4];
 #pragma unroll
   for (int j = 0; j < A_LD4; ++j) {
-    const int64_t r = m0 + r0 + 32 * j;
-    arow[j] = ap.row(r < m ? r : m - 1, ent.a_off);  // clamped: rows >= m are never stored
+    const int lr = r0 + 32 * j;
+    arow[j] = ap.row(ti.row0 + (lr < ti.count ? lr : ti.count - 1), ent.a_off);  // clamped rows are never stored
   }
   const float *wrow[B_LD4];
 #pragma unroll
   for (int j = 0; j < B_LD4; ++j) {
     const int n = n0 + r0 + 32 * j;
-    wrow[j] = ent.w + (int64_t)(n < n_out ? n : n_out - 1) * ldw;  // clamped: columns >= n_out never stored
+    wrow[j] = ent.w + ti.w_off + (int64_t)(n < n_out ? n : n_out - 1) * ldw;  // clamped columns never stored
   }
 
   f32x16 acc[TM][TN];
@@ -259,7 +316,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31,
   //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int half = lane >> 5;
-  const int64_t wrow0 = m0 + wm * WTM;
+  const int wrow0 = wm * WTM;  // block-local
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * WTN + j * 32 + (lane & 31);
@@ -276,8 +333,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const bool ok = row < m;
+          const int lr = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const bool ok = lr < ti.count;
           sum += ok ? acc[i][j][r] + bias : 0.f;
           cnt += ok ? 1 : 0;
         }
@@ -287,9 +344,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int lr = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           const float d = (acc[i][j][r] + bias) - mean;
-          m2 += row < m ? d * d : 0.f;
+          m2 += lr < ti.count ? d * d : 0.f;
         }
       const float o_mean = __shfl_xor(mean, 32);
       const float o_m2 = __shfl_xor(m2, 32);
@@ -312,23 +369,25 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      int64_t grow[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        grow[r] = ap.out_row(ti, lr < ti.count ? lr : ti.count - 1);
+      }
       float res[16];
       if (RESID) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int64_t row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          row = row < m ? row : m - 1;
-          res[r] = epi.residual[row * epi.ldr + colc];
-        }
+        for (int r = 0; r < 16; ++r) res[r] = epi.residual[grow[r] * epi.ldr + colc];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int lr = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         float v = acc[i][j][r] + bias;
         if (AFFINE) v = v * sc + sh;
         v = epi.relu_out ? fmaxf(v, 0.f) : v;
         if (RESID) v += res[r];
-        if (row < m && col_ok) ent.out[row * ldo + col] = v;
+        if (lr < ti.count && col_ok) ent.out[grow[r] * ldo + col] = v;
       }
     }
   }
@@ -337,22 +396,61 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
 // --------------------------------------------------------------------------
 // host-side dispatch
 // --------------------------------------------------------------------------
+// Tile configurations (block BM x BN, 4 waves).  Skinny f32 GEMMs (M large, N and K small) are
+// latency- and quantisation-bound rather than operand-bandwidth-bound (f32 MFMA is 16x slower
+// than bf16 per FLOP), so small tiles with more resident waves win; see DESIGN.md.
+enum GemmCfg { kCfg256x32 = 0, kCfg128x64 = 1, kCfg128x128 = 2, kCfg64x64 = 3, kCfg64x128 = 4, kCfg128x32 = 5,
+               kNumCfg = 6 };
+static const int kCfgBM[kNumCfg] = {256, 128, 128, 64, 64, 128};
+static const int kCfgBN[kNumCfg] = {32, 64, 128, 64, 128, 32};
+static const bool kCfgStatsOk[kNumCfg] = {true, true, true, false, true, false};
+static int g_cfg_override = -1;  // gnnsaft_debug_set_gemm_config (tuning only)
+
+static int pick_cfg(int64_t m, int n_out, bool stats) {
+  if (g_cfg_override >= 0 && g_cfg_override < kNumCfg && (!stats || kCfgStatsOk[g_cfg_override]))
+    return g_cfg_override;
+  if (n_out <= 32) return stats ? kCfg256x32 : kCfg128x32;
+  if (n_out <= 64 || (n_out % 128) == 64) return stats ? kCfg128x64 : kCfg64x64;
+  return kCfg64x128;
+}
+
+template <int BM, int BN, int WM, int WN, class AProv, bool STATS, bool AFFINE, bool RESID>
+static void launch_one(const AProv &ap, int nbatch, const GemmBatch &b, int64_t ldw, int64_t ldo, int64_t m,
+                       int n_out, int k, const EpiArgs &ea, int64_t grid_x, hipStream_t stream) {
+  if constexpr (STATS && BM / WM != kBnRowsPerGroup) {
+    return;  // not instantiated: BatchNorm partials need 64-row wave tiles
+  } else {
+    const dim3 grid((unsigned)(grid_x > 0 ? grid_x : gs_ceil_div(m, BM)), (unsigned)gs_ceil_div(n_out, BN),
+                    (unsigned)nbatch);
+    hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, AProv, STATS, AFFINE, RESID>), grid, dim3(256), 0, stream, ap, b,
+                       ldw, ldo, m, n_out, k, ea);
+  }
+}
+
 template <class AProv, bool STATS, bool AFFINE, bool RESID>
 static int launch_cfg(const AProv &ap, int nbatch, const GemmBatch &b, int64_t ldw, int64_t ldo, int64_t m, int n_out,
-                      int k, const EpiArgs &ea, hipStream_t stream) {
-  const dim3 block(256);
-  if (n_out <= 32) {
-    const dim3 grid((unsigned)gs_ceil_div(m, 256), (unsigned)gs_ceil_div(n_out, 32), (unsigned)nbatch);
-    hipLaunchKernelGGL((k_gemm_f32<256, 32, 4, 1, AProv, STATS, AFFINE, RESID>), grid, block, 0, stream, ap, b, ldw,
-                       ldo, m, n_out, k, ea);
-  } else if (n_out <= 64 || (n_out % 128) == 64) {
-    const dim3 grid((unsigned)gs_ceil_div(m, 128), (unsigned)gs_ceil_div(n_out, 64), (unsigned)nbatch);
-    hipLaunchKernelGGL((k_gemm_f32<128, 64, 2, 2, AProv, STATS, AFFINE, RESID>), grid, block, 0, stream, ap, b, ldw,
-                       ldo, m, n_out, k, ea);
-  } else {
-    const dim3 grid((unsigned)gs_ceil_div(m, 128), (unsigned)gs_ceil_div(n_out, 128), (unsigned)nbatch);
-    hipLaunchKernelGGL((k_gemm_f32<128, 128, 2, 2, AProv, STATS, AFFINE, RESID>), grid, block, 0, stream, ap, b, ldw,
-                       ldo, m, n_out, k, ea);
+                      int k, const EpiArgs &ea, hipStream_t stream, int cfg = -1, int64_t grid_x = 0) {
+  if (cfg < 0) cfg = pick_cfg(m, n_out, STATS);
+  GS_REQUIRE(cfg >= 0 && cfg < kNumCfg && (!STATS || kCfgStatsOk[cfg]), GNNSAFT_ERR_UNSUPPORTED);
+  switch (cfg) {
+    case kCfg256x32:
+      launch_one<256, 32, 4, 1, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream);
+      break;
+    case kCfg128x64:
+      launch_one<128, 64, 2, 2, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream);
+      break;
+    case kCfg128x128:
+      launch_one<128, 128, 2, 2, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream);
+      break;
+    case kCfg64x64:
+      launch_one<64, 64, 2, 2, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream);
+      break;
+    case kCfg64x128:
+      launch_one<64, 128, 1, 4, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream);
+      break;
+    default:
+      launch_one<128, 32, 4, 1, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream);
+      break;
   }
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
@@ -421,5 +519,31 @@ int launch_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *c
   LinearEpilogue epi;
   return dispatch<EdgeA, false>(ap, 2, e, hidden, ldo, rows, hidden, hidden, epi, stream);
 }
+
+int pna_fold_tile_rows(int hidden) {
+  // rows per degree tile = BM of the configuration the folded update runs with (n_out = F/2 per tower)
+  return kCfgBM[pick_cfg(1 << 20, hidden / 2, false)];
+}
+
+int launch_pna_update_folded(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
+                             const int32_t *num_tiles, int64_t max_tiles, int64_t n, int hidden,
+                             const float *w_eff /* [D,2,F/2,5F] */, const float *b_post0, const float *b_post1,
+                             float *u, hipStream_t stream) {
+  GS_REQUIRE(x && agg && perm && tiles && num_tiles && w_eff && u, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
+  if (n == 0) return GNNSAFT_OK;
+  const int64_t per_tower = (int64_t)(hidden / 2) * 5 * hidden;
+  PostFoldA ap{x, agg, perm, tiles, num_tiles, 2 * per_tower, hidden};
+  GemmBatch b;
+  b.e[0] = GemmBatchEntry{w_eff, b_post0, u, 0};
+  b.e[1] = GemmBatchEntry{w_eff + per_tower, b_post1, u + hidden / 2, 4 * (int64_t)hidden};
+  b.e[2] = b.e[0];
+  b.e[3] = b.e[0];
+  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr};
+  return launch_cfg<PostFoldA, false, false, false>(ap, 2, b, 5 * (int64_t)hidden, hidden, n, hidden / 2, 5 * hidden,
+                                                    ea, stream, pick_cfg(1 << 20, hidden / 2, false), max_tiles);
+}
+
+void debug_set_gemm_config(int cfg) { g_cfg_override = cfg; }
 
 }  // namespace gs

@@ -179,3 +179,35 @@ def mape(pred, target) -> torch.Tensor:
     check(lib.gnnsaft_mape(_p(pred.contiguous()), _p(target.contiguous()), pred.numel(), _p(out), _stream(pred)),
           "gnnsaft_mape")
     return out
+
+
+def degree_tiles(rowptr: torch.Tensor, hidden: int):
+    """-> perm[N], tiles[cap,4], num_tiles[1], hist3[3*buckets] (first `buckets` ints: degree histogram), err."""
+    n = rowptr.shape[0] - 1
+    dev = rowptr.device
+    cap = int(lib.gnnsaft_degree_tiles_capacity(n, hidden))
+    buckets = int(lib.gnnsaft_degree_buckets())
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    tiles = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    num_tiles = torch.zeros(1, dtype=torch.int32, device=dev)
+    hist3 = torch.zeros(3 * buckets, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib.gnnsaft_degree_tiles(_p(rowptr), n, hidden, _p(perm), _p(tiles), _p(num_tiles), _p(hist3), _p(err),
+                                   _stream(rowptr)), "gnnsaft_degree_tiles")
+    return perm, tiles, num_tiles, hist3, err
+
+
+def pna_update_folded(x, agg, perm, tiles, num_tiles, hist3, avg_deg_log, w_post0, b_post0, w_post1, b_post1):
+    n, h = x.shape
+    buckets = int(lib.gnnsaft_degree_buckets())
+    w_eff = torch.full((buckets, 2, h // 2, 5 * h), float("nan"), dtype=torch.float32, device=x.device)
+    check(lib.gnnsaft_pna_fold_post_weights(_p(w_post0), _p(w_post1), _p(avg_deg_log), _p(hist3), h, _p(w_eff),
+                                            _stream(x)), "gnnsaft_pna_fold_post_weights")
+    u = torch.empty((n, h), dtype=torch.float32, device=x.device)
+    check(lib.gnnsaft_pna_update_folded(_p(x), _p(agg), _p(perm), _p(tiles), _p(num_tiles), n, h, _p(w_eff),
+                                        _p(b_post0), _p(b_post1), _p(u), _stream(x)), "gnnsaft_pna_update_folded")
+    return u
+
+
+def debug_set_gemm_config(cfg: int) -> None:
+    lib.gnnsaft_debug_set_gemm_config(int(cfg))

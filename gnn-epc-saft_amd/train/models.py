@@ -151,6 +151,10 @@ class PNAPCSAFT(nn.Module):
         self._workspace: Optional[torch.Tensor] = None
         self._err_flag: Optional[torch.Tensor] = None
         self._loss_buf: Optional[torch.Tensor] = None
+        # Degree-folded update GEMM (K = 5F instead of 13F): exact for in-degrees (self-loop included) below
+        # gnnsaft_degree_buckets() = 32, which covers molecular graphs; set False for other graphs
+        # (input_error_flags() reports GNNSAFT_FLAG_BAD_DEGREE = 8 if a larger degree was met).
+        self.fold_degree_scalers = True
         self._profile = None  # gnnsaft_profile* (bench.py attaches one to time kernels with HIP events)
 
     # ------------------------------------------------------------------ host glue
@@ -197,6 +201,7 @@ class PNAPCSAFT(nn.Module):
         bn0 = self.batch_norms[0].module if len(self.batch_norms) else self.mlp[4 * d.num_mlp_layers][1]
         d.bn_eps = bn0.eps
         d.bn_momentum = 0.1 if bn0.momentum is None else bn0.momentum
+        d.fold_degree_scalers = int(self.fold_degree_scalers)
         return d
 
     def _check_mode(self, x: torch.Tensor) -> None:

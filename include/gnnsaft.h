@@ -42,6 +42,8 @@ extern "C" {
 #define GNNSAFT_FLAG_BAD_EDGE 1     /* edge_index value outside [0,N)            */
 #define GNNSAFT_FLAG_BAD_ATTR 2     /* categorical index outside its vocabulary  */
 #define GNNSAFT_FLAG_BAD_BATCH 4    /* batch not sorted / outside [0,G)          */
+#define GNNSAFT_FLAG_BAD_DEGREE 8   /* in-degree >= gnnsaft_degree_buckets() with */
+                                    /* degree folding on: disable folding         */
 
 #define GNNSAFT_MAX_TABLES 16
 #define GNNSAFT_TOWERS 2            /* models.py:76 towers=2                      */
@@ -176,6 +178,33 @@ int gnnsaft_pna_update(const float *x, const float *agg, const float *log_amp,
                        float *u /* [N,F] */, gnnsaft_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
+/* Degree-folded form of the same update (default in gnnsaft_forward): nodes  */
+/* are grouped by in-degree into tiles of one degree each, the three scalers  */
+/* are folded into per-degree weights W_eff(d) = [W_x | W_id + amp(d) W_amp + */
+/* att(d) W_att], and the GEMM's K shrinks from 13F to 5F.                    */
+/*   gnnsaft_degree_tiles: perm[N] (node ids grouped by degree), tiles[cap,4] */
+/*     = (degree, first slot, rows, 0), num_tiles[1], hist3[3*buckets] scratch */
+/*     whose first `buckets` ints are the degree histogram;                    */
+/*   gnnsaft_pna_fold_post_weights: w_eff[buckets,2,F/2,5F] (only degrees      */
+/*     present in the histogram are written);                                  */
+/*   gnnsaft_pna_update_folded: u[N,F] as gnnsaft_pna_update.                  */
+/* ------------------------------------------------------------------------ */
+int32_t gnnsaft_degree_buckets(void);
+int64_t gnnsaft_degree_tiles_capacity(int64_t num_nodes, int32_t hidden);
+int gnnsaft_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm,
+                         int32_t *tiles, int32_t *num_tiles, int32_t *hist3, int32_t *err_flag,
+                         gnnsaft_stream_t stream);
+int gnnsaft_pna_fold_post_weights(const float *w_post0, const float *w_post1,
+                                  const float *avg_deg_log, const int32_t *hist, int32_t hidden,
+                                  float *w_eff, gnnsaft_stream_t stream);
+int gnnsaft_pna_update_folded(const float *x, const float *agg, const int32_t *perm,
+                              const int32_t *tiles, const int32_t *num_tiles, int64_t num_nodes,
+                              int32_t hidden, const float *w_eff, const float *b_post0,
+                              const float *b_post1, float *u, gnnsaft_stream_t stream);
+/* tuning hook: force a GEMM tile configuration (-1 = heuristic) */
+void gnnsaft_debug_set_gemm_config(int32_t cfg);
+
+/* ------------------------------------------------------------------------ */
 /* BatchNorm (PyG BatchNorm -> torch BatchNorm1d, models.py:82,87,94,98,128).  */
 /* training != 0: combine the (mean, M2) partials written by gnnsaft_linear    */
 /* into batch statistics, update running_mean / running_var (unbiased) /       */
@@ -224,6 +253,7 @@ typedef struct gnnsaft_model_desc {
   int32_t bond_dims[GNNSAFT_MAX_TABLES];
   float bn_eps;
   float bn_momentum;
+  int32_t fold_degree_scalers; /* 1: degree-folded update (in-degrees < gnnsaft_degree_buckets()) */
 } gnnsaft_model_desc;
 
 int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);

@@ -1,0 +1,108 @@
+"""Degree-folded PNAConv update (degree tiles + per-degree weights + K = 5F GEMM) against the
+oracle's update stage, and the GEMM tile configurations against an f64 product."""
+
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import mini4, rel_err  # noqa: E402
+from test_gpu_stages import BOND_DIMS, DEV, K, conv_pieces, synth  # noqa: E402
+
+
+@pytest.mark.parametrize("case", ["mini4", "synth300"])
+@pytest.mark.parametrize("hidden", [64, 128, 256])
+def test_degree_tiles_partition_nodes_by_degree(case, hidden):
+    d = mini4() if case == "mini4" else synth(300, 17)
+    n = d.x.shape[0]
+    k = K()
+    rowptr, *_ = k.csr_build(d.edge_index.to(DEV), d.edge_attr.to(DEV), n, BOND_DIMS, True)
+    perm, tiles, num_tiles, hist3, err = k.degree_tiles(rowptr, hidden)
+    assert int(err.item()) == 0
+    deg = (rowptr[1:] - rowptr[:-1]).cpu().long()
+    buckets = hist3.numel() // 3
+    assert torch.equal(hist3[:buckets].cpu().long(), torch.bincount(deg, minlength=buckets))
+    perm = perm.cpu().long()
+    assert torch.equal(torch.sort(perm).values, torch.arange(n))          # a permutation
+    nt = int(num_tiles.item())
+    tiles = tiles.cpu().long()[:nt]
+    covered = torch.zeros(n, dtype=torch.bool)
+    for dgr, start, count, _ in tiles.tolist():
+        assert count >= 1
+        rows = perm[start:start + count]
+        assert bool((deg[rows] == dgr).all())                            # one degree per tile
+        assert not bool(covered[rows].any())
+        covered[rows] = True
+    assert bool(covered.all())
+
+
+def test_degree_overflow_is_flagged():
+    # a hub with 40 in-edges exceeds the 32 degree buckets
+    n = 41
+    src = torch.arange(1, n)
+    ei = torch.stack([src, torch.zeros(n - 1, dtype=torch.int64)])
+    ea = torch.zeros((n - 1, 3), dtype=torch.int64)
+    rowptr, *_ = K().csr_build(ei.to(DEV), ea.to(DEV), n, BOND_DIMS, True)
+    *_, err = K().degree_tiles(rowptr, 64)
+    assert int(err.item()) & 8
+
+
+@pytest.mark.parametrize("hidden", [64, 128, 256])
+@pytest.mark.parametrize("loops", [True, False])
+def test_folded_update_matches_oracle(hidden, loops):
+    d = synth(40, hidden + 5)
+    conv, x, btabs, ei, edge_emb = conv_pieces(hidden, 1, 1, d, loops, seed=4)
+    n = x.shape[0]
+    stages = {}
+    with torch.no_grad():
+        conv.double()(x.double(), ei, edge_emb.double(), stages)
+        conv.float()
+    k = K()
+    g = lambda t: t.detach().float().contiguous().to(DEV)
+    rowptr, src, dst, combo, la, lt, err = k.csr_build(d.edge_index.to(DEV), d.edge_attr.to(DEV), n, BOND_DIMS, loops)
+    perm, tiles, num_tiles, hist3, err = k.degree_tiles(rowptr, hidden)
+    agg = g(stages["agg"])
+    q0, q1 = conv.post_nns[0], conv.post_nns[1]
+    u = k.pna_update_folded(g(x), agg, perm, tiles, num_tiles, hist3, g(conv.aggr_module.avg_deg_log), g(q0[0].weight),
+                            g(q0[0].bias), g(q1[0].weight), g(q1[0].bias))
+    assert not torch.isnan(u).any()
+    assert rel_err(u.cpu(), stages["post"]) < 3e-6
+    # and the unfolded (scalers-on-load) kernel agrees with it
+    u2 = k.pna_update(g(x), agg, la, lt, g(conv.aggr_module.avg_deg_log), g(q0[0].weight), g(q0[0].bias),
+                      g(q1[0].weight), g(q1[0].bias))
+    assert rel_err(u2.cpu(), stages["post"]) < 6e-6  # K = 13F f32 chain (3328 terms at H=256)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("m,n_out,k", [(1000, 128, 128), (257, 96, 64), (77, 5, 16)])
+def test_every_gemm_tile_configuration(cfg, m, n_out, k):
+    torch.manual_seed(cfg * 7 + m)
+    a, w, b = torch.randn(m, k), torch.randn(n_out, k) / math.sqrt(k), torch.randn(n_out)
+    ref = a.double() @ w.double().t() + b.double()
+    kk = K()
+    kk.debug_set_gemm_config(cfg)
+    try:
+        out = kk.linear(a.to(DEV), w.to(DEV), b.to(DEV)).cpu()
+    finally:
+        kk.debug_set_gemm_config(-1)
+    assert rel_err(out, ref) < 2e-6
+
+
+def test_forward_folded_equals_unfolded():
+    import copy
+
+    import gnn_epc_saft_amd as G
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    data = make_synthetic_batch(64, 5)
+    torch.manual_seed(0)
+    m = G.PNAPCSAFT(128, G.PnaconvsParams(3, 1, 2, degree_histogram(data), skip_connections=True, self_loops=True),
+                    G.ReadoutMLPParams(1, 3)).to(DEV).eval()
+    with torch.no_grad():
+        m.fold_degree_scalers = True
+        a = m(data.to(DEV))
+        m.fold_degree_scalers = False
+        b = m(data.to(DEV))
+    assert m.input_error_flags() == 0
+    assert rel_err(a, b) < 2e-6
