@@ -58,11 +58,15 @@ SIGNATURES = {
     "gnnsaft_pna_update": (c_int32, [P, P, P, P, P, c_int64, c_int32, P, P, P, P, P, P]),
     "gnnsaft_degree_buckets": (c_int32, []),
     "gnnsaft_degree_tiles_capacity": (c_int64, [c_int64, c_int32]),
+    "gnnsaft_degree_scratch_ints": (c_size_t, [c_int64]),
     "gnnsaft_degree_tiles": (c_int32, [P, c_int64, c_int32, P, P, P, P, P, P]),
     "gnnsaft_pna_fold_post_weights": (c_int32, [P, P, P, P, c_int32, P, P]),
     "gnnsaft_pna_update_folded": (c_int32, [P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
     "gnnsaft_debug_set_gemm_config": (None, [c_int32]),
     "gnnsaft_bn_finalize": (c_int32, [P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, c_int32, P, P, P]),
+    "gnnsaft_bn_train_apply": (c_int32, [P, P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, P, P, P]),
+    "gnnsaft_pna_fold_post_weights_multi": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                                      P, c_int32, P, c_int64, P]),
     "gnnsaft_bn_relu_residual": (c_int32, [P, P, P, P, P, c_int64, c_int32, P]),
     "gnnsaft_add_pool": (c_int32, [P, P, c_int64, c_int64, c_int32, P, P]),
     "gnnsaft_mape": (c_int32, [P, P, c_int64, P, P]),

@@ -1,0 +1,136 @@
+// Train-mode BatchNorm in one launch after the producing GEMM
+// (/root/reference/gnnepcsaft/train/models.py:82,87,94,98,128-131; torch BatchNorm1d
+// semantics: SURVEY.md Appendix A.3).  The GEMM epilogue left per-64-row (mean, M2) column
+// partials; every workgroup here owns a 32-column slab x a chunk of rows, first folds the
+// partials of its 32 columns (Chan's combine in f64 -- redundant across the row chunks, but a
+// few tens of KB of L2 reads per workgroup, cheaper than a separate finalize launch), then
+// streams its rows:  out = relu(y * scale + shift) (+ residual).  Row chunk 0 also updates
+// running_mean / running_var (unbiased) / num_batches_tracked.
+#include "common.hpp"
+
+namespace gs {
+
+constexpr int kBnCols = 32;
+constexpr int kBnGroupLanes = 8;  // 256 threads = 8 partial-lanes x 32 columns
+
+__global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict__ stats, const float *__restrict__ y,
+                                                        int64_t rows, int ch, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta,
+                                                        float *__restrict__ running_mean,
+                                                        float *__restrict__ running_var, int64_t *nbt,
+                                                        float momentum, float eps,
+                                                        const float *__restrict__ residual, float *__restrict__ out,
+                                                        int64_t rows_per_chunk) {
+  __shared__ double s_n[kBnGroupLanes][kBnCols], s_mean[kBnGroupLanes][kBnCols], s_m2[kBnGroupLanes][kBnCols];
+  __shared__ float s_scale[kBnCols], s_shift[kBnCols];
+  const int c0 = blockIdx.x * kBnCols;
+  const int cl = threadIdx.x & (kBnCols - 1);
+  const int gl = threadIdx.x / kBnCols;
+  const int col = c0 + cl;
+  const bool col_ok = col < ch;
+  const int colc = col_ok ? col : ch - 1;
+
+  // ---- phase 1: batch statistics of this slab's columns
+  const int64_t groups = (rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int64_t g = gl; g < groups; g += kBnGroupLanes) {
+    const int64_t left = rows - g * kBnRowsPerGroup;
+    const double gn = (double)(left < kBnRowsPerGroup ? left : kBnRowsPerGroup);
+    const double gm = (double)stats[(g * 2 + 0) * ch + colc];
+    const double g2 = (double)stats[(g * 2 + 1) * ch + colc];
+    const double tot = n + gn;
+    const double delta = gm - mean;
+    mean += delta * (gn / tot);
+    m2 += g2 + delta * delta * (n * gn / tot);
+    n = tot;
+  }
+  s_n[gl][cl] = n;
+  s_mean[gl][cl] = mean;
+  s_m2[gl][cl] = m2;
+  __syncthreads();
+  if (gl == 0) {
+    for (int o = 1; o < kBnGroupLanes; ++o) {
+      const double nb = s_n[o][cl];
+      const double tot = n + nb;
+      if (tot > 0.0) {
+        const double delta = s_mean[o][cl] - mean;
+        mean += delta * (nb / tot);
+        m2 += s_m2[o][cl] + delta * delta * (n * nb / tot);
+        n = tot;
+      }
+    }
+    const float mean_f = (float)mean;
+    const float var_f = (float)(m2 / n);  // biased: used for normalisation
+    const float rstd = 1.f / sqrtf(var_f + eps);
+    const float sc = rstd * (gamma != nullptr ? gamma[colc] : 1.f);
+    s_scale[cl] = sc;
+    s_shift[cl] = (beta != nullptr ? beta[colc] : 0.f) - mean_f * sc;
+    if (blockIdx.y == 0 && col_ok) {
+      if (running_mean != nullptr) {
+        const float unbiased = (float)(n > 1.0 ? m2 / (n - 1.0) : m2);
+        running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * mean_f;
+        running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
+      }
+      if (nbt != nullptr && col == 0) nbt[0] += 1;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: normalise + ReLU (+ residual) over this workgroup's rows; 8 float4 per 32-column row
+  const int c4 = (threadIdx.x & 7) * 4;
+  const int rl = threadIdx.x >> 3;  // 32 rows per pass
+  if (c0 + c4 >= ch) return;
+  const f32x4 sc = {s_scale[c4], s_scale[c4 + 1], s_scale[c4 + 2], s_scale[c4 + 3]};
+  const f32x4 sh = {s_shift[c4], s_shift[c4 + 1], s_shift[c4 + 2], s_shift[c4 + 3]};
+  const int64_t r_beg = (int64_t)blockIdx.y * rows_per_chunk;
+  int64_t r_end = r_beg + rows_per_chunk;
+  if (r_end > rows) r_end = rows;
+  for (int64_t r = r_beg + rl; r < r_end; r += 64) {
+    const int64_t r2 = r + 32;
+    const bool two = r2 < r_end;
+    const int64_t o1 = r * ch + c0 + c4;
+    const int64_t o2 = (two ? r2 : r) * ch + c0 + c4;
+    const f32x4 v1 = gs_ld4(y + o1), v2 = gs_ld4(y + o2);
+    f32x4 q1 = {0.f, 0.f, 0.f, 0.f}, q2 = {0.f, 0.f, 0.f, 0.f};
+    if (residual != nullptr) {
+      q1 = gs_ld4(residual + o1);
+      q2 = gs_ld4(residual + o2);
+    }
+    f32x4 a = v1 * sc + sh, b = v2 * sc + sh;
+    a.x = fmaxf(a.x, 0.f);
+    a.y = fmaxf(a.y, 0.f);
+    a.z = fmaxf(a.z, 0.f);
+    a.w = fmaxf(a.w, 0.f);
+    b.x = fmaxf(b.x, 0.f);
+    b.y = fmaxf(b.y, 0.f);
+    b.z = fmaxf(b.z, 0.f);
+    b.w = fmaxf(b.w, 0.f);
+    gs_st4(out + o1, a + q1);
+    if (two) gs_st4(out + o2, b + q2);
+  }
+}
+
+}  // namespace gs
+
+extern "C" int gnnsaft_bn_train_apply(const float *stats, const float *y, int64_t num_rows, int32_t channels,
+                                      const float *gamma, const float *beta, float *running_mean,
+                                      float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
+                                      const float *residual, float *out, gnnsaft_stream_t stream) {
+  GS_REQUIRE(stats && y && out, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(num_rows >= 2, GNNSAFT_ERR_SHAPE);  // torch: "Expected more than 1 value per channel"
+  GS_REQUIRE(channels >= 4 && (channels % 4) == 0, GNNSAFT_ERR_SHAPE);
+  const int slabs = (channels + gs::kBnCols - 1) / gs::kBnCols;
+  // ~1024 workgroups in total, at least 64 rows each
+  int64_t chunks = 1024 / slabs;
+  const int64_t max_chunks = gs_ceil_div(num_rows, 64);
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  int64_t rows_per_chunk = gs_ceil_div(num_rows, chunks);
+  rows_per_chunk = gs_ceil_div(rows_per_chunk, 64) * 64;
+  chunks = gs_ceil_div(num_rows, rows_per_chunk);
+  hipLaunchKernelGGL(gs::k_bn_train_apply, dim3((unsigned)slabs, (unsigned)chunks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), stats, y, num_rows, channels, gamma, beta, running_mean,
+                     running_var, num_batches_tracked, momentum, eps, residual, out, rows_per_chunk);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}

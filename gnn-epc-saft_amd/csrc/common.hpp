@@ -38,7 +38,7 @@ struct GemmBatchEntry {
   int64_t a_off;      // provider-specific offset (e.g. tower offset into agg)
 };
 
-constexpr int kMaxGemmBatch = 4;
+constexpr int kMaxGemmBatch = 8;
 constexpr int kBnRowsPerGroup = 64;  // rows covered by one wave's accumulator tile
 
 struct LinearEpilogue {

@@ -22,72 +22,121 @@ __device__ __forceinline__ int clamp_degree(int d, int32_t *err) {
   return d;
 }
 
-// wave-aggregated histogram: one atomic per (wave, distinct degree)
-__global__ __launch_bounds__(256) void k_degree_hist(const int32_t *__restrict__ rowptr, int64_t n,
-                                                     int32_t *__restrict__ hist, int32_t *err) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
-  const int d = live ? clamp_degree(rowptr[i + 1] - rowptr[i], err) : -1;
-  unsigned long long todo = __ballot(live);
-  while (todo != 0ull) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int dl = __shfl(d, leader);
-    const unsigned long long same = __ballot(d == dl);
-    if ((threadIdx.x & 63) == leader) atomicAdd(&hist[dl], __popcll(same));
-    todo &= ~same;
-  }
-}
+constexpr int kDegBlock = 1024;  // nodes per workgroup in the bucketing passes (16 waves)
 
-// single thread: bucket starts (slots in `perm`) and the tile table
-__global__ void k_degree_tiles(const int32_t *__restrict__ hist, int tile_rows, int32_t *__restrict__ start,
-                               int32_t *__restrict__ cursor, int32_t *__restrict__ tiles,
-                               int32_t *__restrict__ num_tiles) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int slot = 0, nt = 0;
-  for (int d = 0; d < kDegreeBuckets; ++d) {
-    const int cnt = hist[d];
-    start[d] = slot;
-    cursor[d] = 0;
-    for (int o = 0; o < cnt; o += tile_rows) {
-      tiles[4 * nt + 0] = d;
-      tiles[4 * nt + 1] = slot + o;
-      tiles[4 * nt + 2] = cnt - o < tile_rows ? cnt - o : tile_rows;
-      tiles[4 * nt + 3] = 0;
-      ++nt;
-    }
-    slot += cnt;
-  }
-  num_tiles[0] = nt;
-}
-
-__global__ __launch_bounds__(256) void k_degree_fill(const int32_t *__restrict__ rowptr, int64_t n,
-                                                     const int32_t *__restrict__ start,
-                                                     int32_t *__restrict__ cursor, int32_t *__restrict__ perm) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
-  int d = live ? rowptr[i + 1] - rowptr[i] : -1;
-  if (d >= kDegreeBuckets) d = kDegreeBuckets - 1;
+// Per-wave counts of every degree among this wave's nodes -> wcount[wave][bucket] (LDS), and
+// the lane's rank among the wave's nodes of the same degree.  No atomics: deterministic.
+__device__ __forceinline__ int wave_degree_ranks(int d, bool live, int32_t (*wcount)[kDegreeBuckets]) {
   const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  int rank = 0;
   unsigned long long todo = __ballot(live);
   while (todo != 0ull) {
     const int leader = __ffsll((long long)todo) - 1;
     const int dl = __shfl(d, leader);
-    const unsigned long long same = __ballot(d == dl);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&cursor[dl], __popcll(same));
-    base = __shfl(base, leader);
-    if (d == dl) perm[start[dl] + base + __popcll(same & ((1ull << lane) - 1ull))] = (int32_t)i;
+    const unsigned long long same = __ballot(live && d == dl);
+    if (lane == leader) wcount[wave][dl] = __popcll(same);
+    if (live && d == dl) rank = __popcll(same & ((1ull << lane) - 1ull));
     todo &= ~same;
   }
+  return rank;
+}
+
+// pass 1: block_hist[b][d] = number of nodes with (clamped) in-degree d in block b
+__global__ __launch_bounds__(kDegBlock) void k_degree_block_hist(const int32_t *__restrict__ rowptr, int64_t n,
+                                                                 int32_t *__restrict__ block_hist, int32_t *err) {
+  __shared__ int32_t wcount[kDegBlock / 64][kDegreeBuckets];
+  for (int t = threadIdx.x; t < (kDegBlock / 64) * kDegreeBuckets; t += kDegBlock) (&wcount[0][0])[t] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * kDegBlock + threadIdx.x;
+  const bool live = i < n;
+  const int d = live ? clamp_degree(rowptr[i + 1] - rowptr[i], err) : 0;
+  wave_degree_ranks(d, live, wcount);
+  __syncthreads();
+  if (threadIdx.x < kDegreeBuckets) {
+    int tot = 0;
+    for (int w = 0; w < kDegBlock / 64; ++w) tot += wcount[w][threadIdx.x];
+    block_hist[(int64_t)blockIdx.x * kDegreeBuckets + threadIdx.x] = tot;
+  }
+}
+
+// pass 2 (one workgroup): per-bucket exclusive scan over blocks (in place), bucket starts, tile table
+__global__ __launch_bounds__(256) void k_degree_plan(int32_t *__restrict__ block_hist, int64_t num_blocks,
+                                                     int tile_rows, int32_t *__restrict__ hist,
+                                                     int32_t *__restrict__ start, int32_t *__restrict__ tiles,
+                                                     int32_t *__restrict__ num_tiles) {
+  __shared__ int32_t s_cnt[kDegreeBuckets], s_start[kDegreeBuckets], s_tile0[kDegreeBuckets + 1];
+  if (threadIdx.x < kDegreeBuckets) {
+    int run = 0;
+    for (int64_t b = 0; b < num_blocks; ++b) {
+      const int c = block_hist[b * kDegreeBuckets + threadIdx.x];
+      block_hist[b * kDegreeBuckets + threadIdx.x] = run;
+      run += c;
+    }
+    s_cnt[threadIdx.x] = run;
+    hist[threadIdx.x] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int slot = 0, nt = 0;
+    for (int d = 0; d < kDegreeBuckets; ++d) {
+      s_start[d] = slot;
+      s_tile0[d] = nt;
+      slot += s_cnt[d];
+      nt += (s_cnt[d] + tile_rows - 1) / tile_rows;
+    }
+    s_tile0[kDegreeBuckets] = nt;
+    num_tiles[0] = nt;
+  }
+  __syncthreads();
+  if (threadIdx.x < kDegreeBuckets) start[threadIdx.x] = s_start[threadIdx.x];
+  const int nt = s_tile0[kDegreeBuckets];
+  for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+    int d = 0;
+    while (t >= s_tile0[d + 1]) ++d;
+    const int o = (t - s_tile0[d]) * tile_rows;
+    tiles[4 * t + 0] = d;
+    tiles[4 * t + 1] = s_start[d] + o;
+    tiles[4 * t + 2] = s_cnt[d] - o < tile_rows ? s_cnt[d] - o : tile_rows;
+    tiles[4 * t + 3] = 0;
+  }
+}
+
+// pass 3: perm[start[d] + (nodes of degree d in earlier blocks / waves / lanes)] = node
+__global__ __launch_bounds__(kDegBlock) void k_degree_fill(const int32_t *__restrict__ rowptr, int64_t n,
+                                                           const int32_t *__restrict__ block_base,
+                                                           const int32_t *__restrict__ start,
+                                                           int32_t *__restrict__ perm) {
+  __shared__ int32_t wcount[kDegBlock / 64][kDegreeBuckets];
+  for (int t = threadIdx.x; t < (kDegBlock / 64) * kDegreeBuckets; t += kDegBlock) (&wcount[0][0])[t] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * kDegBlock + threadIdx.x;
+  const bool live = i < n;
+  int d = live ? rowptr[i + 1] - rowptr[i] : 0;
+  if (d >= kDegreeBuckets) d = kDegreeBuckets - 1;
+  const int rank = wave_degree_ranks(d, live, wcount);
+  __syncthreads();
+  if (!live) return;
+  const int wave = threadIdx.x >> 6;
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += wcount[w][d];
+  perm[start[d] + block_base[(int64_t)blockIdx.x * kDegreeBuckets + d] + before + rank] = (int32_t)i;
 }
 
 // w_eff[d][t][o][0:F] = W_t[o][0:F];  w_eff[d][t][o][F+j] = W_t[o][F+j] + amp(d) W_t[o][5F+j] + att(d) W_t[o][9F+j]
-__global__ __launch_bounds__(256) void k_fold_post_weights(const float *__restrict__ w0, const float *__restrict__ w1,
-                                                           const float *__restrict__ avg,
-                                                           const int32_t *__restrict__ hist, int f,
-                                                           float *__restrict__ w_eff) {
-  const int d = blockIdx.z;
+struct FoldLayers {
+  const float *w0[GNNSAFT_MAX_FOLD_LAYERS];
+  const float *w1[GNNSAFT_MAX_FOLD_LAYERS];
+  const float *avg[GNNSAFT_MAX_FOLD_LAYERS];
+};
+
+__global__ __launch_bounds__(256) void k_fold_post_weights(FoldLayers fl, const int32_t *__restrict__ hist, int f,
+                                                           float *__restrict__ w_eff_all, int64_t layer_stride) {
+  const int d = blockIdx.z % kDegreeBuckets;
+  const int layer = blockIdx.z / kDegreeBuckets;
   if (hist[d] == 0) return;  // degree absent from this batch
+  const float *w0 = fl.w0[layer], *w1 = fl.w1[layer], *avg = fl.avg[layer];
+  float *w_eff = w_eff_all + layer * layer_stride;
   const int t = blockIdx.y;
   const int per_row4 = 5 * f / 4;
   const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,20 +165,49 @@ extern "C" int64_t gnnsaft_degree_tiles_capacity(int64_t num_nodes, int32_t hidd
 
 extern "C" int32_t gnnsaft_degree_buckets(void) { return gs::kDegreeBuckets; }
 
+extern "C" size_t gnnsaft_degree_scratch_ints(int64_t num_nodes) {
+  // hist[B] | start[B] | block_hist[ceil(N/1024)][B]
+  return (size_t)(2 + gs_ceil_div(num_nodes > 0 ? num_nodes : 1, gs::kDegBlock)) * gs::kDegreeBuckets;
+}
+
 extern "C" int gnnsaft_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm,
-                                    int32_t *tiles, int32_t *num_tiles, int32_t *hist3, int32_t *err_flag,
+                                    int32_t *tiles, int32_t *num_tiles, int32_t *scratch, int32_t *err_flag,
                                     gnnsaft_stream_t stream) {
-  GS_REQUIRE(rowptr && perm && tiles && num_tiles && hist3, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(rowptr && perm && tiles && num_tiles && scratch, GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_nodes >= 1 && hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int32_t *hist = hist3, *start = hist3 + gs::kDegreeBuckets, *cursor = hist3 + 2 * gs::kDegreeBuckets;
-  hipError_t e = hipMemsetAsync(hist, 0, sizeof(int32_t) * gs::kDegreeBuckets, st);
-  if (e != hipSuccess) return (int)e;
-  const dim3 grid((unsigned)gs_ceil_div(num_nodes, 256)), block(256);
-  hipLaunchKernelGGL(gs::k_degree_hist, grid, block, 0, st, rowptr, num_nodes, hist, err_flag);
-  hipLaunchKernelGGL(gs::k_degree_tiles, dim3(1), dim3(64), 0, st, hist, gs::pna_fold_tile_rows(hidden), start, cursor,
-                     tiles, num_tiles);
-  hipLaunchKernelGGL(gs::k_degree_fill, grid, block, 0, st, rowptr, num_nodes, start, cursor, perm);
+  int32_t *hist = scratch, *start = scratch + gs::kDegreeBuckets, *block_hist = scratch + 2 * gs::kDegreeBuckets;
+  const int64_t nb = gs_ceil_div(num_nodes, gs::kDegBlock);
+  hipLaunchKernelGGL(gs::k_degree_block_hist, dim3((unsigned)nb), dim3(gs::kDegBlock), 0, st, rowptr, num_nodes,
+                     block_hist, err_flag);
+  hipLaunchKernelGGL(gs::k_degree_plan, dim3(1), dim3(256), 0, st, block_hist, nb, gs::pna_fold_tile_rows(hidden),
+                     hist, start, tiles, num_tiles);
+  hipLaunchKernelGGL(gs::k_degree_fill, dim3((unsigned)nb), dim3(gs::kDegBlock), 0, st, rowptr, num_nodes,
+                     block_hist, start, perm);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const float *const *w_post0_host,
+                                                   const float *const *w_post1_host,
+                                                   const float *const *avg_deg_log_host, const int32_t *hist,
+                                                   int32_t hidden, float *w_eff, int64_t layer_stride,
+                                                   gnnsaft_stream_t stream) {
+  GS_REQUIRE(w_post0_host && w_post1_host && avg_deg_log_host && hist && w_eff, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(num_layers >= 1 && num_layers <= GNNSAFT_MAX_FOLD_LAYERS, GNNSAFT_ERR_SHAPE);
+  gs::FoldLayers fl;
+  for (int i = 0; i < GNNSAFT_MAX_FOLD_LAYERS; ++i) {
+    const int j = i < num_layers ? i : 0;
+    fl.w0[i] = w_post0_host[j];
+    fl.w1[i] = w_post1_host[j];
+    fl.avg[i] = avg_deg_log_host[j];
+    GS_REQUIRE(fl.w0[i] && fl.w1[i] && fl.avg[i], GNNSAFT_ERR_NULL);
+  }
+  const int64_t threads = (int64_t)(hidden / 2) * (5 * hidden / 4);
+  const dim3 grid((unsigned)gs_ceil_div(threads, 256), 2, (unsigned)(gs::kDegreeBuckets * num_layers));
+  hipLaunchKernelGGL(gs::k_fold_post_weights, grid, dim3(256), 0, static_cast<hipStream_t>(stream), fl, hist, hidden,
+                     w_eff, layer_stride);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }
@@ -137,14 +215,7 @@ extern "C" int gnnsaft_degree_tiles(const int32_t *rowptr, int64_t num_nodes, in
 extern "C" int gnnsaft_pna_fold_post_weights(const float *w_post0, const float *w_post1, const float *avg_deg_log,
                                              const int32_t *hist, int32_t hidden, float *w_eff,
                                              gnnsaft_stream_t stream) {
-  GS_REQUIRE(w_post0 && w_post1 && avg_deg_log && hist && w_eff, GNNSAFT_ERR_NULL);
-  GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
-  const int64_t threads = (int64_t)(hidden / 2) * (5 * hidden / 4);
-  const dim3 grid((unsigned)gs_ceil_div(threads, 256), 2, gs::kDegreeBuckets);
-  hipLaunchKernelGGL(gs::k_fold_post_weights, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w_post0, w_post1,
-                     avg_deg_log, hist, hidden, w_eff);
-  GS_CHECK_LAUNCH();
-  return GNNSAFT_OK;
+  return gnnsaft_pna_fold_post_weights_multi(1, &w_post0, &w_post1, &avg_deg_log, hist, hidden, w_eff, 0, stream);
 }
 
 extern "C" int gnnsaft_pna_update_folded(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,

@@ -104,8 +104,9 @@ static int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, int64_t 
   p.msg0 = d->pre_layers > 1 ? take(ee * 2 * h * 4) : 0;
   p.msg1 = d->pre_layers > 2 ? take(ee * 2 * h * 4) : p.msg0;
   p.cemb = take((size_t)p.combos * h * 4);
-  p.cenc = take((size_t)p.combos * h * 4);
-  p.rtab = take((size_t)p.combos * 2 * h * 4);
+  const size_t nl = (size_t)(d->num_layers > 0 ? d->num_layers : 1);
+  p.cenc = take(nl * (size_t)p.combos * h * 4);
+  p.rtab = take(nl * (size_t)p.combos * 2 * h * 4);
   const size_t max_rows = nn > gg ? nn : gg;
   p.stats = take(((max_rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup) * 2 * h * 4);
   p.scale = take(h * 4);
@@ -118,8 +119,8 @@ static int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, int64_t 
   p.perm = take(nn * 4);
   p.tiles = take((size_t)p.tile_cap * 16);
   p.num_tiles = take(4);
-  p.hist3 = take(3 * kDegreeBuckets * 4);
-  p.weff = d->fold_degree_scalers ? take((size_t)kDegreeBuckets * 5 * h * h * 4) : 0;
+  p.hist3 = take(gnnsaft_degree_scratch_ints(n) * 4);
+  p.weff = d->fold_degree_scalers ? take(nl * (size_t)kDegreeBuckets * 5 * h * h * 4) : 0;
   p.total = off;
   return GNNSAFT_OK;
 }
@@ -178,9 +179,8 @@ static int linear_bn_relu(const float *a, int64_t lda, const float *w, const flo
       ProfScope ps(prof, GNNSAFT_PROF_LIN, st);
       GS_TRY(launch_linear(a, lda, 0, 1, &ent, k, n_out, rows, n_out, k, epi, st));
     }
-    GS_TRY(gnnsaft_bn_finalize(stats, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt, d->bn_momentum,
-                               d->bn_eps, 1, scale, shift, st));
-    GS_TRY(gnnsaft_bn_relu_residual(y_tmp, scale, shift, residual, out, rows, n_out, st));
+    GS_TRY(gnnsaft_bn_train_apply(stats, y_tmp, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt,
+                                  d->bn_momentum, d->bn_eps, residual, out, st));
   } else {
     GS_TRY(gnnsaft_bn_finalize(nullptr, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, nullptr, d->bn_momentum,
                                d->bn_eps, 0, scale, shift, st));
@@ -415,29 +415,83 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
   GS_TRY(gnnsaft_embed_sum(x_idx, n, d->num_atom_cols, atom_tab, d->atom_dims, h, F(p.x0), err_flag, st));
   GS_TRY(gnnsaft_bond_combo_embed(d->num_bond_cols, bond_tab, d->bond_dims, h, F(p.cemb), st));
 
-  float *xc = F(p.x0), *xn = F(p.x1);
-  for (int l = 0; l < d->num_layers; ++l) {
-    const float *avg = wc.f();
-    const float *we = wc.f(), *be = wc.f();
+  // ---- parse every layer's weights, then do the x-independent prologue work of ALL layers in a
+  //      few batched launches: edge-class tables (edge_encoder + pre_nns[t][0] edge block) and the
+  //      degree-folded update weights
+  struct LayerW {
+    const float *avg, *we, *be, *wlin, *blin;
     const float *wpre[2][8], *bpre[2][8], *wpost[2][8], *bpost[2][8];
-    GS_REQUIRE(d->pre_layers <= 8 && d->post_layers <= 8, GNNSAFT_ERR_UNSUPPORTED);
+    BnPtrs bn;
+  };
+  GS_REQUIRE(d->pre_layers <= 8 && d->post_layers <= 8, GNNSAFT_ERR_UNSUPPORTED);
+  std::vector<LayerW> lw(d->num_layers);
+  for (int l = 0; l < d->num_layers; ++l) {
+    LayerW &w = lw[l];
+    w.avg = wc.f();
+    w.we = wc.f();
+    w.be = wc.f();
     for (int t = 0; t < 2; ++t)
       for (int j = 0; j < d->pre_layers; ++j) {
-        wpre[t][j] = wc.f();
-        bpre[t][j] = wc.f();
+        w.wpre[t][j] = wc.f();
+        w.bpre[t][j] = wc.f();
       }
     for (int t = 0; t < 2; ++t)
       for (int j = 0; j < d->post_layers; ++j) {
-        wpost[t][j] = wc.f();
-        bpost[t][j] = wc.f();
+        w.wpost[t][j] = wc.f();
+        w.bpost[t][j] = wc.f();
       }
-    const float *wlin = wc.f(), *blin = wc.f();
-    BnPtrs bn = wc.bn();
+    w.wlin = wc.f();
+    w.blin = wc.f();
+    w.bn = wc.bn();
     GS_REQUIRE(wc.ok, GNNSAFT_ERR_NULL);
+  }
+  const int64_t cstride = p.combos * (int64_t)h;          // floats per layer in cenc
+  const int64_t rstride = p.combos * (int64_t)(2 * h);    // floats per layer in rtab
+  const int64_t wstride = (int64_t)kDegreeBuckets * 5 * h * h;  // floats per layer in weff
+  for (int l0 = 0; l0 < d->num_layers; l0 += kMaxGemmBatch) {
+    const int nl = d->num_layers - l0 < kMaxGemmBatch ? d->num_layers - l0 : kMaxGemmBatch;
+    GemmBatchEntry e[kMaxGemmBatch];
+    for (int i = 0; i < nl; ++i) e[i] = GemmBatchEntry{lw[l0 + i].we, lw[l0 + i].be, F(p.cenc) + (l0 + i) * cstride, 0};
+    LinearEpilogue epi;
+    GS_TRY(launch_linear(F(p.cemb), h, 0, nl, e, h, h, p.combos, h, h, epi, st));
+  }
+  for (int i0 = 0; i0 < 2 * d->num_layers; i0 += kMaxGemmBatch) {
+    const int ne = 2 * d->num_layers - i0 < kMaxGemmBatch ? 2 * d->num_layers - i0 : kMaxGemmBatch;
+    GemmBatchEntry e[kMaxGemmBatch];
+    for (int i = 0; i < ne; ++i) {
+      const int l = (i0 + i) / 2, t = (i0 + i) % 2;
+      e[i] = GemmBatchEntry{lw[l].wpre[t][0] + 2 * h, lw[l].bpre[t][0], F(p.rtab) + l * rstride + t * h, l * cstride};
+    }
+    LinearEpilogue epi;
+    GS_TRY(launch_linear(F(p.cenc), h, 0, ne, e, 3 * (int64_t)h, 2 * (int64_t)h, p.combos, h, h, epi, st));
+  }
+  if (d->fold_degree_scalers) {
+    for (int l0 = 0; l0 < d->num_layers; l0 += GNNSAFT_MAX_FOLD_LAYERS) {
+      const int nl = d->num_layers - l0 < GNNSAFT_MAX_FOLD_LAYERS ? d->num_layers - l0 : GNNSAFT_MAX_FOLD_LAYERS;
+      const float *w0[GNNSAFT_MAX_FOLD_LAYERS], *w1[GNNSAFT_MAX_FOLD_LAYERS], *av[GNNSAFT_MAX_FOLD_LAYERS];
+      for (int i = 0; i < nl; ++i) {
+        w0[i] = lw[l0 + i].wpost[0][0];
+        w1[i] = lw[l0 + i].wpost[1][0];
+        av[i] = lw[l0 + i].avg;
+      }
+      GS_TRY(gnnsaft_pna_fold_post_weights_multi(nl, w0, w1, av, I(p.hist3), h, F(p.weff) + l0 * wstride, wstride, st));
+    }
+  }
 
-    // message: node terms + edge-class table (+ extra pre-layers on edge rows)
-    GS_TRY(edge_table(F(p.cemb), p.combos, h, we, be, wpre[0][0], bpre[0][0], wpre[1][0], bpre[1][0], F(p.cenc),
-                      F(p.rtab), st));
+  float *xc = F(p.x0), *xn = F(p.x1);
+  for (int l = 0; l < d->num_layers; ++l) {
+    const LayerW &w = lw[l];
+    const float *avg = w.avg;
+    const float *const(*wpre)[8] = w.wpre;
+    const float *const(*bpre)[8] = w.bpre;
+    const float *const(*wpost)[8] = w.wpost;
+    const float *const(*bpost)[8] = w.bpost;
+    const float *wlin = w.wlin, *blin = w.blin;
+    const BnPtrs bn = w.bn;
+    const float *rtab = F(p.rtab) + l * rstride;
+    const float *weff = F(p.weff) + l * wstride;
+
+    // message: node terms (+ extra pre-layers on edge rows)
     {
       ProfScope ps(prof, GNNSAFT_PROF_NODE_TERMS, st);
       GS_TRY(node_terms(xc, n, h, wpre[0][0], wpre[1][0], F(p.pq), st));
@@ -446,7 +500,7 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     if (d->pre_layers > 1) {
       float *ma = F(p.msg0), *mb = F(p.msg1);
       GemmBatchEntry e[2] = {{wpre[0][1], bpre[0][1], ma, 0}, {wpre[1][1], bpre[1][1], ma + h, 0}};
-      GS_TRY(launch_pna_edge_mlp(I(p.src), I(p.dst), I(p.combo), p.ep, h, F(p.pq), F(p.rtab), e, 2 * (int64_t)h, st));
+      GS_TRY(launch_pna_edge_mlp(I(p.src), I(p.dst), I(p.combo), p.ep, h, F(p.pq), rtab, e, 2 * (int64_t)h, st));
       for (int j = 2; j < d->pre_layers; ++j) {
         GemmBatchEntry e2[2] = {{wpre[0][j], bpre[0][j], mb, 0}, {wpre[1][j], bpre[1][j], mb + h, h}};
         LinearEpilogue epi;
@@ -460,15 +514,14 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     // K4 aggregation
     {
       ProfScope ps(prof, GNNSAFT_PROF_AGGREGATE, st);
-      GS_TRY(gnnsaft_pna_aggregate(I(p.rowptr), I(p.src), I(p.combo), n, h, F(p.pq), F(p.rtab), msgs, F(p.agg), st));
+      GS_TRY(gnnsaft_pna_aggregate(I(p.rowptr), I(p.src), I(p.combo), n, h, F(p.pq), rtab, msgs, F(p.agg), st));
     }
     // update: first post-layer with scalers on load, then extra post-layers
     float *ua = F(p.u0), *ub = F(p.u1);
     if (d->fold_degree_scalers) {
-      GS_TRY(gnnsaft_pna_fold_post_weights(wpost[0][0], wpost[1][0], avg, I(p.hist3), h, F(p.weff), st));
       ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
-      GS_TRY(launch_pna_update_folded(xc, F(p.agg), I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap, n, h,
-                                      F(p.weff), bpost[0][0], bpost[1][0], ua, st));
+      GS_TRY(launch_pna_update_folded(xc, F(p.agg), I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap, n, h, weff,
+                                      bpost[0][0], bpost[1][0], ua, st));
     } else {
       GemmBatchEntry e[2] = {{wpost[0][0], bpost[0][0], ua, 0}, {wpost[1][0], bpost[1][0], ua + h / 2, 0}};
       ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);

@@ -406,12 +406,14 @@ static const int kCfgBN[kNumCfg] = {32, 64, 128, 64, 128, 32};
 static const bool kCfgStatsOk[kNumCfg] = {true, true, true, false, true, false};
 static int g_cfg_override = -1;  // gnnsaft_debug_set_gemm_config (tuning only)
 
-static int pick_cfg(int64_t m, int n_out, bool stats) {
+static int pick_cfg(int64_t m, int n_out, int k, bool stats) {
   if (g_cfg_override >= 0 && g_cfg_override < kNumCfg && (!stats || kCfgStatsOk[g_cfg_override]))
     return g_cfg_override;
+  // measured on MI355X (tools/gemm_tune.py, profiles/r01_gemm_tile_sweep.txt)
   if (n_out <= 32) return stats ? kCfg256x32 : kCfg128x32;
-  if (n_out <= 64 || (n_out % 128) == 64) return stats ? kCfg128x64 : kCfg64x64;
-  return kCfg64x128;
+  if (stats) return n_out <= 64 ? kCfg128x64 : kCfg128x128;
+  if (n_out >= 128 && k >= 1024) return kCfg128x128;  // long-K update at H = 256
+  return kCfg64x64;
 }
 
 template <int BM, int BN, int WM, int WN, class AProv, bool STATS, bool AFFINE, bool RESID>
@@ -430,7 +432,7 @@ static void launch_one(const AProv &ap, int nbatch, const GemmBatch &b, int64_t 
 template <class AProv, bool STATS, bool AFFINE, bool RESID>
 static int launch_cfg(const AProv &ap, int nbatch, const GemmBatch &b, int64_t ldw, int64_t ldo, int64_t m, int n_out,
                       int k, const EpiArgs &ea, hipStream_t stream, int cfg = -1, int64_t grid_x = 0) {
-  if (cfg < 0) cfg = pick_cfg(m, n_out, STATS);
+  if (cfg < 0) cfg = pick_cfg(m, n_out, k, STATS);
   GS_REQUIRE(cfg >= 0 && cfg < kNumCfg && (!STATS || kCfgStatsOk[cfg]), GNNSAFT_ERR_UNSUPPORTED);
   switch (cfg) {
     case kCfg256x32:
@@ -522,7 +524,7 @@ int launch_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *c
 
 int pna_fold_tile_rows(int hidden) {
   // rows per degree tile = BM of the configuration the folded update runs with (n_out = F/2 per tower)
-  return kCfgBM[pick_cfg(1 << 20, hidden / 2, false)];
+  return kCfgBM[pick_cfg(1 << 20, hidden / 2, 5 * hidden, false)];
 }
 
 int launch_pna_update_folded(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
@@ -537,11 +539,10 @@ int launch_pna_update_folded(const float *x, const float *agg, const int32_t *pe
   GemmBatch b;
   b.e[0] = GemmBatchEntry{w_eff, b_post0, u, 0};
   b.e[1] = GemmBatchEntry{w_eff + per_tower, b_post1, u + hidden / 2, 4 * (int64_t)hidden};
-  b.e[2] = b.e[0];
-  b.e[3] = b.e[0];
+  for (int i = 2; i < kMaxGemmBatch; ++i) b.e[i] = b.e[0];
   EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr};
   return launch_cfg<PostFoldA, false, false, false>(ap, 2, b, 5 * (int64_t)hidden, hidden, n, hidden / 2, 5 * hidden,
-                                                    ea, stream, pick_cfg(1 << 20, hidden / 2, false), max_tiles);
+                                                    ea, stream, pick_cfg(1 << 20, hidden / 2, 5 * hidden, false), max_tiles);
 }
 
 void debug_set_gemm_config(int cfg) { g_cfg_override = cfg; }

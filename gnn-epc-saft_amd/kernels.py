@@ -190,7 +190,7 @@ def degree_tiles(rowptr: torch.Tensor, hidden: int):
     perm = torch.empty(n, dtype=torch.int32, device=dev)
     tiles = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
     num_tiles = torch.zeros(1, dtype=torch.int32, device=dev)
-    hist3 = torch.zeros(3 * buckets, dtype=torch.int32, device=dev)
+    hist3 = torch.zeros(int(lib.gnnsaft_degree_scratch_ints(n)), dtype=torch.int32, device=dev)
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     check(lib.gnnsaft_degree_tiles(_p(rowptr), n, hidden, _p(perm), _p(tiles), _p(num_tiles), _p(hist3), _p(err),
                                    _stream(rowptr)), "gnnsaft_degree_tiles")
@@ -211,3 +211,12 @@ def pna_update_folded(x, agg, perm, tiles, num_tiles, hist3, avg_deg_log, w_post
 
 def debug_set_gemm_config(cfg: int) -> None:
     lib.gnnsaft_debug_set_gemm_config(int(cfg))
+
+
+def bn_train_apply(stats, y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum: float, eps: float,
+                   residual=None) -> torch.Tensor:
+    out = torch.empty_like(y)
+    check(lib.gnnsaft_bn_train_apply(_p(stats), _p(y), y.shape[0], y.shape[1], _p(gamma), _p(beta), _p(running_mean),
+                                     _p(running_var), _p(num_batches_tracked), momentum, eps, _p(residual), _p(out),
+                                     _stream(y)), "gnnsaft_bn_train_apply")
+    return out

@@ -183,20 +183,30 @@ int gnnsaft_pna_update(const float *x, const float *agg, const float *log_amp,
 /* are folded into per-degree weights W_eff(d) = [W_x | W_id + amp(d) W_amp + */
 /* att(d) W_att], and the GEMM's K shrinks from 13F to 5F.                    */
 /*   gnnsaft_degree_tiles: perm[N] (node ids grouped by degree), tiles[cap,4] */
-/*     = (degree, first slot, rows, 0), num_tiles[1], hist3[3*buckets] scratch */
-/*     whose first `buckets` ints are the degree histogram;                    */
+/*     = (degree, first slot, rows, 0), num_tiles[1]; `scratch` holds          */
+/*     gnnsaft_degree_scratch_ints(N) int32, the first `buckets` of which are   */
+/*     the degree histogram afterwards.  Nodes of equal degree keep ascending   */
+/*     node order (no atomics: deterministic);                                  */
 /*   gnnsaft_pna_fold_post_weights: w_eff[buckets,2,F/2,5F] (only degrees      */
 /*     present in the histogram are written);                                  */
 /*   gnnsaft_pna_update_folded: u[N,F] as gnnsaft_pna_update.                  */
 /* ------------------------------------------------------------------------ */
 int32_t gnnsaft_degree_buckets(void);
 int64_t gnnsaft_degree_tiles_capacity(int64_t num_nodes, int32_t hidden);
+size_t gnnsaft_degree_scratch_ints(int64_t num_nodes);
 int gnnsaft_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm,
-                         int32_t *tiles, int32_t *num_tiles, int32_t *hist3, int32_t *err_flag,
+                         int32_t *tiles, int32_t *num_tiles, int32_t *scratch, int32_t *err_flag,
                          gnnsaft_stream_t stream);
 int gnnsaft_pna_fold_post_weights(const float *w_post0, const float *w_post1,
                                   const float *avg_deg_log, const int32_t *hist, int32_t hidden,
                                   float *w_eff, gnnsaft_stream_t stream);
+#define GNNSAFT_MAX_FOLD_LAYERS 8
+/* the same for several layers in one launch (weights of layer i at w_eff + i*layer_stride) */
+int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const float *const *w_post0_host,
+                                        const float *const *w_post1_host,
+                                        const float *const *avg_deg_log_host, const int32_t *hist,
+                                        int32_t hidden, float *w_eff, int64_t layer_stride,
+                                        gnnsaft_stream_t stream);
 int gnnsaft_pna_update_folded(const float *x, const float *agg, const int32_t *perm,
                               const int32_t *tiles, const int32_t *num_tiles, int64_t num_nodes,
                               int32_t hidden, const float *w_eff, const float *b_post0,
@@ -216,6 +226,13 @@ int gnnsaft_bn_finalize(const float *stats, int64_t num_rows, int32_t channels,
                         float *running_mean, float *running_var, int64_t *num_batches_tracked,
                         float momentum, float eps, int32_t training,
                         float *scale, float *shift, gnnsaft_stream_t stream);
+
+/* Train-mode BatchNorm + ReLU (+ residual) in ONE launch: folds the (mean, M2) partials */
+/* of gnnsaft_linear, normalises y, updates the running statistics and the counter.      */
+int gnnsaft_bn_train_apply(const float *stats, const float *y, int64_t num_rows, int32_t channels,
+                           const float *gamma, const float *beta, float *running_mean,
+                           float *running_var, int64_t *num_batches_tracked, float momentum,
+                           float eps, const float *residual, float *out, gnnsaft_stream_t stream);
 
 /* out = relu(y*scale + shift) (+ residual)   (models.py:128-131) */
 int gnnsaft_bn_relu_residual(const float *y, const float *scale, const float *shift,

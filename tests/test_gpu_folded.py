@@ -22,10 +22,12 @@ def test_degree_tiles_partition_nodes_by_degree(case, hidden):
     perm, tiles, num_tiles, hist3, err = k.degree_tiles(rowptr, hidden)
     assert int(err.item()) == 0
     deg = (rowptr[1:] - rowptr[:-1]).cpu().long()
-    buckets = hist3.numel() // 3
+    buckets = 32
     assert torch.equal(hist3[:buckets].cpu().long(), torch.bincount(deg, minlength=buckets))
     perm = perm.cpu().long()
     assert torch.equal(torch.sort(perm).values, torch.arange(n))          # a permutation
+    order = torch.argsort(deg, stable=True)
+    assert torch.equal(perm, order)                                       # ascending node id inside a degree
     nt = int(num_tiles.item())
     tiles = tiles.cpu().long()[:nt]
     covered = torch.zeros(n, dtype=torch.bool)
@@ -88,6 +90,29 @@ def test_every_gemm_tile_configuration(cfg, m, n_out, k):
     finally:
         kk.debug_set_gemm_config(-1)
     assert rel_err(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("rows,ch", [(1000, 128), (63, 64), (20480, 256), (2, 32), (777, 16)])
+def test_fused_batchnorm_train_apply(rows, ch):
+    torch.manual_seed(rows + ch)
+    a = torch.randn(rows, ch) * 2 + 3
+    bn = torch.nn.BatchNorm1d(ch).double().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2)
+    res = torch.randn(rows, ch)
+    g = lambda t: t.detach().float().to(DEV)
+    rm, rv, nbt = g(bn.running_mean), g(bn.running_var), torch.tensor(5, device=DEV)
+    y, stats = K().linear(a.to(DEV), torch.eye(ch).to(DEV), None, want_stats=True)
+    out = K().bn_train_apply(stats, y, g(bn.weight), g(bn.bias), rm, rv, nbt, 0.1, 1e-5, res.to(DEV)).cpu()
+    ref = torch.relu(bn(a.double())) + res.double()
+    assert rel_err(out, ref) < 2e-6
+    assert rel_err(rm.cpu(), bn.running_mean) < 1e-6 and rel_err(rv.cpu(), bn.running_var) < 1e-6
+    assert int(nbt.item()) == 6
+    out = K().bn_train_apply(stats, y, g(bn.weight), g(bn.bias), None, None, None, 0.1, 1e-5, None).cpu()
+    assert rel_err(out, torch.relu(bn(a.double()))) < 2e-6
 
 
 def test_forward_folded_equals_unfolded():
