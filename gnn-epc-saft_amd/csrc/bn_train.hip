@@ -33,16 +33,30 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
   // ---- phase 1: batch statistics of this slab's columns
   const int64_t groups = (rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup;
   double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int64_t g = gl; g < groups; g += kBnGroupLanes) {
-    const int64_t left = rows - g * kBnRowsPerGroup;
-    const double gn = (double)(left < kBnRowsPerGroup ? left : kBnRowsPerGroup);
-    const double gm = (double)stats[(g * 2 + 0) * ch + colc];
-    const double g2 = (double)stats[(g * 2 + 1) * ch + colc];
-    const double tot = n + gn;
-    const double delta = gm - mean;
-    mean += delta * (gn / tot);
-    m2 += g2 + delta * delta * (n * gn / tot);
-    n = tot;
+  constexpr int kUnroll = 8;  // independent loads in flight per thread (the combine itself is a serial chain)
+  for (int64_t g0 = gl; g0 < groups; g0 += kBnGroupLanes * kUnroll) {
+    float gm[kUnroll], g2[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      int64_t g = g0 + (int64_t)u * kBnGroupLanes;
+      g = g < groups ? g : groups - 1;
+      gm[u] = stats[(g * 2 + 0) * ch + colc];
+      g2[u] = stats[(g * 2 + 1) * ch + colc];
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t g = g0 + (int64_t)u * kBnGroupLanes;
+      if (g < groups) {
+        const int64_t left = rows - g * kBnRowsPerGroup;
+        const double gn = (double)(left < kBnRowsPerGroup ? left : kBnRowsPerGroup);
+        const double tot = n + gn;
+        const double w = gn / tot;
+        const double delta = (double)gm[u] - mean;
+        mean += delta * w;
+        m2 += (double)g2[u] + delta * delta * (n * w);
+        n = tot;
+      }
+    }
   }
   s_n[gl][cl] = n;
   s_mean[gl][cl] = mean;

@@ -256,11 +256,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  typename AProv::Raw ra[A_LD4];
-  f32x4 rb[B_LD4];
+  // two register sets: the global loads run TWO k-tiles ahead of the MFMAs (one tile of MFMA work,
+  // ~0.4 us for a 32x32 wave tile, is shorter than an L2/HBM round trip)
+  typename AProv::Raw ra0[A_LD4], ra1[A_LD4];
+  f32x4 rb0[B_LD4], rb1[B_LD4];
   const int nk = (k + BK - 1) / BK;
 
-  auto fetch = [&](int kt) {
+  auto fetch = [&](int kt, typename AProv::Raw(&ra)[A_LD4], f32x4(&rb)[B_LD4]) {
     const int k0 = kt * BK;
     const int kk = k0 + c4 * 4;
 #pragma unroll
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
 #pragma unroll
     for (int j = 0; j < B_LD4; ++j) rb[j] = gs_ld4(wrow[j] + (kk < k ? kk : 0));
   };
-  auto stash = [&](int kt) {
+  auto stash = [&](int kt, const typename AProv::Raw(&ra)[A_LD4], const f32x4(&rb)[B_LD4]) {
     float *as = lds + (kt & 1) * STAGE;
     float *bs = as + BM * LDS_LD;
     const int k0 = kt * BK;
@@ -282,16 +284,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
       if (r0 + 32 * j < BN) gs_st4(bs + (r0 + 32 * j) * LDS_LD + c4 * 4, kok ? rb[j] : zero);
   };
 
-  fetch(0);
-  stash(0);
-  __syncthreads();
-
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) fetch(kt + 1);
+  auto compute = [&](int kt) {
     const float *as = lds + (kt & 1) * STAGE + (wm * WTM + frag_row) * LDS_LD + frag_k;
     const float *bs = lds + (kt & 1) * STAGE + BM * LDS_LD + (wn * WTN + frag_row) * LDS_LD + frag_k;
 #pragma unroll
@@ -309,7 +304,35 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
-    if (more) stash(kt + 1);
+  };
+
+  // the big tile cannot afford the second register set (it would halve the waves per SIMD)
+  constexpr bool kDeepPrefetch = BM * BN <= 128 * 64;
+  fetch(0, ra0, rb0);
+  stash(0, ra0, rb0);
+  if (kDeepPrefetch && nk > 1) fetch(1, ra0, rb0);
+  __syncthreads();
+
+  if (!kDeepPrefetch) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 1 < nk;
+      if (more) fetch(kt + 1, ra0, rb0);
+      compute(kt);
+      if (more) stash(kt + 1, ra0, rb0);
+      __syncthreads();
+    }
+  }
+  for (int kt = 0; kDeepPrefetch && kt < nk; kt += 2) {
+    // LDS[0] = tile kt, set 0 = tile kt+1 in flight; start tile kt+2 into set 1
+    if (kt + 2 < nk) fetch(kt + 2, ra1, rb1);
+    compute(kt);
+    if (kt + 1 < nk) stash(kt + 1, ra0, rb0);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // LDS[1] = tile kt+1, set 1 = tile kt+2 in flight; start tile kt+3 into set 0
+    if (kt + 3 < nk) fetch(kt + 3, ra0, rb0);
+    compute(kt + 1);
+    if (kt + 2 < nk) stash(kt + 2, ra1, rb1);
     __syncthreads();
   }
 
@@ -474,18 +497,19 @@ static int dispatch(const AProv &ap, int nbatch, const GemmBatchEntry *entries, 
   GS_REQUIRE((epi.scale == nullptr) == (epi.shift == nullptr), GNNSAFT_ERR_NULL);
   GS_REQUIRE(epi.stats == nullptr || nbatch == 1, GNNSAFT_ERR_SHAPE);
   const bool st = epi.stats != nullptr, af = epi.scale != nullptr, rs = epi.residual != nullptr;
-  if (!FULL_EPILOGUES) {
+  if constexpr (!FULL_EPILOGUES) {
     GS_REQUIRE(!st && !af && !rs, GNNSAFT_ERR_UNSUPPORTED);
     return launch_cfg<AProv, false, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
+  } else {
+    if (st) {
+      GS_REQUIRE(!af && !rs, GNNSAFT_ERR_UNSUPPORTED);  // train mode writes the pre-BN tensor
+      return launch_cfg<AProv, true, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
+    }
+    if (af && rs) return launch_cfg<AProv, false, true, true>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
+    if (af) return launch_cfg<AProv, false, true, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
+    if (rs) return launch_cfg<AProv, false, false, true>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
+    return launch_cfg<AProv, false, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
   }
-  if (st) {
-    GS_REQUIRE(!af && !rs, GNNSAFT_ERR_UNSUPPORTED);  // train mode writes the pre-BN tensor
-    return launch_cfg<AProv, true, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
-  }
-  if (af && rs) return launch_cfg<AProv, false, true, true>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
-  if (af) return launch_cfg<AProv, false, true, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
-  if (rs) return launch_cfg<AProv, false, false, true>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
-  return launch_cfg<AProv, false, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
 }
 
 int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const GemmBatchEntry *entries, int64_t ldw,
