@@ -26,6 +26,7 @@ class ModelDesc(ctypes.Structure):
         ("self_loops", c_int32), ("training", c_int32), ("num_atom_cols", c_int32), ("num_bond_cols", c_int32),
         ("atom_dims", c_int32 * MAX_TABLES), ("bond_dims", c_int32 * MAX_TABLES),
         ("bn_eps", c_float), ("bn_momentum", c_float), ("fold_degree_scalers", c_int32),
+        ("fold_dst_term", c_int32),
     ]
 
 
@@ -66,7 +67,10 @@ SIGNATURES = {
     "gnnsaft_bn_finalize": (c_int32, [P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, c_int32, P, P, P]),
     "gnnsaft_bn_train_apply": (c_int32, [P, P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, P, P, P]),
     "gnnsaft_pna_fold_post_weights_multi": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
-                                                      P, c_int32, P, c_int64, P]),
+                                                      POINTER(c_void_p), POINTER(c_void_p), P, P, c_int32, P, c_int64,
+                                                      P]),
+    "gnnsaft_pna_src_terms": (c_int32, [P, c_int64, c_int32, P, P, P, P]),
+    "gnnsaft_pna_aggregate_src": (c_int32, [P, P, P, c_int64, c_int32, P, P, P, P]),
     "gnnsaft_bn_relu_residual": (c_int32, [P, P, P, P, P, c_int64, c_int32, P]),
     "gnnsaft_add_pool": (c_int32, [P, P, c_int64, c_int64, c_int32, P, P]),
     "gnnsaft_mape": (c_int32, [P, P, c_int64, P, P]),

@@ -13,9 +13,13 @@
 // x float4 = one full 1 KiB wave load at H = 128 (two waves per node at 256,
 // two nodes per wave at 64).
 //
-// Two sources for the message row r of node i:
-//   fused (pre_layers == 1): m = pq[i, c] + pq[src_r, 2F + c] + rtab[combo_r, c]
-//   materialised (pre_layers >= 2): m = msgs[r, c]
+// Three sources for the message row r of node i:
+//   kMsgs    (pre_layers >= 2): m = msgs[r, c]                      (materialised edge-MLP output)
+//   kFusedPQ (pre_layers == 1): m = pq[i, c] + pq[src_r, 2F + c] + rtab[combo_r, c]
+//   kFusedQ  (pre_layers == 1, destination term folded into the update weights):
+//                               m~ = q[src_r, c] + rtab[combo_r, c];  the outputs are the
+//            aggregates of m~ = m - P_i: mean/min/max shifted by the per-node constant P_i (which
+//            gnnsaft_pna_dst_fold moves into W_eff), std identical.
 //
 // HBM-bound.  Algorithmic bytes per launch:
 //   4*2F*E' (each message row once) + 8*E' (ids) + 4*2F*4*N (four aggregates).
@@ -24,27 +28,33 @@
 namespace gs {
 
 constexpr int kEdgeBatch = 4;  // gathers kept in flight per thread
+enum AggSource { kMsgs = 0, kFusedPQ = 1, kFusedQ = 2 };
 
-template <bool FUSED>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict__ rowptr,
                                                        const int32_t *__restrict__ src,
                                                        const int32_t *__restrict__ combo,
                                                        const float *__restrict__ pq, const float *__restrict__ rtab,
                                                        const float *__restrict__ msgs, float *__restrict__ agg,
-                                                       int64_t num_nodes, int f) {
-  const int lanes_per_node = f / 2;  // 2F floats / 4 per thread
+                                                       int64_t num_nodes, int f, RowSplit rs) {
+  // rs.per_row = f / 2 lanes per node (2F floats / 4 per thread)
   const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t node = slot / lanes_per_node;
+  int64_t node;
+  int lane_in_node;
+  gs_split(rs, slot, node, lane_in_node);
   if (node >= num_nodes) return;
-  const int c = (int)(slot - node * lanes_per_node) * 4;  // column in [0, 2F)
-  const int tower = c / f;
+  const int c = lane_in_node * 4;  // column in [0, 2F)
+  const int tower = c >= f ? 1 : 0;
   const int col = c - tower * f;
+  // source-term row layout: [N,4F] with Q at column 2F (kFusedPQ) or [N,2F] (kFusedQ)
+  const int q_stride = MODE == kFusedPQ ? 4 * f : 2 * f;
+  const int q_off = MODE == kFusedPQ ? 2 * f : 0;
 
   const int beg = rowptr[node];
   const int end = rowptr[node + 1];
 
   f32x4 p = {0.f, 0.f, 0.f, 0.f};
-  if (FUSED) p = gs_ld4(pq + node * (int64_t)(4 * f) + c);
+  if (MODE == kFusedPQ) p = gs_ld4(pq + node * (int64_t)(4 * f) + c);
 
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   const float inf = __builtin_huge_valf();
@@ -52,7 +62,7 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict
 
   for (int r0 = beg; r0 < end; r0 += kEdgeBatch) {
     f32x4 mrow[kEdgeBatch];
-    if (FUSED) {
+    if (MODE != kMsgs) {
       int sidx[kEdgeBatch], cidx[kEdgeBatch];
 #pragma unroll
       for (int j = 0; j < kEdgeBatch; ++j) {
@@ -63,11 +73,11 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict
       f32x4 q[kEdgeBatch], t[kEdgeBatch];
 #pragma unroll
       for (int j = 0; j < kEdgeBatch; ++j) {
-        q[j] = gs_ld4(pq + (int64_t)sidx[j] * (4 * f) + 2 * f + c);
+        q[j] = gs_ld4(pq + (int64_t)sidx[j] * q_stride + q_off + c);
         t[j] = gs_ld4(rtab + (int64_t)cidx[j] * (2 * f) + c);
       }
 #pragma unroll
-      for (int j = 0; j < kEdgeBatch; ++j) mrow[j] = (p + q[j]) + t[j];
+      for (int j = 0; j < kEdgeBatch; ++j) mrow[j] = MODE == kFusedPQ ? (p + q[j]) + t[j] : q[j] + t[j];
     } else {
 #pragma unroll
       for (int j = 0; j < kEdgeBatch; ++j) {
@@ -119,26 +129,44 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict
   gs_st4(o + 3 * f, sd);
 }
 
-}  // namespace gs
-
-extern "C" int gnnsaft_pna_aggregate(const int32_t *rowptr, const int32_t *src, const int32_t *combo,
-                                     int64_t num_nodes, int32_t hidden, const float *pq, const float *rtab,
-                                     const float *msgs, float *agg, gnnsaft_stream_t stream) {
+static int launch_aggregate(int mode, const int32_t *rowptr, const int32_t *src, const int32_t *combo,
+                            int64_t num_nodes, int32_t hidden, const float *pq, const float *rtab, const float *msgs,
+                            float *agg, hipStream_t st) {
   GS_REQUIRE(rowptr != nullptr && agg != nullptr, GNNSAFT_ERR_NULL);
   GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(num_nodes >= 0 && num_nodes * (int64_t)(hidden / 2) < ((int64_t)1 << 40), GNNSAFT_ERR_SHAPE);
   if (num_nodes == 0) return GNNSAFT_OK;
   const int64_t threads = num_nodes * (hidden / 2);
   const dim3 grid((unsigned)gs_ceil_div(threads, 256)), block(256);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (msgs == nullptr) {
-    GS_REQUIRE(src && combo && pq && rtab, GNNSAFT_ERR_NULL);
-    hipLaunchKernelGGL((gs::k_pna_aggregate<true>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
-                       num_nodes, hidden);
+  if (mode == kMsgs) {
+    GS_REQUIRE(msgs != nullptr, GNNSAFT_ERR_NULL);
+    hipLaunchKernelGGL((k_pna_aggregate<kMsgs>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
+                       num_nodes, hidden, gs_row_split(hidden / 2));
   } else {
-    hipLaunchKernelGGL((gs::k_pna_aggregate<false>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
-                       num_nodes, hidden);
+    GS_REQUIRE(src && combo && pq && rtab, GNNSAFT_ERR_NULL);
+    if (mode == kFusedPQ)
+      hipLaunchKernelGGL((k_pna_aggregate<kFusedPQ>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
+                         num_nodes, hidden, gs_row_split(hidden / 2));
+    else
+      hipLaunchKernelGGL((k_pna_aggregate<kFusedQ>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
+                         num_nodes, hidden, gs_row_split(hidden / 2));
   }
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
+}
+
+}  // namespace gs
+
+extern "C" int gnnsaft_pna_aggregate(const int32_t *rowptr, const int32_t *src, const int32_t *combo,
+                                     int64_t num_nodes, int32_t hidden, const float *pq, const float *rtab,
+                                     const float *msgs, float *agg, gnnsaft_stream_t stream) {
+  return gs::launch_aggregate(msgs != nullptr ? gs::kMsgs : gs::kFusedPQ, rowptr, src, combo, num_nodes, hidden, pq,
+                              rtab, msgs, agg, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gnnsaft_pna_aggregate_src(const int32_t *rowptr, const int32_t *src, const int32_t *combo,
+                                         int64_t num_nodes, int32_t hidden, const float *q, const float *rtab,
+                                         float *agg, gnnsaft_stream_t stream) {
+  return gs::launch_aggregate(gs::kFusedQ, rowptr, src, combo, num_nodes, hidden, q, rtab, nullptr, agg,
+                              static_cast<hipStream_t>(stream));
 }

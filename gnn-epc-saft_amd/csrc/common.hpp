@@ -24,6 +24,34 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static inline int64_t gs_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t gs_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// slot -> (row, lane-in-row) without 64-bit integer division (AMDGPU has no hardware divide):
+// shift/mask when `per_row` is a power of two (always for H in {64,128,256}), 32-bit division otherwise.
+struct RowSplit {
+  int per_row;
+  int shift;  // log2(per_row) or -1
+};
+static inline RowSplit gs_row_split(int per_row) {
+  int sh = -1;
+  if (per_row > 0 && (per_row & (per_row - 1)) == 0) {
+    sh = 0;
+    while ((1 << sh) < per_row) ++sh;
+  }
+  return RowSplit{per_row, sh};
+}
+__device__ __forceinline__ void gs_split(const RowSplit rs, int64_t slot, int64_t &row, int &lane) {
+  if (rs.shift >= 0) {
+    row = slot >> rs.shift;
+    lane = (int)(slot & (rs.per_row - 1));
+  } else if (slot < 0x7fffffffll) {
+    const unsigned s = (unsigned)slot, q = s / (unsigned)rs.per_row;
+    row = q;
+    lane = (int)(s - q * (unsigned)rs.per_row);
+  } else {
+    row = slot / rs.per_row;
+    lane = (int)(slot - row * rs.per_row);
+  }
+}
+
 __device__ __forceinline__ f32x4 gs_ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void gs_st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 

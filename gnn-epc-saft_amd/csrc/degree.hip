@@ -128,10 +128,48 @@ struct FoldLayers {
   const float *w0[GNNSAFT_MAX_FOLD_LAYERS];
   const float *w1[GNNSAFT_MAX_FOLD_LAYERS];
   const float *avg[GNNSAFT_MAX_FOLD_LAYERS];
+  const float *pre0[GNNSAFT_MAX_FOLD_LAYERS];  // pre_nns[t][0].weight [F,3F] or null: fold the destination term
+  const float *pre1[GNNSAFT_MAX_FOLD_LAYERS];
 };
 
+// Destination-term fold.  msg = P_i + m~ with P_i = W_dst x_i constant over a node's in-edges, so
+// mean/min/max(msg) = P_i + mean/min/max(m~) and std(msg) = std(m~).  The update's aggregate block
+// then contributes  sum_s scale_s(d) (W_s,mean + W_s,min + W_s,max) P_i, i.e. an extra x-block
+//   G_s = (W_s,mean + W_s,min + W_s,max) W_dst      ([F/2, F] per layer, tower, scaler s)
+// so the W_dst GEMM over all nodes disappears.  Tiled f32 matmul, 32x32 outputs per workgroup.
+__global__ __launch_bounds__(256) void k_dst_fold(FoldLayers fl, int f, float *__restrict__ g_all) {
+  __shared__ float as[32][33], bs[32][33];
+  const int layer = blockIdx.z / 6, rem = blockIdx.z % 6, t = rem / 3, sc = rem % 3;
+  const float *wpost = t == 0 ? fl.w0[layer] : fl.w1[layer];
+  const float *wpre = t == 0 ? fl.pre0[layer] : fl.pre1[layer];
+  const int o0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < f; k0 += 32) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = o0 + ty + 8 * r;  // A[o][k] = sum over the mean, min, max column blocks of scaler sc
+      const float *w = wpost + (int64_t)o * (13 * f) + f + sc * 4 * f + k0 + tx;
+      as[ty + 8 * r][tx] = (w[0] + w[f]) + w[2 * f];
+      bs[ty + 8 * r][tx] = wpre[(int64_t)(k0 + ty + 8 * r) * (3 * f) + j0 + tx];  // W_dst[k][j]
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const float b = bs[k][tx];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += as[ty + 8 * r][k] * b;
+    }
+    __syncthreads();
+  }
+  float *g = g_all + ((((int64_t)layer * 2 + t) * 3 + sc) * (f / 2)) * f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) g[(int64_t)(o0 + ty + 8 * r) * f + j0 + tx] = acc[r];
+}
+
 __global__ __launch_bounds__(256) void k_fold_post_weights(FoldLayers fl, const int32_t *__restrict__ hist, int f,
-                                                           float *__restrict__ w_eff_all, int64_t layer_stride) {
+                                                           float *__restrict__ w_eff_all, int64_t layer_stride,
+                                                           const float *__restrict__ g_all) {
   const int d = blockIdx.z % kDegreeBuckets;
   const int layer = blockIdx.z / kDegreeBuckets;
   if (hist[d] == 0) return;  // degree absent from this batch
@@ -144,13 +182,18 @@ __global__ __launch_bounds__(256) void k_fold_post_weights(FoldLayers fl, const 
   if (o >= f / 2) return;
   const int c = (int)(slot - o * per_row4) * 4;
   const float *w = (t == 0 ? w0 : w1) + o * (int64_t)(13 * f);
+  const float avgv = avg[0];
+  const float amp = logf((float)d + 1.f) / avgv;
+  const float att = avgv / logf(fmaxf((float)d, 1.f) + 1.f);
   f32x4 v;
   if (c < f) {
     v = gs_ld4(w + c);
+    if (g_all != nullptr && d > 0) {  // d == 0: no in-edge, the aggregates (and the P term) are zero
+      const float *g = g_all + ((((int64_t)layer * 2 + t) * 3) * (f / 2) + o) * f + c;
+      const int64_t gs = (int64_t)(f / 2) * f;
+      v = v + (gs_ld4(g) + gs_ld4(g + gs) * amp + gs_ld4(g + 2 * gs) * att);
+    }
   } else {
-    const float avgv = avg[0];
-    const float amp = logf((float)d + 1.f) / avgv;
-    const float att = avgv / logf(fmaxf((float)d, 1.f) + 1.f);
     v = gs_ld4(w + c) + gs_ld4(w + 4 * f + c) * amp + gs_ld4(w + 8 * f + c) * att;
   }
   gs_st4(w_eff + (((int64_t)d * 2 + t) * (f / 2) + o) * (int64_t)(5 * f) + c, v);
@@ -190,24 +233,36 @@ extern "C" int gnnsaft_degree_tiles(const int32_t *rowptr, int64_t num_nodes, in
 
 extern "C" int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const float *const *w_post0_host,
                                                    const float *const *w_post1_host,
-                                                   const float *const *avg_deg_log_host, const int32_t *hist,
-                                                   int32_t hidden, float *w_eff, int64_t layer_stride,
-                                                   gnnsaft_stream_t stream) {
+                                                   const float *const *avg_deg_log_host,
+                                                   const float *const *w_pre0_host, const float *const *w_pre1_host,
+                                                   float *g_scratch, const int32_t *hist, int32_t hidden,
+                                                   float *w_eff, int64_t layer_stride, gnnsaft_stream_t stream) {
   GS_REQUIRE(w_post0_host && w_post1_host && avg_deg_log_host && hist && w_eff, GNNSAFT_ERR_NULL);
   GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(num_layers >= 1 && num_layers <= GNNSAFT_MAX_FOLD_LAYERS, GNNSAFT_ERR_SHAPE);
+  const bool fold_dst = w_pre0_host != nullptr;
+  GS_REQUIRE(!fold_dst || (hidden % 64) == 0, GNNSAFT_ERR_SHAPE);  // k_dst_fold works on 32x32 tiles of [F/2, F]
+  GS_REQUIRE(!fold_dst || (w_pre1_host != nullptr && g_scratch != nullptr), GNNSAFT_ERR_NULL);
   gs::FoldLayers fl;
   for (int i = 0; i < GNNSAFT_MAX_FOLD_LAYERS; ++i) {
     const int j = i < num_layers ? i : 0;
     fl.w0[i] = w_post0_host[j];
     fl.w1[i] = w_post1_host[j];
     fl.avg[i] = avg_deg_log_host[j];
+    fl.pre0[i] = fold_dst ? w_pre0_host[j] : nullptr;
+    fl.pre1[i] = fold_dst ? w_pre1_host[j] : nullptr;
     GS_REQUIRE(fl.w0[i] && fl.w1[i] && fl.avg[i], GNNSAFT_ERR_NULL);
+    GS_REQUIRE(!fold_dst || (fl.pre0[i] && fl.pre1[i]), GNNSAFT_ERR_NULL);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (fold_dst) {
+    const dim3 gridg((unsigned)(hidden / 32), (unsigned)(hidden / 2 / 32), (unsigned)(6 * num_layers));
+    hipLaunchKernelGGL(gs::k_dst_fold, gridg, dim3(256), 0, st, fl, hidden, g_scratch);
   }
   const int64_t threads = (int64_t)(hidden / 2) * (5 * hidden / 4);
   const dim3 grid((unsigned)gs_ceil_div(threads, 256), 2, (unsigned)(gs::kDegreeBuckets * num_layers));
-  hipLaunchKernelGGL(gs::k_fold_post_weights, grid, dim3(256), 0, static_cast<hipStream_t>(stream), fl, hist, hidden,
-                     w_eff, layer_stride);
+  hipLaunchKernelGGL(gs::k_fold_post_weights, grid, dim3(256), 0, st, fl, hist, hidden, w_eff, layer_stride,
+                     fold_dst ? g_scratch : nullptr);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }
@@ -215,7 +270,8 @@ extern "C" int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const flo
 extern "C" int gnnsaft_pna_fold_post_weights(const float *w_post0, const float *w_post1, const float *avg_deg_log,
                                              const int32_t *hist, int32_t hidden, float *w_eff,
                                              gnnsaft_stream_t stream) {
-  return gnnsaft_pna_fold_post_weights_multi(1, &w_post0, &w_post1, &avg_deg_log, hist, hidden, w_eff, 0, stream);
+  return gnnsaft_pna_fold_post_weights_multi(1, &w_post0, &w_post1, &avg_deg_log, nullptr, nullptr, nullptr, hist,
+                                             hidden, w_eff, 0, stream);
 }
 
 extern "C" int gnnsaft_pna_update_folded(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,

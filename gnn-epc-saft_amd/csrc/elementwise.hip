@@ -13,22 +13,34 @@ struct TableSet {
 };
 
 // out[i, :] = sum_k tab_k[idx[i,k], :]   (left-to-right, as ogb's encoder loop)
+template <int MAXT>
 __global__ __launch_bounds__(256) void k_embed_sum(const int64_t *__restrict__ idx, int64_t rows, TableSet ts, int h,
-                                                   float *__restrict__ out, int32_t *err) {
-  const int per_row = h / 4;
+                                                   float *__restrict__ out, int32_t *err, RowSplit rs) {
   const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t i = slot / per_row;
+  int64_t i;
+  int lane_in_row;
+  gs_split(rs, slot, i, lane_in_row);
   if (i >= rows) return;
-  const int c = (int)(slot - i * per_row) * 4;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < ts.n; ++k) {
-    int64_t v = idx[i * ts.n + k];
-    if (v < 0 || v >= ts.dims[k]) {
-      if (err) atomicOr(err, GNNSAFT_FLAG_BAD_ATTR);
-      v = 0;
-    }
-    acc += gs_ld4(ts.tab[k] + v * h + c);
+  const int c = lane_in_row * 4;
+  // all index loads first, then all table-row loads (no branch between them: a guarded load would be
+  // waited for on the spot), then the left-to-right sum
+  int64_t v[MAXT];
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k) v[k] = idx[i * ts.n + (k < ts.n ? k : 0)];
+  bool bad = false;
+  f32x4 row[MAXT];
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k) {
+    const int kk = k < ts.n ? k : 0;
+    const bool oob = v[k] < 0 || v[k] >= ts.dims[kk];
+    bad |= oob && k < ts.n;
+    row[k] = gs_ld4(ts.tab[kk] + (oob ? 0 : v[k]) * h + c);
   }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k)
+    if (k < ts.n) acc += row[k];
+  if (bad && err) atomicOr(err, GNNSAFT_FLAG_BAD_ATTR);
   gs_st4(out + i * h + c, acc);
 }
 
@@ -133,12 +145,14 @@ __global__ __launch_bounds__(256) void k_bn_relu_residual(const float *__restric
 
 // out[g, :] = sum over rows ptr[g] .. ptr[g+1]-1, sequential (graph-contiguous rows)
 __global__ __launch_bounds__(256) void k_add_pool(const float *__restrict__ x, const int32_t *__restrict__ ptr,
-                                                  int64_t graphs, int64_t nodes, int h, float *__restrict__ out) {
-  const int per_row = h / 4;
+                                                  int64_t graphs, int64_t nodes, int h, float *__restrict__ out,
+                                                  RowSplit rs) {
   const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t g = slot / per_row;
+  int64_t g;
+  int lane_in_row;
+  gs_split(rs, slot, g, lane_in_row);
   if (g >= graphs) return;
-  const int c = (int)(slot - g * per_row) * 4;
+  const int c = lane_in_row * 4;
   int64_t beg = ptr[g], end = ptr[g + 1];
   beg = beg < 0 ? 0 : (beg > nodes ? nodes : beg);
   end = end < beg ? beg : (end > nodes ? nodes : end);
@@ -201,8 +215,16 @@ extern "C" int gnnsaft_embed_sum(const int64_t *idx, int64_t num_rows, int32_t n
   if (rc != GNNSAFT_OK) return rc;
   if (num_rows == 0) return GNNSAFT_OK;
   const int64_t threads = num_rows * (hidden / 4);
-  hipLaunchKernelGGL(gs::k_embed_sum, dim3((unsigned)gs_ceil_div(threads, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), idx, num_rows, ts, hidden, out, err_flag);
+  const dim3 grid((unsigned)gs_ceil_div(threads, 256)), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const RowSplit rs = gs_row_split(hidden / 4);
+  if (num_cols <= 3)
+    hipLaunchKernelGGL(gs::k_embed_sum<3>, grid, block, 0, st, idx, num_rows, ts, hidden, out, err_flag, rs);
+  else if (num_cols <= 9)
+    hipLaunchKernelGGL(gs::k_embed_sum<9>, grid, block, 0, st, idx, num_rows, ts, hidden, out, err_flag, rs);
+  else
+    hipLaunchKernelGGL(gs::k_embed_sum<GNNSAFT_MAX_TABLES>, grid, block, 0, st, idx, num_rows, ts, hidden, out,
+                       err_flag, rs);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }
@@ -265,7 +287,8 @@ extern "C" int gnnsaft_add_pool(const float *x, const int32_t *graph_ptr, int64_
   if (num_graphs == 0) return GNNSAFT_OK;
   const int64_t threads = num_graphs * (hidden / 4);
   hipLaunchKernelGGL(gs::k_add_pool, dim3((unsigned)gs_ceil_div(threads, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, graph_ptr, num_graphs, num_nodes, hidden, out);
+                     static_cast<hipStream_t>(stream), x, graph_ptr, num_graphs, num_nodes, hidden, out,
+                     gs_row_split(hidden / 4));
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }

@@ -51,7 +51,7 @@ struct Plan {
   // byte offsets into the workspace
   size_t csr_ws, rowptr, src, dst, combo, log_amp, log_att, graph_ptr;
   size_t x0, x1, pq, agg, u0, u1, y, msg0, msg1, cemb, cenc, rtab, stats, scale, shift, pooled, m0, m1, m2;
-  size_t perm, tiles, num_tiles, hist3, weff;
+  size_t perm, tiles, num_tiles, hist3, weff, gfold;
   int64_t tile_cap;
   size_t total;
 };
@@ -121,6 +121,7 @@ static int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, int64_t 
   p.num_tiles = take(4);
   p.hist3 = take(gnnsaft_degree_scratch_ints(n) * 4);
   p.weff = d->fold_degree_scalers ? take(nl * (size_t)kDegreeBuckets * 5 * h * h * 4) : 0;
+  p.gfold = d->fold_degree_scalers ? take(nl * 2 * 3 * (h / 2) * h * 4) : 0;
   p.total = off;
   return GNNSAFT_OK;
 }
@@ -204,6 +205,12 @@ static int node_terms(const float *x, int64_t n, int h, const float *w0, const f
   return launch_linear(x, h, 0, 4, e, 3 * (int64_t)h, 4 * (int64_t)h, n, h, h, epi, st);
 }
 
+static int src_terms(const float *x, int64_t n, int h, const float *w0, const float *w1, float *q, hipStream_t st) {
+  GemmBatchEntry e[2] = {{w0 + h, nullptr, q, 0}, {w1 + h, nullptr, q + h, 0}};
+  LinearEpilogue epi;
+  return launch_linear(x, h, 0, 2, e, 3 * (int64_t)h, 2 * (int64_t)h, n, h, h, epi, st);
+}
+
 static int edge_table(const float *cemb, int64_t combos, int h, const float *we, const float *be, const float *w0,
                       const float *b0, const float *w1, const float *b1, float *cenc, float *rtab, hipStream_t st) {
   LinearEpilogue epi;
@@ -254,6 +261,13 @@ extern "C" int gnnsaft_pna_node_terms(const float *x, int64_t num_nodes, int32_t
   GS_REQUIRE(x && w_pre0 && w_pre1 && pq, GNNSAFT_ERR_NULL);
   GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
   return node_terms(x, num_nodes, hidden, w_pre0, w_pre1, pq, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gnnsaft_pna_src_terms(const float *x, int64_t num_nodes, int32_t hidden, const float *w_pre0,
+                                     const float *w_pre1, float *q, gnnsaft_stream_t stream) {
+  GS_REQUIRE(x && w_pre0 && w_pre1 && q, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
+  return src_terms(x, num_nodes, hidden, w_pre0, w_pre1, q, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gnnsaft_pna_edge_table(const float *combo_emb, int32_t num_combos, int32_t hidden,
@@ -445,6 +459,8 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     w.bn = wc.bn();
     GS_REQUIRE(wc.ok, GNNSAFT_ERR_NULL);
   }
+  // destination-term fold: only with the degree-folded update and a purely linear message (pre_layers == 1)
+  const bool fold_dst = d->fold_dst_term && d->fold_degree_scalers && d->pre_layers == 1 && (h % 64) == 0;
   const int64_t cstride = p.combos * (int64_t)h;          // floats per layer in cenc
   const int64_t rstride = p.combos * (int64_t)(2 * h);    // floats per layer in rtab
   const int64_t wstride = (int64_t)kDegreeBuckets * 5 * h * h;  // floats per layer in weff
@@ -469,12 +485,17 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     for (int l0 = 0; l0 < d->num_layers; l0 += GNNSAFT_MAX_FOLD_LAYERS) {
       const int nl = d->num_layers - l0 < GNNSAFT_MAX_FOLD_LAYERS ? d->num_layers - l0 : GNNSAFT_MAX_FOLD_LAYERS;
       const float *w0[GNNSAFT_MAX_FOLD_LAYERS], *w1[GNNSAFT_MAX_FOLD_LAYERS], *av[GNNSAFT_MAX_FOLD_LAYERS];
+      const float *p0[GNNSAFT_MAX_FOLD_LAYERS], *p1[GNNSAFT_MAX_FOLD_LAYERS];
       for (int i = 0; i < nl; ++i) {
         w0[i] = lw[l0 + i].wpost[0][0];
         w1[i] = lw[l0 + i].wpost[1][0];
         av[i] = lw[l0 + i].avg;
+        p0[i] = lw[l0 + i].wpre[0][0];
+        p1[i] = lw[l0 + i].wpre[1][0];
       }
-      GS_TRY(gnnsaft_pna_fold_post_weights_multi(nl, w0, w1, av, I(p.hist3), h, F(p.weff) + l0 * wstride, wstride, st));
+      GS_TRY(gnnsaft_pna_fold_post_weights_multi(nl, w0, w1, av, fold_dst ? p0 : nullptr, fold_dst ? p1 : nullptr,
+                                                 fold_dst ? F(p.gfold) + (int64_t)l0 * 6 * (h / 2) * h : nullptr,
+                                                 I(p.hist3), h, F(p.weff) + l0 * wstride, wstride, st));
     }
   }
 
@@ -494,7 +515,10 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     // message: node terms (+ extra pre-layers on edge rows)
     {
       ProfScope ps(prof, GNNSAFT_PROF_NODE_TERMS, st);
-      GS_TRY(node_terms(xc, n, h, wpre[0][0], wpre[1][0], F(p.pq), st));
+      if (fold_dst)
+        GS_TRY(src_terms(xc, n, h, wpre[0][0], wpre[1][0], F(p.pq), st));
+      else
+        GS_TRY(node_terms(xc, n, h, wpre[0][0], wpre[1][0], F(p.pq), st));
     }
     const float *msgs = nullptr;
     if (d->pre_layers > 1) {
@@ -514,7 +538,10 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     // K4 aggregation
     {
       ProfScope ps(prof, GNNSAFT_PROF_AGGREGATE, st);
-      GS_TRY(gnnsaft_pna_aggregate(I(p.rowptr), I(p.src), I(p.combo), n, h, F(p.pq), rtab, msgs, F(p.agg), st));
+      if (fold_dst)
+        GS_TRY(gnnsaft_pna_aggregate_src(I(p.rowptr), I(p.src), I(p.combo), n, h, F(p.pq), rtab, F(p.agg), st));
+      else
+        GS_TRY(gnnsaft_pna_aggregate(I(p.rowptr), I(p.src), I(p.combo), n, h, F(p.pq), rtab, msgs, F(p.agg), st));
     }
     // update: first post-layer with scalers on load, then extra post-layers
     float *ua = F(p.u0), *ub = F(p.u1);

@@ -220,3 +220,35 @@ def bn_train_apply(stats, y, gamma, beta, running_mean, running_var, num_batches
                                      _p(running_var), _p(num_batches_tracked), momentum, eps, _p(residual), _p(out),
                                      _stream(y)), "gnnsaft_bn_train_apply")
     return out
+
+
+def pna_src_terms(x: torch.Tensor, w_pre0: torch.Tensor, w_pre1: torch.Tensor) -> torch.Tensor:
+    n, h = x.shape
+    q = torch.empty((n, 2 * h), dtype=torch.float32, device=x.device)
+    check(lib.gnnsaft_pna_src_terms(_p(x), n, h, _p(w_pre0), _p(w_pre1), _p(q), _stream(x)), "gnnsaft_pna_src_terms")
+    return q
+
+
+def pna_aggregate_src(rowptr, src, combo, hidden: int, q, rtab) -> torch.Tensor:
+    n = rowptr.shape[0] - 1
+    agg = torch.empty((n, 2, 4 * hidden), dtype=torch.float32, device=rowptr.device)
+    check(lib.gnnsaft_pna_aggregate_src(_p(rowptr), _p(src), _p(combo), n, hidden, _p(q), _p(rtab), _p(agg),
+                                        _stream(agg)), "gnnsaft_pna_aggregate_src")
+    return agg
+
+
+def pna_update_folded_dst(x, agg_src, perm, tiles, num_tiles, hist3, avg_deg_log, w_post0, b_post0, w_post1, b_post1,
+                          w_pre0, w_pre1):
+    """Degree-folded update with the destination term folded in: `agg_src` comes from pna_aggregate_src."""
+    n, h = x.shape
+    buckets = int(lib.gnnsaft_degree_buckets())
+    w_eff = torch.full((buckets, 2, h // 2, 5 * h), float("nan"), dtype=torch.float32, device=x.device)
+    g = torch.empty((2, 3, h // 2, h), dtype=torch.float32, device=x.device)
+    arr = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+    check(lib.gnnsaft_pna_fold_post_weights_multi(1, arr(w_post0), arr(w_post1), arr(avg_deg_log), arr(w_pre0),
+                                                  arr(w_pre1), _p(g), _p(hist3), h, _p(w_eff), 0, _stream(x)),
+          "gnnsaft_pna_fold_post_weights_multi")
+    u = torch.empty((n, h), dtype=torch.float32, device=x.device)
+    check(lib.gnnsaft_pna_update_folded(_p(x), _p(agg_src), _p(perm), _p(tiles), _p(num_tiles), n, h, _p(w_eff),
+                                        _p(b_post0), _p(b_post1), _p(u), _stream(x)), "gnnsaft_pna_update_folded")
+    return u

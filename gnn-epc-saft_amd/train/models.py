@@ -155,6 +155,10 @@ class PNAPCSAFT(nn.Module):
         # gnnsaft_degree_buckets() = 32, which covers molecular graphs; set False for other graphs
         # (input_error_flags() reports GNNSAFT_FLAG_BAD_DEGREE = 8 if a larger degree was met).
         self.fold_degree_scalers = True
+        # Also fold the message's destination term W_dst x_dst (a per-node constant under mean/min/max, invisible
+        # to std) into those weights: removes half of the message GEMM and a quarter of K4's reads.  Used when
+        # fold_degree_scalers is on, pre_layers == 1 and hidden_dim % 64 == 0; otherwise ignored.
+        self.fold_dst_term = True
         self._profile = None  # gnnsaft_profile* (bench.py attaches one to time kernels with HIP events)
 
     # ------------------------------------------------------------------ host glue
@@ -202,6 +206,7 @@ class PNAPCSAFT(nn.Module):
         d.bn_eps = bn0.eps
         d.bn_momentum = 0.1 if bn0.momentum is None else bn0.momentum
         d.fold_degree_scalers = int(self.fold_degree_scalers)
+        d.fold_dst_term = int(self.fold_dst_term)
         return d
 
     def _check_mode(self, x: torch.Tensor) -> None:

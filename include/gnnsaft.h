@@ -201,12 +201,27 @@ int gnnsaft_pna_fold_post_weights(const float *w_post0, const float *w_post1,
                                   const float *avg_deg_log, const int32_t *hist, int32_t hidden,
                                   float *w_eff, gnnsaft_stream_t stream);
 #define GNNSAFT_MAX_FOLD_LAYERS 8
-/* the same for several layers in one launch (weights of layer i at w_eff + i*layer_stride) */
+/* the same for several layers in one launch (weights of layer i at w_eff + i*layer_stride).  */
+/* If w_pre0_host / w_pre1_host (pre_nns[t][0].weight per layer) are given, the DESTINATION    */
+/* term of the message is folded too: msg = W_dst x_dst + m~ shifts mean/min/max of a node by   */
+/* the constant P_i = W_dst x_i and leaves std unchanged, so W_eff's x-block gains              */
+/* sum_s scale_s(d) (W_s,mean+W_s,min+W_s,max) W_dst (for d > 0) and the aggregates are taken   */
+/* over m~ = W_src x_src + edge term (gnnsaft_pna_aggregate_src).  g_scratch: L*2*3*(F/2)*F f32. */
 int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const float *const *w_post0_host,
                                         const float *const *w_post1_host,
-                                        const float *const *avg_deg_log_host, const int32_t *hist,
+                                        const float *const *avg_deg_log_host,
+                                        const float *const *w_pre0_host /* or NULL */,
+                                        const float *const *w_pre1_host /* or NULL */,
+                                        float *g_scratch /* or NULL */, const int32_t *hist,
                                         int32_t hidden, float *w_eff, int64_t layer_stride,
                                         gnnsaft_stream_t stream);
+/* source term only: q[i, tF:(t+1)F] = W_t[:,F:2F] x_i   ([N,2F]) */
+int gnnsaft_pna_src_terms(const float *x, int64_t num_nodes, int32_t hidden, const float *w_pre0,
+                          const float *w_pre1, float *q /* [N,2F] */, gnnsaft_stream_t stream);
+/* K4 over m~ = q[src] + rtab[class]: same outputs as gnnsaft_pna_aggregate minus the per-node shift P_i */
+int gnnsaft_pna_aggregate_src(const int32_t *rowptr, const int32_t *src, const int32_t *combo,
+                              int64_t num_nodes, int32_t hidden, const float *q, const float *rtab,
+                              float *agg, gnnsaft_stream_t stream);
 int gnnsaft_pna_update_folded(const float *x, const float *agg, const int32_t *perm,
                               const int32_t *tiles, const int32_t *num_tiles, int64_t num_nodes,
                               int32_t hidden, const float *w_eff, const float *b_post0,
@@ -271,6 +286,7 @@ typedef struct gnnsaft_model_desc {
   float bn_eps;
   float bn_momentum;
   int32_t fold_degree_scalers; /* 1: degree-folded update (in-degrees < gnnsaft_degree_buckets()) */
+  int32_t fold_dst_term;       /* 1: also fold the message's destination term (needs the above, pre_layers == 1) */
 } gnnsaft_model_desc;
 
 int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);
