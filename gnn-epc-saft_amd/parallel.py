@@ -52,6 +52,30 @@ def global_mape(loss3: torch.Tensor) -> torch.Tensor:
     return parts[0] / parts[1]
 
 
+class PendingMape:
+    """Handle of an in-flight ``[sum(ape), count]`` all-reduce; ``result()`` waits for it."""
+
+    def __init__(self, parts: torch.Tensor, work):
+        self.parts = parts
+        self.work = work
+
+    def result(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.parts[0] / self.parts[1]
+
+
+def global_mape_async(loss3: torch.Tensor) -> PendingMape:
+    """As ``global_mape`` but returns at once: the 8-byte collective is latency-bound, and the loss is only
+    a logged metric (``sync_dist=True``), so the next step's kernels need not queue behind it."""
+    parts = loss3[1:3].clone()
+    work = None
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        work = dist.all_reduce(parts, op=dist.ReduceOp.SUM, async_op=True)
+    return PendingMape(parts, work)
+
+
 class FlatGradientAllReduce:
     """Averages gradients across ranks with a single collective over one flat buffer."""
 
