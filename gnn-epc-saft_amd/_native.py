@@ -26,7 +26,7 @@ class ModelDesc(ctypes.Structure):
         ("self_loops", c_int32), ("training", c_int32), ("num_atom_cols", c_int32), ("num_bond_cols", c_int32),
         ("atom_dims", c_int32 * MAX_TABLES), ("bond_dims", c_int32 * MAX_TABLES),
         ("bn_eps", c_float), ("bn_momentum", c_float), ("fold_degree_scalers", c_int32),
-        ("fold_dst_term", c_int32),
+        ("fold_dst_term", c_int32), ("save_tape", c_int32),
     ]
 
 
@@ -65,7 +65,7 @@ SIGNATURES = {
     "gnnsaft_pna_update_folded": (c_int32, [P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
     "gnnsaft_debug_set_gemm_config": (None, [c_int32]),
     "gnnsaft_bn_finalize": (c_int32, [P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, c_int32, P, P, P]),
-    "gnnsaft_bn_train_apply": (c_int32, [P, P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, P, P, P]),
+    "gnnsaft_bn_train_apply": (c_int32, [P, P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, P, P, P, P]),
     "gnnsaft_pna_fold_post_weights_multi": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                                       POINTER(c_void_p), POINTER(c_void_p), P, P, c_int32, P, c_int64,
                                                       P]),

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
                                                         float *__restrict__ running_var, int64_t *nbt,
                                                         float momentum, float eps,
                                                         const float *__restrict__ residual, float *__restrict__ out,
-                                                        int64_t rows_per_chunk) {
+                                                        int64_t rows_per_chunk, float *__restrict__ save_stat) {
   __shared__ double s_n[kBnGroupLanes][kBnCols], s_mean[kBnGroupLanes][kBnCols], s_m2[kBnGroupLanes][kBnCols];
   __shared__ float s_scale[kBnCols], s_shift[kBnCols];
   const int c0 = blockIdx.x * kBnCols;
@@ -79,6 +79,10 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
     const float sc = rstd * (gamma != nullptr ? gamma[colc] : 1.f);
     s_scale[cl] = sc;
     s_shift[cl] = (beta != nullptr ? beta[colc] : 0.f) - mean_f * sc;
+    if (blockIdx.y == 0 && col_ok && save_stat != nullptr) {
+      save_stat[col] = mean_f;
+      save_stat[ch + col] = rstd;
+    }
     if (blockIdx.y == 0 && col_ok) {
       if (running_mean != nullptr) {
         const float unbiased = (float)(n > 1.0 ? m2 / (n - 1.0) : m2);
@@ -129,7 +133,8 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
 extern "C" int gnnsaft_bn_train_apply(const float *stats, const float *y, int64_t num_rows, int32_t channels,
                                       const float *gamma, const float *beta, float *running_mean,
                                       float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
-                                      const float *residual, float *out, gnnsaft_stream_t stream) {
+                                      const float *residual, float *out, float *save_mean_rstd,
+                                      gnnsaft_stream_t stream) {
   GS_REQUIRE(stats && y && out, GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_rows >= 2, GNNSAFT_ERR_SHAPE);  // torch: "Expected more than 1 value per channel"
   GS_REQUIRE(channels >= 4 && (channels % 4) == 0, GNNSAFT_ERR_SHAPE);
@@ -144,7 +149,7 @@ extern "C" int gnnsaft_bn_train_apply(const float *stats, const float *y, int64_
   chunks = gs_ceil_div(num_rows, rows_per_chunk);
   hipLaunchKernelGGL(gs::k_bn_train_apply, dim3((unsigned)slabs, (unsigned)chunks), dim3(256), 0,
                      static_cast<hipStream_t>(stream), stats, y, num_rows, channels, gamma, beta, running_mean,
-                     running_var, num_batches_tracked, momentum, eps, residual, out, rows_per_chunk);
+                     running_var, num_batches_tracked, momentum, eps, residual, out, rows_per_chunk, save_mean_rstd);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }

@@ -53,6 +53,11 @@ struct Plan {
   size_t x0, x1, pq, agg, u0, u1, y, msg0, msg1, cemb, cenc, rtab, stats, scale, shift, pooled, m0, m1, m2;
   size_t perm, tiles, num_tiles, hist3, weff, gfold;
   int64_t tile_cap;
+  // per-layer strides in floats (0 unless desc->save_tape: then every layer keeps its own tensors for backward)
+  int64_t sx, spq, sagg, su, sy;
+  size_t bnstat;          // [L][2][H] batch mean, rstd of the node BatchNorms
+  size_t ry, ro, rstat;   // readout blocks: pre-BN [nb][G,H], output [nb][G,H], (mean, rstd) [nb][2][H]
+  int nb;                 // BatchNorm blocks in the readout = num_mlp_layers + 2
   size_t total;
 };
 
@@ -94,13 +99,26 @@ static int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, int64_t 
   p.log_amp = take(nn * 4);
   p.log_att = take(nn * 4);
   p.graph_ptr = take((gg + 1) * 4);
-  p.x0 = take(nn * h * 4);
-  p.x1 = take(nn * h * 4);
-  p.pq = take(nn * 4 * h * 4);
-  p.agg = take(nn * 8 * h * 4);
-  p.u0 = take(nn * h * 4);
+  const size_t nlay = (size_t)(d->num_layers > 0 ? d->num_layers : 1);
+  const bool tape = d->save_tape != 0;
+  const size_t rep = tape ? nlay : 1;
+  p.sx = tape ? (int64_t)(nn * h) : 0;
+  p.spq = tape ? (int64_t)(nn * 4 * h) : 0;
+  p.sagg = tape ? (int64_t)(nn * 8 * h) : 0;
+  p.su = tape ? (int64_t)(nn * h) : 0;
+  p.sy = tape ? (int64_t)(nn * h) : 0;
+  p.x0 = take((tape ? nlay + 1 : 1) * nn * h * 4);  // tape: x_0 .. x_L contiguous
+  p.x1 = tape ? p.x0 : take(nn * h * 4);
+  p.pq = take(rep * nn * 4 * h * 4);
+  p.agg = take(rep * nn * 8 * h * 4);
+  p.u0 = take(rep * nn * h * 4);
   p.u1 = d->post_layers > 1 ? take(nn * h * 4) : p.u0;
-  p.y = take(nn * h * 4);
+  p.y = take(rep * nn * h * 4);
+  p.bnstat = take(nlay * 2 * h * 4);
+  p.nb = d->num_mlp_layers + 2;
+  p.ry = take((size_t)p.nb * gg * h * 4);
+  p.ro = take((size_t)p.nb * gg * h * 4);
+  p.rstat = take((size_t)p.nb * 2 * h * 4);
   p.msg0 = d->pre_layers > 1 ? take(ee * 2 * h * 4) : 0;
   p.msg1 = d->pre_layers > 2 ? take(ee * 2 * h * 4) : p.msg0;
   p.cemb = take((size_t)p.combos * h * 4);
@@ -166,7 +184,8 @@ struct WeightCursor {
 // train writes y with (mean, M2) partials, finalises the statistics and applies them.
 static int linear_bn_relu(const float *a, int64_t lda, const float *w, const float *b, int64_t rows, int n_out, int k,
                           const BnPtrs &bn, const gnnsaft_model_desc *d, char *ws, const Plan &p, float *y_tmp,
-                          const float *residual, float *out, hipStream_t st, gnnsaft_profile *prof = nullptr) {
+                          const float *residual, float *out, hipStream_t st, gnnsaft_profile *prof = nullptr,
+                          float *save_stat = nullptr) {
   float *scale = reinterpret_cast<float *>(ws + p.scale);
   float *shift = reinterpret_cast<float *>(ws + p.shift);
   float *stats = reinterpret_cast<float *>(ws + p.stats);
@@ -181,7 +200,7 @@ static int linear_bn_relu(const float *a, int64_t lda, const float *w, const flo
       GS_TRY(launch_linear(a, lda, 0, 1, &ent, k, n_out, rows, n_out, k, epi, st));
     }
     GS_TRY(gnnsaft_bn_train_apply(stats, y_tmp, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt,
-                                  d->bn_momentum, d->bn_eps, residual, out, st));
+                                  d->bn_momentum, d->bn_eps, residual, out, save_stat, st));
   } else {
     GS_TRY(gnnsaft_bn_finalize(nullptr, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, nullptr, d->bn_momentum,
                                d->bn_eps, 0, scale, shift, st));
@@ -381,7 +400,8 @@ extern "C" int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int
   map->log_att = p.log_att;
   map->graph_ptr = p.graph_ptr;
   map->x_embed = p.x0;
-  map->x_final = (desc->num_layers % 2) ? p.x1 : p.x0;
+  map->x_final = desc->save_tape ? p.x0 + (size_t)desc->num_layers * (size_t)p.sx * 4
+                                 : ((desc->num_layers % 2) ? p.x1 : p.x0);
   map->pq = p.pq;
   map->agg = p.agg;
   map->u = p.u0;
@@ -499,9 +519,12 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     }
   }
 
-  float *xc = F(p.x0), *xn = F(p.x1);
+  const bool tape = d->save_tape != 0;
+  float *xc = F(p.x0), *xn = tape ? F(p.x0) + p.sx : F(p.x1);
   for (int l = 0; l < d->num_layers; ++l) {
     const LayerW &w = lw[l];
+    float *pq_l = F(p.pq) + l * p.spq, *agg_l = F(p.agg) + l * p.sagg, *u_l = F(p.u0) + l * p.su;
+    float *y_l = F(p.y) + l * p.sy;
     const float *avg = w.avg;
     const float *const(*wpre)[8] = w.wpre;
     const float *const(*bpre)[8] = w.bpre;
@@ -516,15 +539,15 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     {
       ProfScope ps(prof, GNNSAFT_PROF_NODE_TERMS, st);
       if (fold_dst)
-        GS_TRY(src_terms(xc, n, h, wpre[0][0], wpre[1][0], F(p.pq), st));
+        GS_TRY(src_terms(xc, n, h, wpre[0][0], wpre[1][0], pq_l, st));
       else
-        GS_TRY(node_terms(xc, n, h, wpre[0][0], wpre[1][0], F(p.pq), st));
+        GS_TRY(node_terms(xc, n, h, wpre[0][0], wpre[1][0], pq_l, st));
     }
     const float *msgs = nullptr;
     if (d->pre_layers > 1) {
       float *ma = F(p.msg0), *mb = F(p.msg1);
       GemmBatchEntry e[2] = {{wpre[0][1], bpre[0][1], ma, 0}, {wpre[1][1], bpre[1][1], ma + h, 0}};
-      GS_TRY(launch_pna_edge_mlp(I(p.src), I(p.dst), I(p.combo), p.ep, h, F(p.pq), rtab, e, 2 * (int64_t)h, st));
+      GS_TRY(launch_pna_edge_mlp(I(p.src), I(p.dst), I(p.combo), p.ep, h, pq_l, rtab, e, 2 * (int64_t)h, st));
       for (int j = 2; j < d->pre_layers; ++j) {
         GemmBatchEntry e2[2] = {{wpre[0][j], bpre[0][j], mb, 0}, {wpre[1][j], bpre[1][j], mb + h, h}};
         LinearEpilogue epi;
@@ -539,20 +562,20 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     {
       ProfScope ps(prof, GNNSAFT_PROF_AGGREGATE, st);
       if (fold_dst)
-        GS_TRY(gnnsaft_pna_aggregate_src(I(p.rowptr), I(p.src), I(p.combo), n, h, F(p.pq), rtab, F(p.agg), st));
+        GS_TRY(gnnsaft_pna_aggregate_src(I(p.rowptr), I(p.src), I(p.combo), n, h, pq_l, rtab, agg_l, st));
       else
-        GS_TRY(gnnsaft_pna_aggregate(I(p.rowptr), I(p.src), I(p.combo), n, h, F(p.pq), rtab, msgs, F(p.agg), st));
+        GS_TRY(gnnsaft_pna_aggregate(I(p.rowptr), I(p.src), I(p.combo), n, h, pq_l, rtab, msgs, agg_l, st));
     }
     // update: first post-layer with scalers on load, then extra post-layers
-    float *ua = F(p.u0), *ub = F(p.u1);
+    float *ua = u_l, *ub = F(p.u1);
     if (d->fold_degree_scalers) {
       ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
-      GS_TRY(launch_pna_update_folded(xc, F(p.agg), I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap, n, h, weff,
+      GS_TRY(launch_pna_update_folded(xc, agg_l, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap, n, h, weff,
                                       bpost[0][0], bpost[1][0], ua, st));
     } else {
       GemmBatchEntry e[2] = {{wpost[0][0], bpost[0][0], ua, 0}, {wpost[1][0], bpost[1][0], ua + h / 2, 0}};
       ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
-      GS_TRY(launch_pna_update(xc, F(p.agg), F(p.log_amp), F(p.log_att), avg, n, h, e, h, st));
+      GS_TRY(launch_pna_update(xc, agg_l, F(p.log_amp), F(p.log_att), avg, n, h, e, h, st));
     }
     for (int j = 1; j < d->post_layers; ++j) {
       GemmBatchEntry e2[2] = {{wpost[0][j], bpost[0][j], ub, 0}, {wpost[1][j], bpost[1][j], ub + h / 2, h / 2}};
@@ -563,28 +586,32 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
       ub = t;
     }
     // lin -> BatchNorm -> ReLU -> (+ x)
-    GS_TRY(linear_bn_relu(ua, h, wlin, blin, n, h, h, bn, d, ws, p, F(p.y), d->skip_connections ? xc : nullptr, xn,
-                          st, prof));
-    float *t = xc;
-    xc = xn;
-    xn = t;
+    GS_TRY(linear_bn_relu(ua, h, wlin, blin, n, h, h, bn, d, ws, p, y_l, d->skip_connections ? xc : nullptr, xn, st,
+                          prof, F(p.bnstat) + (int64_t)l * 2 * h));
+    if (tape) {
+      xc = xn;
+      xn = xn + p.sx;
+    } else {
+      float *t = xc;
+      xc = xn;
+      xn = t;
+    }
   }
 
   // ---- readout
   GS_TRY(gnnsaft_add_pool(xc, I(p.graph_ptr), g, n, h, F(p.pooled), st));
   const float *cur = F(p.pooled);
-  float *rot[3] = {F(p.m0), F(p.m1), F(p.m2)};
-  int ci = 2;  // index of `cur` in rot (pooled counts as slot 2 for the first block)
-  int width = h;
+  int width = h, bi = 0;
+  const int64_t rs = g * (int64_t)h;  // floats per readout block buffer
   auto block = [&](int n_out) -> int {
     const float *w = wc.f(), *b = wc.f();
     BnPtrs bn = wc.bn();
     GS_REQUIRE(wc.ok, GNNSAFT_ERR_NULL);
-    // pre-BN scratch and output are the two rotating buffers that are not the input
-    float *y_tmp = rot[(ci + 1) % 3], *o = rot[(ci + 2) % 3];
-    GS_TRY(linear_bn_relu(cur, width, w, b, g, n_out, width, bn, d, ws, p, y_tmp, nullptr, o, st));
+    float *y_tmp = F(p.ry) + bi * rs, *o = F(p.ro) + bi * rs;  // kept for backward
+    GS_TRY(linear_bn_relu(cur, width, w, b, g, n_out, width, bn, d, ws, p, y_tmp, nullptr, o, st, nullptr,
+                          F(p.rstat) + (int64_t)bi * 2 * h));
     cur = o;
-    ci = (ci + 2) % 3;
+    ++bi;
     width = n_out;
     return GNNSAFT_OK;
   };

@@ -1,0 +1,314 @@
+// Weight-gradient GEMM ("TN"):  dW[n][k] = sum_m dY[m][n] * A[m][k]
+// for the backward of every Linear on the path (autograd through
+// /root/reference/gnnepcsaft/train/models.py:105-135).
+//
+// The contraction runs over the ROWS m (nodes / edges / graphs: 1e4..1e6) and the output is a small
+// [n_out, k] weight matrix, so the rows are cut into chunks of kTnChunk and every workgroup produces
+// one 64x64 output tile for one chunk into a slab [chunk][n_out][k]; a second kernel sums the slabs in
+// chunk order.  No atomics: bitwise reproducible.  Both operands are staged in their natural
+// row-major layout (row = m); the 32x32x2 f32 MFMA reads its fragments column-wise (ds_read_b32,
+// conflict-free: consecutive lanes read consecutive n / k).
+//
+// The A operand is virtual, as in gemm.hip:
+//   TnPlain  : a row-major matrix (optionally ReLU'd: extra pre/post layers)
+//   TnPost   : cat[x_i, A, A*amp_i, A*att_i]                 (PNAConv update input, never materialised)
+//   TnOneHot : concatenated one-hot rows of categorical columns (embedding tables: dE = OneHot^T dX)
+#include "common.hpp"
+
+namespace gs {
+
+constexpr int kTnChunk = 1024;  // rows per slab
+constexpr int kTnBK = 32;       // rows per LDS stage
+constexpr int kTnTile = 64;     // output tile (n and k)
+constexpr int kTnLd = kTnTile + 4;
+
+struct TnPlain {
+  const float *a;
+  int64_t lda;
+  int relu;
+  int k;
+  __device__ __forceinline__ f32x4 load(int64_t m, int kk) const {
+    f32x4 v = gs_ld4(a + m * lda + (kk < k ? kk : 0));
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f);
+      v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f);
+      v.w = fmaxf(v.w, 0.f);
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    return kk < k ? v : zero;
+  }
+};
+
+struct TnPost {
+  const float *x;        // [N,F]
+  const float *agg;      // [N,2,4F] + tower offset applied by the launcher
+  const float *log_amp;  // [N]
+  const float *log_att;  // [N]
+  const float *avg;      // device [1]
+  int f;
+  __device__ __forceinline__ f32x4 load(int64_t m, int kk) const {
+    const int j = kk - f;
+    const int seg = j < 4 * f ? 0 : (j < 8 * f ? 1 : 2);
+    const float *p = j < 0 ? x + m * f + kk : agg + m * (int64_t)(8 * f) + (j - seg * 4 * f);
+    const f32x4 v = gs_ld4(p);
+    const float avgv = avg[0];
+    const float s = (j < 0 || seg == 0) ? 1.f : (seg == 1 ? log_amp[m] / avgv : avgv / log_att[m]);
+    return v * s;
+  }
+};
+
+struct TnOneHot {
+  const int64_t *idx;  // [N, ncol]
+  int ncol;
+  int32_t off[GNNSAFT_MAX_TABLES + 1];  // first concatenated row of every table
+  __device__ __forceinline__ f32x4 load(int64_t m, int kk) const {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < ncol; ++t) {
+      int64_t r = idx[m * ncol + t];
+      const int dim = off[t + 1] - off[t];
+      r = (r < 0 || r >= dim) ? 0 : r;  // as the forward clamps
+      const int c = off[t] + (int)r - kk;
+      v.x += c == 0 ? 1.f : 0.f;
+      v.y += c == 1 ? 1.f : 0.f;
+      v.z += c == 2 ? 1.f : 0.f;
+      v.w += c == 3 ? 1.f : 0.f;
+    }
+    return v;
+  }
+};
+
+template <class AProv>
+__global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dy, int64_t ldy, AProv ap, int64_t m,
+                                                 int n_out, int k, float *__restrict__ slabs) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kTnBK * kTnLd];  // [buf][dy | a][32][68]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;  // 2 x 2 waves, 32 x 32 each
+  const int n0 = blockIdx.y * kTnTile, k0 = blockIdx.x * kTnTile;
+  const int64_t m_beg = (int64_t)blockIdx.z * kTnChunk;
+  int64_t m_end = m_beg + kTnChunk;
+  if (m_end > m) m_end = m;
+
+  // staging: 32 rows x 16 float4; thread -> (row tid>>4 (+16), float4 column tid&15)
+  const int sc = (tid & 15) * 4;
+  const int sr = tid >> 4;
+  f32x4 ry[2], ra[2];
+  auto fetch = [&](int64_t mrow0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int64_t mm = mrow0 + sr + 16 * j;
+      const bool ok = mm < m_end;
+      mm = ok ? mm : m_end - 1;
+      const int nn = n0 + sc;
+      f32x4 vy = gs_ld4(dy + mm * ldy + (nn < n_out ? nn : 0));
+      f32x4 va = ap.load(mm, k0 + sc);
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      ry[j] = (ok && nn < n_out) ? vy : zero;  // rows past the chunk contribute nothing
+      ra[j] = ok ? va : zero;
+    }
+  };
+  auto stash = [&](int buf) {
+    float *ys = lds + buf * 2 * kTnBK * kTnLd;
+    float *as = ys + kTnBK * kTnLd;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      gs_st4(ys + (sr + 16 * j) * kTnLd + sc, ry[j]);
+      gs_st4(as + (sr + 16 * j) * kTnLd + sc, ra[j]);
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const int64_t steps = (m_end - m_beg + kTnBK - 1) / kTnBK;
+  fetch(m_beg);
+  stash(0);
+  __syncthreads();
+  for (int64_t s = 0; s < steps; ++s) {
+    const bool more = s + 1 < steps;
+    if (more) fetch(m_beg + (s + 1) * kTnBK);
+    const float *ys = lds + (s & 1) * 2 * kTnBK * kTnLd + wn * 32 + (lane & 31);
+    const float *as = ys + kTnBK * kTnLd - wn * 32 + wk * 32;
+#pragma unroll
+    for (int q = 0; q < kTnBK / 2; ++q) {
+      const int row = 2 * q + (lane >> 5);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ys[row * kTnLd], as[row * kTnLd], acc, 0, 0, 0);
+    }
+    if (more) stash((s + 1) & 1);
+    __syncthreads();
+  }
+  // C/D: col = lane & 31 (k), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (n)
+  float *slab = slabs + (int64_t)blockIdx.z * n_out * (int64_t)k;
+  const int kc = k0 + wk * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int nr = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (nr < n_out && kc < k) slab[(int64_t)nr * k + kc] = acc[r];
+  }
+}
+
+// out[i] (+)= sum over chunks of slabs[c][i]; fixed chunk order
+__global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ slabs, int64_t per_slab, int64_t chunks,
+                                                   float *__restrict__ out, int64_t ld_out, int cols, int accumulate) {
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= per_slab) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t c = 0; c < chunks; ++c) s += gs_ld4(slabs + c * per_slab + i4);
+  const int64_t r = i4 / cols, cc = i4 - r * cols;  // slab is dense [rows, cols]; out may be a column block
+  float *o = out + r * ld_out + cc;
+  if (accumulate) s += gs_ld4(o);
+  gs_st4(o, s);
+}
+
+// out[c][r] = in[r][c] for a batch of small matrices (weights): LDS-tiled 32x32
+struct TransposeBatch {
+  const float *in[kMaxGemmBatch];
+  float *out[kMaxGemmBatch];
+  int64_t ld_in[kMaxGemmBatch];
+  int64_t ld_out[kMaxGemmBatch];
+};
+__global__ __launch_bounds__(256) void k_transpose(TransposeBatch tb, int rows, int cols) {
+  __shared__ float t[32][33];
+  const float *in = tb.in[blockIdx.z];
+  float *out = tb.out[blockIdx.z];
+  const int64_t ldi = tb.ld_in[blockIdx.z], ldo = tb.ld_out[blockIdx.z];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + ty + 8 * j, c = c0 + tx;
+    t[ty + 8 * j][tx] = (r < rows && c < cols) ? in[r * ldi + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, r = r0 + tx;
+    if (c < cols && r < rows) out[c * ldo + r] = t[tx][ty + 8 * j];
+  }
+}
+
+// column sums (bias gradients): partial[chunk][col] then fixed-order sum
+__global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ a, int64_t lda, int64_t m, int cols,
+                                                        float *__restrict__ partial) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int64_t m_beg = (int64_t)blockIdx.y * kTnChunk;
+  int64_t m_end = m_beg + kTnChunk;
+  if (m_end > m) m_end = m;
+  float s = 0.f;
+  for (int64_t r = m_beg; r < m_end; ++r) s += a[r * lda + c];
+  partial[(int64_t)blockIdx.y * cols + c] = s;
+}
+__global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ partial, int64_t chunks, int cols,
+                                                      float *__restrict__ out, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int64_t j = 0; j < chunks; ++j) s += partial[j * cols + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+template <class AProv>
+static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, int n_out, int k, float *out,
+                     int64_t ld_out, int accumulate, float *slabs, size_t slab_bytes, hipStream_t st) {
+  GS_REQUIRE(dy && out && slabs, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(m >= 1 && n_out >= 1 && k >= 4 && (k % 4) == 0 && (ldy % 4) == 0 && (ld_out % 4) == 0,
+             GNNSAFT_ERR_SHAPE);
+  const int64_t chunks = gs_ceil_div(m, kTnChunk);
+  GS_REQUIRE(slab_bytes >= (size_t)chunks * n_out * k * 4, GNNSAFT_ERR_WORKSPACE);
+  const dim3 grid((unsigned)gs_ceil_div(k, kTnTile), (unsigned)gs_ceil_div(n_out, kTnTile), (unsigned)chunks);
+  hipLaunchKernelGGL((k_gemm_tn<AProv>), grid, dim3(256), 0, st, dy, ldy, ap, m, n_out, k, slabs);
+  const int64_t per_slab = (int64_t)n_out * k;
+  hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)gs_ceil_div(per_slab / 4, 256)), dim3(256), 0, st, slabs, per_slab,
+                     chunks, out, ld_out, k, accumulate);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+size_t tn_slab_bytes(int64_t m, int n_out, int k) {
+  return (size_t)gs_ceil_div(m > 0 ? m : 1, kTnChunk) * (size_t)n_out * (size_t)k * 4;
+}
+
+int launch_wgrad_plain(const float *dy, int64_t ldy, const float *a, int64_t lda, int relu_a, int64_t m, int n_out,
+                       int k, float *out, int64_t ld_out, int accumulate, float *slabs, size_t slab_bytes,
+                       hipStream_t st) {
+  GS_REQUIRE(a != nullptr && (lda % 4) == 0, GNNSAFT_ERR_SHAPE);
+  TnPlain ap{a, lda, relu_a, k};
+  return launch_tn(dy, ldy, ap, m, n_out, k, out, ld_out, accumulate, slabs, slab_bytes, st);
+}
+
+int launch_wgrad_post(const float *du_t, int64_t ldu, const float *x, const float *agg_t, const float *log_amp,
+                      const float *log_att, const float *avg, int64_t n, int hidden, float *dw /* [F/2,13F] */,
+                      float *slabs, size_t slab_bytes, hipStream_t st) {
+  GS_REQUIRE(x && agg_t && log_amp && log_att && avg, GNNSAFT_ERR_NULL);
+  GS_REQUIRE((hidden % 64) == 0, GNNSAFT_ERR_UNSUPPORTED);  // a 64-wide k tile must not straddle segments
+  TnPost ap{x, agg_t, log_amp, log_att, avg, hidden};
+  return launch_tn(du_t, ldu, ap, n, hidden / 2, 13 * hidden, dw, 13 * (int64_t)hidden, 0, slabs, slab_bytes, st);
+}
+
+int launch_wgrad_onehot(const float *dx, int64_t ldx, const int64_t *idx, int ncol, const int32_t *dims_host, int64_t n,
+                        int hidden, float *dtab_t /* [H, total_rows] */, int total_rows_padded, float *slabs,
+                        size_t slab_bytes, hipStream_t st) {
+  GS_REQUIRE(idx != nullptr && ncol >= 1 && ncol <= GNNSAFT_MAX_TABLES, GNNSAFT_ERR_SHAPE);
+  TnOneHot ap;
+  ap.idx = idx;
+  ap.ncol = ncol;
+  int32_t off = 0;
+  for (int t = 0; t <= GNNSAFT_MAX_TABLES; ++t) {
+    ap.off[t] = off;
+    if (t < ncol) off += dims_host[t];
+  }
+  GS_REQUIRE(total_rows_padded >= off && (total_rows_padded % 4) == 0, GNNSAFT_ERR_SHAPE);
+  // output [n_out = H][k = total rows]: dE^T; the caller reads table t's row r at column off[t] + r
+  return launch_tn(dx, ldx, ap, n, hidden, total_rows_padded, dtab_t, total_rows_padded, 0, slabs, slab_bytes, st);
+}
+
+int launch_transpose(int count, const float *const *in, float *const *out, const int64_t *ld_in, const int64_t *ld_out,
+                     int rows, int cols, hipStream_t st) {
+  GS_REQUIRE(count >= 1 && count <= kMaxGemmBatch, GNNSAFT_ERR_SHAPE);
+  TransposeBatch tb;
+  for (int i = 0; i < kMaxGemmBatch; ++i) {
+    const int j = i < count ? i : 0;
+    tb.in[i] = in[j];
+    tb.out[i] = out[j];
+    tb.ld_in[i] = ld_in[j];
+    tb.ld_out[i] = ld_out[j];
+    GS_REQUIRE(tb.in[i] && tb.out[i], GNNSAFT_ERR_NULL);
+  }
+  hipLaunchKernelGGL(k_transpose, dim3((unsigned)gs_ceil_div(cols, 32), (unsigned)gs_ceil_div(rows, 32), (unsigned)count),
+                     dim3(256), 0, st, tb, rows, cols);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+int launch_colsum(const float *a, int64_t lda, int64_t m, int cols, float *out, int accumulate, float *partial,
+                  size_t partial_bytes, hipStream_t st) {
+  GS_REQUIRE(a && out && partial, GNNSAFT_ERR_NULL);
+  const int64_t chunks = gs_ceil_div(m > 0 ? m : 1, kTnChunk);
+  GS_REQUIRE(partial_bytes >= (size_t)chunks * cols * 4, GNNSAFT_ERR_WORKSPACE);
+  hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)gs_ceil_div(cols, 256), (unsigned)chunks), dim3(256), 0, st, a,
+                     lda, m, cols, partial);
+  hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)gs_ceil_div(cols, 256)), dim3(256), 0, st, partial, chunks, cols,
+                     out, accumulate);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+}  // namespace gs
+
+extern "C" size_t gnnsaft_wgrad_scratch_bytes(int64_t m, int32_t n_out, int32_t k) {
+  return gs::tn_slab_bytes(m, n_out, k);
+}
+
+extern "C" int gnnsaft_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t lda, int32_t relu_a,
+                                    int64_t m, int32_t n_out, int32_t k, float *dw, int64_t ld_dw,
+                                    int32_t accumulate, float *dbias /* or NULL */, void *scratch,
+                                    size_t scratch_bytes, gnnsaft_stream_t stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = gs::launch_wgrad_plain(dy, ldy, a, lda, relu_a, m, n_out, k, dw, ld_dw, accumulate,
+                                  static_cast<float *>(scratch), scratch_bytes, st);
+  if (rc != GNNSAFT_OK || dbias == nullptr) return rc;
+  return gs::launch_colsum(dy, ldy, m, n_out, dbias, accumulate, static_cast<float *>(scratch), scratch_bytes, st);
+}

@@ -218,7 +218,7 @@ def bn_train_apply(stats, y, gamma, beta, running_mean, running_var, num_batches
     out = torch.empty_like(y)
     check(lib.gnnsaft_bn_train_apply(_p(stats), _p(y), y.shape[0], y.shape[1], _p(gamma), _p(beta), _p(running_mean),
                                      _p(running_var), _p(num_batches_tracked), momentum, eps, _p(residual), _p(out),
-                                     _stream(y)), "gnnsaft_bn_train_apply")
+                                     None, _stream(y)), "gnnsaft_bn_train_apply")
     return out
 
 

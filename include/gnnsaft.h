@@ -247,7 +247,9 @@ int gnnsaft_bn_finalize(const float *stats, int64_t num_rows, int32_t channels,
 int gnnsaft_bn_train_apply(const float *stats, const float *y, int64_t num_rows, int32_t channels,
                            const float *gamma, const float *beta, float *running_mean,
                            float *running_var, int64_t *num_batches_tracked, float momentum,
-                           float eps, const float *residual, float *out, gnnsaft_stream_t stream);
+                           float eps, const float *residual, float *out,
+                           float *save_mean_rstd /* [2*channels] or NULL: kept for backward */,
+                           gnnsaft_stream_t stream);
 
 /* out = relu(y*scale + shift) (+ residual)   (models.py:128-131) */
 int gnnsaft_bn_relu_residual(const float *y, const float *scale, const float *shift,
@@ -287,6 +289,7 @@ typedef struct gnnsaft_model_desc {
   float bn_momentum;
   int32_t fold_degree_scalers; /* 1: degree-folded update (in-degrees < gnnsaft_degree_buckets()) */
   int32_t fold_dst_term;       /* 1: also fold the message's destination term (needs the above, pre_layers == 1) */
+  int32_t save_tape;           /* 1: every layer keeps its tensors in the workspace for gnnsaft_backward */
 } gnnsaft_model_desc;
 
 int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);
