@@ -79,6 +79,13 @@ SIGNATURES = {
     "gnnsaft_forward_workspace_map": (c_int32, [POINTER(ModelDesc), c_int64, c_int64, c_int64, POINTER(WorkspaceMap)]),
     "gnnsaft_forward": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), c_int32, P, P, P, P, c_int64, c_int64,
                                   c_int64, P, P, P, P, P, c_size_t, P, P]),
+    "gnnsaft_backward_scratch_bytes": (c_size_t, [POINTER(ModelDesc), c_int64, c_int64, c_int64]),
+    "gnnsaft_backward": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), POINTER(c_void_p), c_int32, P, P, c_int64,
+                                   c_int64, c_int64, P, P, c_size_t, P, c_size_t, P]),
+    "gnnsaft_mape_backward": (c_int32, [P, P, c_int64, c_int32, P, P, P]),
+    "gnnsaft_wgrad_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "gnnsaft_linear_wgrad": (c_int32, [P, c_int64, P, c_int64, c_int32, c_int64, c_int32, c_int32, P, c_int64, c_int32,
+                                       P, P, c_size_t, P]),
     "gnnsaft_profile_create": (c_int32, [c_int32, ctypes.c_uint32, POINTER(c_void_p)]),
     "gnnsaft_profile_destroy": (None, [P]),
     "gnnsaft_profile_reset": (c_int32, [P]),

@@ -1,0 +1,659 @@
+// Backward of the PNAPCSAFT forward + MAPE loss: what autograd does through
+// /root/reference/gnnepcsaft/train/models.py:105-135,191-194 when Lightning calls loss.backward()
+// (SURVEY.md section 8(f) rank 1).  Everything is recomputed from the forward's tape (x_l, pq_l, agg_l,
+// u_l, y_l, BatchNorm batch statistics) that gnnsaft_forward keeps in its workspace when
+// desc->save_tape is set; nothing here runs on the CPU and nothing synchronises.
+//
+// Per layer, in reverse:  BatchNorm+ReLU backward -> lin (dgrad NT / wgrad TN) -> update (dgrad through
+// the degree-folded weights, wgrad against the virtual cat[x, A, A*amp, A*att]) -> aggregation backward
+// (mean / tie-aware min, max / std, per CSR row) -> gather of the row gradients by SOURCE node through a
+// transposed CSR (no atomics) + reduction by edge class -> message GEMMs (dgrad / wgrad) -> edge-class
+// table (edge_encoder, bond embeddings).  Supported: pre_layers == post_layers == 1 (the shipped
+// default, configs/default.py:39-40), hidden % 64 == 0.
+#include "plan.hpp"
+
+namespace gs {
+
+// ------------------------------------------------------------------ small elementwise pieces
+__global__ void k_mape_bwd(const float *__restrict__ pred, const float *__restrict__ target, int64_t g, int p, int ldp,
+                           const float *__restrict__ dloss, float *__restrict__ dout) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g * ldp) return;
+  const int64_t r = i / ldp;
+  const int c = (int)(i - r * ldp);
+  float v = 0.f;
+  if (c < p) {
+    const float t = target[r * p + c], d = pred[r * p + c] - t;
+    const float s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    v = s / fmaxf(fabsf(t), 1.17e-06f) / (float)(g * p) * (dloss != nullptr ? dloss[0] : 1.f);
+  }
+  dout[i] = v;
+}
+
+__global__ void k_pad_cols(const float *__restrict__ in, int64_t rows, int cols, int ld_out, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ld_out) return;
+  const int64_t r = i / ld_out;
+  const int c = (int)(i - r * ld_out);
+  out[i] = c < cols ? in[r * cols + c] : 0.f;
+}
+
+__global__ void k_fill_zero(float *__restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
+// dx[i, :] = dg[graph(i), :]  (backward of global_add_pool)
+__global__ __launch_bounds__(256) void k_pool_bwd(const float *__restrict__ dg, const int32_t *__restrict__ ptr,
+                                                  int64_t graphs, int64_t nodes, int h, float *__restrict__ dx,
+                                                  RowSplit rs) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t g;
+  int lane;
+  gs_split(rs, slot, g, lane);
+  if (g >= graphs) return;
+  const int c = lane * 4;
+  int64_t beg = ptr[g], end = ptr[g + 1];
+  beg = beg < 0 ? 0 : (beg > nodes ? nodes : beg);
+  end = end < beg ? beg : (end > nodes ? nodes : end);
+  const f32x4 v = gs_ld4(dg + g * h + c);
+  for (int64_t r = beg; r < end; ++r) gs_st4(dx + r * h + c, v);
+}
+
+// ------------------------------------------------------------------ BatchNorm (+ReLU) backward, train mode
+constexpr int kBwdCols = 32;
+__global__ __launch_bounds__(256) void k_bn_bwd_partial(const float *__restrict__ y, const float *__restrict__ dout,
+                                                        const float *__restrict__ stat,
+                                                        const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, int64_t rows, int ch,
+                                                        int64_t rows_per_chunk, float *__restrict__ partial) {
+  __shared__ double s1s[8][kBwdCols], s2s[8][kBwdCols];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = blockIdx.x * kBwdCols + cl;
+  const int colc = col < ch ? col : ch - 1;
+  const float mean = stat[colc], rstd = stat[ch + colc], gm = gamma[colc], bt = beta[colc];
+  const int64_t r_beg = (int64_t)blockIdx.y * rows_per_chunk;
+  int64_t r_end = r_beg + rows_per_chunk;
+  if (r_end > rows) r_end = rows;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t r = r_beg + rl; r < r_end; r += 8) {
+    const float yh = (y[r * ch + colc] - mean) * rstd;
+    const float dz = (yh * gm + bt) > 0.f ? dout[r * ch + colc] : 0.f;
+    s1 += (double)dz;
+    s2 += (double)dz * (double)yh;
+  }
+  s1s[rl][cl] = s1;
+  s2s[rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && col < ch) {
+    for (int o = 1; o < 8; ++o) {
+      s1 += s1s[o][cl];
+      s2 += s2s[o][cl];
+    }
+    partial[((int64_t)blockIdx.y * 2 + 0) * ch + col] = (float)s1;
+    partial[((int64_t)blockIdx.y * 2 + 1) * ch + col] = (float)s2;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ y, const float *__restrict__ dout,
+                                                      const float *__restrict__ stat, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, int64_t rows, int ch,
+                                                      int64_t rows_per_chunk, const float *__restrict__ partial,
+                                                      int64_t chunks, float *__restrict__ dgamma,
+                                                      float *__restrict__ dbeta, float *__restrict__ dy) {
+  __shared__ double s1s[8][kBwdCols], s2s[8][kBwdCols];
+  __shared__ float s_a[kBwdCols], s_b[kBwdCols], s_c[kBwdCols], s_mean[kBwdCols], s_rstd[kBwdCols], s_g[kBwdCols],
+      s_bt[kBwdCols];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * kBwdCols;
+  const int col = c0 + cl;
+  const int colc = col < ch ? col : ch - 1;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t j = rl; j < chunks; j += 8) {
+    s1 += (double)partial[(j * 2 + 0) * ch + colc];
+    s2 += (double)partial[(j * 2 + 1) * ch + colc];
+  }
+  s1s[rl][cl] = s1;
+  s2s[rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0) {
+    for (int o = 1; o < 8; ++o) {
+      s1 += s1s[o][cl];
+      s2 += s2s[o][cl];
+    }
+    const float gm = gamma[colc], rstd = stat[ch + colc];
+    // dy = gamma*rstd*(dz - s1/N - yhat*s2/N) = a*dz - b - c*yhat
+    s_a[cl] = gm * rstd;
+    s_b[cl] = gm * rstd * (float)(s1 / (double)rows);
+    s_c[cl] = gm * rstd * (float)(s2 / (double)rows);
+    s_mean[cl] = stat[colc];
+    s_rstd[cl] = rstd;
+    s_g[cl] = gm;
+    s_bt[cl] = beta[colc];
+    if (blockIdx.y == 0 && col < ch) {
+      if (dgamma != nullptr) dgamma[col] = (float)s2;
+      if (dbeta != nullptr) dbeta[col] = (float)s1;
+    }
+  }
+  __syncthreads();
+  const int c4 = (threadIdx.x & 7) * 4;
+  const int rr = threadIdx.x >> 3;
+  if (c0 + c4 >= ch) return;
+  const int64_t r_beg = (int64_t)blockIdx.y * rows_per_chunk;
+  int64_t r_end = r_beg + rows_per_chunk;
+  if (r_end > rows) r_end = rows;
+  for (int64_t r = r_beg + rr; r < r_end; r += 32) {
+    const int64_t o = r * ch + c0 + c4;
+    const f32x4 yv = gs_ld4(y + o), dv = gs_ld4(dout + o);
+    f32x4 res;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float yh = (yv[j] - s_mean[c4 + j]) * s_rstd[c4 + j];
+      const float dz = (yh * s_g[c4 + j] + s_bt[c4 + j]) > 0.f ? dv[j] : 0.f;
+      res[j] = s_a[c4 + j] * dz - s_b[c4 + j] - s_c[c4 + j] * yh;
+    }
+    gs_st4(dy + o, res);
+  }
+}
+
+static int bn_relu_backward(const float *y, const float *dout, const float *stat, const float *gamma,
+                            const float *beta, int64_t rows, int ch, float *dgamma, float *dbeta, float *dy,
+                            float *partial, hipStream_t st) {
+  const int slabs = (ch + kBwdCols - 1) / kBwdCols;
+  int64_t chunks = 512 / slabs;
+  const int64_t max_chunks = gs_ceil_div(rows, 64);
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  int64_t rpc = gs_ceil_div(rows, chunks);
+  rpc = gs_ceil_div(rpc, 32) * 32;
+  chunks = gs_ceil_div(rows, rpc);
+  hipLaunchKernelGGL(k_bn_bwd_partial, dim3((unsigned)slabs, (unsigned)chunks), dim3(256), 0, st, y, dout, stat, gamma,
+                     beta, rows, ch, rpc, partial);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)slabs, (unsigned)chunks), dim3(256), 0, st, y, dout, stat, gamma,
+                     beta, rows, ch, rpc, partial, chunks, dgamma, dbeta, dy);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+// ------------------------------------------------------------------ aggregation backward
+// For node i, column slice c: recompute its in-edge messages exactly as the forward did, then
+//   dm_e = dmean/cnt + [m_e == min] dmin/#ties + [m_e == max] dmax/#ties + dstd (m_e - mean)/(cnt std)
+// (std term only where the forward left std unmasked).  dm rows are written in CSR order, dP_i = sum_e dm_e.
+__global__ __launch_bounds__(256) void k_agg_bwd(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ src,
+                                                 const int32_t *__restrict__ combo, const float *__restrict__ pq,
+                                                 const float *__restrict__ rtab, const float *__restrict__ agg,
+                                                 const float *__restrict__ dagg, float *__restrict__ dm,
+                                                 float *__restrict__ dp, int64_t num_nodes, int f, RowSplit rs) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t node;
+  int lane;
+  gs_split(rs, slot, node, lane);
+  if (node >= num_nodes) return;
+  const int c = lane * 4;
+  const int tower = c >= f ? 1 : 0;
+  const int col = c - tower * f;
+  const int beg = rowptr[node], end = rowptr[node + 1];
+  const int cnt = end - beg;
+  f32x4 dpacc = {0.f, 0.f, 0.f, 0.f};
+  if (cnt > 0) {
+    const int64_t ao = node * (int64_t)(8 * f) + tower * (4 * f) + col;
+    const f32x4 mean = gs_ld4(agg + ao), mn = gs_ld4(agg + ao + f), mx = gs_ld4(agg + ao + 2 * f),
+                sd = gs_ld4(agg + ao + 3 * f);
+    const f32x4 dmean = gs_ld4(dagg + ao), dmn = gs_ld4(dagg + ao + f), dmx = gs_ld4(dagg + ao + 2 * f),
+                dsd = gs_ld4(dagg + ao + 3 * f);
+    const f32x4 p = gs_ld4(pq + node * (int64_t)(4 * f) + c);
+    f32x4 nmin = {0.f, 0.f, 0.f, 0.f}, nmax = {0.f, 0.f, 0.f, 0.f};
+    for (int r = beg; r < end; ++r) {
+      const f32x4 m = (p + gs_ld4(pq + (int64_t)src[r] * (4 * f) + 2 * f + c)) +
+                      gs_ld4(rtab + (int64_t)combo[r] * (2 * f) + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        nmin[j] += m[j] == mn[j] ? 1.f : 0.f;
+        nmax[j] += m[j] == mx[j] ? 1.f : 0.f;
+      }
+    }
+    const float fc = (float)cnt;
+    f32x4 cs;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs[j] = sd[j] > 0.f ? dsd[j] / (fc * sd[j]) : 0.f;
+    for (int r = beg; r < end; ++r) {
+      const f32x4 m = (p + gs_ld4(pq + (int64_t)src[r] * (4 * f) + 2 * f + c)) +
+                      gs_ld4(rtab + (int64_t)combo[r] * (2 * f) + c);
+      f32x4 d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = dmean[j] / fc + cs[j] * (m[j] - mean[j]);
+        if (m[j] == mn[j]) v += dmn[j] / nmin[j];
+        if (m[j] == mx[j]) v += dmx[j] / nmax[j];
+        d[j] = v;
+      }
+      gs_st4(dm + (int64_t)r * (2 * f) + c, d);
+      dpacc += d;
+    }
+  }
+  gs_st4(dp + node * (int64_t)(4 * f) + c, dpacc);  // dPQ[:, 0:2F]
+}
+
+// dq[j, :] = sum over the CSR rows whose source is j (ascending row id) -> dPQ[:, 2F:4F]
+__global__ __launch_bounds__(256) void k_gather_rows_sum(const int32_t *__restrict__ rowptr_s,
+                                                         const int32_t *__restrict__ rows_s,
+                                                         const float *__restrict__ dm, float *__restrict__ dpq,
+                                                         int64_t num_nodes, int f, RowSplit rs) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t node;
+  int lane;
+  gs_split(rs, slot, node, lane);
+  if (node >= num_nodes) return;
+  const int c = lane * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = rowptr_s[node]; s < rowptr_s[node + 1]; ++s) acc += gs_ld4(dm + (int64_t)rows_s[s] * (2 * f) + c);
+  gs_st4(dpq + node * (int64_t)(4 * f) + 2 * f + c, acc);
+}
+
+// dr[class, :] += dm[row, :]: LDS accumulators per workgroup, then one global atomic per (class, column)
+__global__ __launch_bounds__(256) void k_class_reduce(const int32_t *__restrict__ combo, const float *__restrict__ dm,
+                                                      int64_t rows, int64_t rows_per_block, int classes, int f,
+                                                      float *__restrict__ dr) {
+  extern __shared__ float acc[];  // [classes][2F]
+  const int width = 2 * f;
+  for (int i = threadIdx.x; i < classes * width; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  const int64_t r_beg = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r_end = r_beg + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  const int per_row = width / 4;            // threads per row
+  const int rows_at_once = blockDim.x / per_row > 0 ? blockDim.x / per_row : 1;
+  const int rl = threadIdx.x / per_row, c = (threadIdx.x % per_row) * 4;
+  if (rl < rows_at_once) {
+    for (int64_t r = r_beg + rl; r < r_end; r += rows_at_once) {
+      const int cls = combo[r];
+      if (cls < 0 || cls >= classes) continue;
+      const f32x4 v = gs_ld4(dm + r * width + c);
+      float *a = acc + cls * width + c;
+      atomicAdd(a + 0, v.x);
+      atomicAdd(a + 1, v.y);
+      atomicAdd(a + 2, v.z);
+      atomicAdd(a + 3, v.w);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < classes * width; i += blockDim.x) {
+    const float v = acc[i];
+    if (v != 0.f) atomicAdd(dr + i, v);
+  }
+}
+
+// WTA[d][t][c][o] = W_t[o][F+c] + amp(d) W_t[o][5F+c] + att(d) W_t[o][9F+c]   (c < 4F, o < F/2)
+struct PostPair {
+  const float *w0, *w1;
+};
+__global__ __launch_bounds__(256) void k_fold_post_weights_t(PostPair pp, const float *__restrict__ avg,
+                                                             const int32_t *__restrict__ hist, int f,
+                                                             float *__restrict__ wta) {
+  __shared__ float tl[32][33];
+  const int d = blockIdx.z / 2, t = blockIdx.z % 2;
+  if (hist[d] == 0) return;
+  const float *w = t == 0 ? pp.w0 : pp.w1;
+  const float avgv = avg[0];
+  const float amp = logf((float)d + 1.f) / avgv;
+  const float att = avgv / logf(fmaxf((float)d, 1.f) + 1.f);
+  const int o0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int o = o0 + ty + 8 * j;
+    const float *wr = w + (int64_t)o * (13 * f) + f + c0 + tx;
+    tl[ty + 8 * j][tx] = wr[0] + wr[4 * f] * amp + wr[8 * f] * att;
+  }
+  __syncthreads();
+  float *out = wta + (((int64_t)d * 2 + t) * (4 * f)) * (f / 2);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[(int64_t)(c0 + ty + 8 * j) * (f / 2) + o0 + tx] = tl[tx][ty + 8 * j];
+}
+
+// bond tables: dtab_k[v, :] (+)= sum over combinations c with digit_k(c) == v of dcemb[c, :]
+struct TableGrads {
+  int32_t n;
+  int32_t dims[GNNSAFT_MAX_TABLES];
+  float *grad[GNNSAFT_MAX_TABLES];
+};
+__global__ __launch_bounds__(256) void k_combo_embed_bwd(const float *__restrict__ dcemb, int64_t combos, int h,
+                                                         TableGrads tg) {
+  const int k = blockIdx.y;
+  if (tg.grad[k] == nullptr) return;
+  const int per_row = h / 4;
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t v = slot / per_row;
+  if (v >= tg.dims[k]) return;
+  const int c = (int)(slot - v * per_row) * 4;
+  int64_t stride = 1;
+  for (int j = tg.n - 1; j > k; --j) stride *= tg.dims[j];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t cid = 0; cid < combos; ++cid)
+    if ((cid / stride) % tg.dims[k] == v) acc += gs_ld4(dcemb + cid * h + c);
+  gs_st4(tg.grad[k] + v * h + c, acc);
+}
+
+// atom tables: dtab_k[v, hh] = det[hh][off_k + v]   (det = one-hot^T dx0, stored transposed)
+__global__ __launch_bounds__(256) void k_unpack_embed_grad(const float *__restrict__ det, int ld, int h, TableGrads tg,
+                                                           int table, int off) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)tg.dims[table] * h) return;
+  const int64_t v = i / h;
+  const int hh = (int)(i - v * h);
+  tg.grad[table][i] = det[(int64_t)hh * ld + off + v];
+}
+
+struct Scratch {
+  char *base;
+  size_t off = 0, cap;
+  template <class T>
+  T *take(size_t count) {
+    const size_t o = off;
+    off += gs_align_up(count * sizeof(T), 256);
+    return off <= cap ? reinterpret_cast<T *>(base + o) : nullptr;
+  }
+};
+
+struct BwdSizes {
+  size_t slab, total;
+};
+
+static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
+  const size_t h = d->hidden, nn = p.n > 0 ? p.n : 1, ee = p.ep > 0 ? p.ep : 1, gg = p.g > 0 ? p.g : 1;
+  const size_t rows = nn > gg ? nn : gg;
+  size_t slab = tn_slab_bytes(p.n, (int)(h / 2), (int)(13 * h));       // dW_post
+  const size_t s2 = tn_slab_bytes(p.n, (int)h, 176 + 16);                 // one-hot (atom vocabulary rows)
+  const size_t s3 = tn_slab_bytes(rows, (int)h, (int)h);
+  slab = slab > s2 ? slab : s2;
+  slab = slab > s3 ? slab : s3;
+  size_t tot = 0;
+  auto add = [&](size_t b) { tot += gs_align_up(b, 256); };
+  add(slab);
+  for (int i = 0; i < 2; ++i) add(nn * h * 4);          // dxa, dxb
+  add(nn * h * 4);                                       // dy
+  add(nn * h * 4);                                       // du
+  add(nn * 8 * h * 4);                                   // dagg
+  add(ee * 2 * h * 4);                                   // dm
+  add(nn * 4 * h * 4);                                   // dpq
+  add((size_t)p.combos * 2 * h * 4);                     // dr
+  add((size_t)p.combos * h * 4 * 2);                     // dcenc, dcemb
+  add(1024 * 2 * h * 4);                                 // bn partials
+  add(h * h * 4 * 3);                                    // wlinT, wxT, weT
+  add((size_t)kDegreeBuckets * 2 * 4 * h * (h / 2) * 4); // wta
+  add(h * 4 * h * 4);                                    // wpqT
+  add(h * 2 * h * 4);                                    // wcT
+  add((nn + 1) * 4);                                     // rowptr_s
+  add(ee * 4);                                           // rows_s
+  add(group_by_key_workspace_bytes(p.n));
+  add(gg * h * 4 * 3);                                   // readout dcur, dnext, dyr
+  add(gg * 8 * 4);                                       // padded dout
+  add(h * 8 * 4);                                        // padded W3^T
+  add(h * (size_t)(176 + 16) * 4);                       // one-hot result
+  return BwdSizes{slab, tot + 65536};
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" size_t gnnsaft_backward_scratch_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes, int64_t num_edges,
+                                                 int64_t num_graphs) {
+  Plan p;
+  if (make_plan(desc, num_nodes, num_edges, num_graphs, p) != GNNSAFT_OK) return 0;
+  return backward_sizes(desc, p).total;
+}
+
+extern "C" int gnnsaft_mape_backward(const float *pred, const float *target, int64_t num_graphs, int32_t num_para,
+                                     const float *dloss, float *dpred, gnnsaft_stream_t stream) {
+  GS_REQUIRE(pred && target && dpred, GNNSAFT_ERR_NULL);
+  const int64_t tot = num_graphs * num_para;
+  hipLaunchKernelGGL(k_mape_bwd, dim3((unsigned)gs_ceil_div(tot, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     pred, target, num_graphs, num_para, num_para, dloss, dpred);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *weights_host,
+                                void *const *grads_host, int32_t num_weights, const int64_t *x_idx,
+                                const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
+                                const float *grad_out /* [G,P] */, void *tape, size_t tape_bytes, void *scratch,
+                                size_t scratch_bytes, gnnsaft_stream_t stream) {
+  (void)batch;
+  GS_REQUIRE(d && weights_host && grads_host && grad_out && tape && scratch && x_idx, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(d->save_tape && d->training, GNNSAFT_ERR_UNSUPPORTED);
+  GS_REQUIRE(d->pre_layers == 1 && d->post_layers == 1 && (d->hidden % 64) == 0 && d->fold_degree_scalers &&
+                 !d->fold_dst_term,
+             GNNSAFT_ERR_UNSUPPORTED);
+  Plan p;
+  GS_TRY(make_plan(d, num_nodes, num_edges, num_graphs, p));
+  GS_REQUIRE(tape_bytes >= p.total, GNNSAFT_ERR_WORKSPACE);
+  const BwdSizes bs = backward_sizes(d, p);
+  GS_REQUIRE(scratch_bytes >= bs.total && (reinterpret_cast<uintptr_t>(scratch) & 255) == 0, GNNSAFT_ERR_WORKSPACE);
+  ParsedWeights pw;
+  GS_TRY(parse_weights(d, weights_host, num_weights, pw));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char *tp = static_cast<char *>(tape);
+  auto F = [&](size_t off) { return reinterpret_cast<float *>(tp + off); };
+  auto I = [&](size_t off) { return reinterpret_cast<int32_t *>(tp + off); };
+  auto G = [&](int idx) { return static_cast<float *>(grads_host[idx]); };
+  const int h = d->hidden, P = d->num_para, L = d->num_layers;
+  const int64_t n = num_nodes, g = num_graphs;
+  const int64_t C = p.combos;
+
+  Scratch sc{static_cast<char *>(scratch), 0, scratch_bytes};
+  float *slabs = sc.take<float>(bs.slab / 4);
+  float *dxa = sc.take<float>(n * h), *dxb = sc.take<float>(n * h);
+  float *dy = sc.take<float>(n * h), *du = sc.take<float>(n * h);
+  float *dagg = sc.take<float>(n * 8 * h);
+  float *dm = sc.take<float>((p.ep > 0 ? p.ep : 1) * 2 * h);
+  float *dpq = sc.take<float>(n * 4 * h);
+  float *dr = sc.take<float>(C * 2 * h);
+  float *dcenc = sc.take<float>(C * h), *dcemb = sc.take<float>(C * h);
+  float *bnpart = sc.take<float>(1024 * 2 * h);
+  float *wlinT = sc.take<float>((size_t)h * h), *wxT = sc.take<float>((size_t)h * h),
+        *weT = sc.take<float>((size_t)h * h);
+  float *wta = sc.take<float>((size_t)kDegreeBuckets * 2 * 4 * h * (h / 2));
+  float *wpqT = sc.take<float>((size_t)h * 4 * h);
+  float *wcT = sc.take<float>((size_t)h * 2 * h);
+  int32_t *rowptr_s = sc.take<int32_t>(n + 1);
+  int32_t *rows_s = sc.take<int32_t>(p.ep > 0 ? p.ep : 1);
+  char *grp_ws = sc.take<char>(group_by_key_workspace_bytes(n));
+  float *dcur = sc.take<float>(g * h), *dnext = sc.take<float>(g * h), *dyr = sc.take<float>(g * h);
+  float *dout_pad = sc.take<float>(g * 8);
+  float *w3T = sc.take<float>((size_t)h * 8);
+  const int vocab_pad = 192;
+  float *det = sc.take<float>((size_t)h * vocab_pad);
+  GS_REQUIRE(det != nullptr, GNNSAFT_ERR_WORKSPACE);
+  const size_t slab_bytes = bs.slab;
+
+  auto transpose1 = [&](const float *in, int64_t ld_in, float *out, int64_t ld_out, int rows, int cols) {
+    const float *i1[1] = {in};
+    float *o1[1] = {out};
+    return launch_transpose(1, i1, o1, &ld_in, &ld_out, rows, cols, st);
+  };
+  auto dgrad = [&](const float *a, int64_t lda, const float *wT, int64_t ldw, float *out, int64_t ldo, int64_t rows,
+                   int n_out, int k, const float *residual) {
+    GemmBatchEntry e{wT, nullptr, out, 0};
+    LinearEpilogue epi;
+    epi.residual = residual;
+    epi.ldr = ldo;
+    return launch_linear(a, lda, 0, 1, &e, ldw, ldo, rows, n_out, k, epi, st);
+  };
+
+  // =========================== readout backward ===========================
+  const int nb = p.nb;
+  const int64_t rs = g * (int64_t)h;
+  GS_REQUIRE(P <= 8, GNNSAFT_ERR_UNSUPPORTED);
+  {
+    // final Linear(H/4 -> P): pad dOut to 8 columns so that the GEMMs can use 16-byte loads
+    hipLaunchKernelGGL(k_pad_cols, dim3((unsigned)gs_ceil_div(g * 8, 256)), dim3(256), 0, st, grad_out, g, P, 8, dout_pad);
+    const ReadoutW &fin = pw.readout[nb];
+    const int ib = pw.readout_base[nb];
+    const float *in = F(p.ro) + (nb - 1) * rs;  // output of the last BN block, width H/4
+    GS_TRY(launch_wgrad_plain(dout_pad, 8, in, fin.n_in, 0, g, P, fin.n_in, G(ib), fin.n_in, 0, slabs, slab_bytes, st));
+    GS_TRY(launch_colsum(dout_pad, 8, g, P, G(ib + 1), 0, slabs, slab_bytes, st));
+    // dIn = dOut W3: W'[n_out = H/4][k = 8] = W3^T zero-padded
+    hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div((int64_t)h * 8, 256)), dim3(256), 0, st, w3T,
+                       (int64_t)h * 8);
+    GS_TRY(transpose1(fin.w, fin.n_in, w3T, 8, P, fin.n_in));
+    GS_TRY(dgrad(dout_pad, 8, w3T, 8, dcur, fin.n_in, g, fin.n_in, 8, nullptr));
+  }
+  for (int bi = nb - 1; bi >= 0; --bi) {
+    const ReadoutW &rw = pw.readout[bi];
+    const int ib = pw.readout_base[bi];
+    const float *yb = F(p.ry) + bi * rs;
+    const float *in = bi == 0 ? F(p.pooled) : F(p.ro) + (bi - 1) * rs;
+    const float *stat = F(p.rstat) + (int64_t)bi * 2 * h;
+    GS_TRY(bn_relu_backward(yb, dcur, stat, rw.bn.gamma, rw.bn.beta, g, rw.n_out, G(ib + 2), G(ib + 3), dyr, bnpart, st));
+    GS_TRY(launch_wgrad_plain(dyr, rw.n_out, in, rw.n_in, 0, g, rw.n_out, rw.n_in, G(ib), rw.n_in, 0, slabs, slab_bytes,
+                              st));
+    GS_TRY(launch_colsum(dyr, rw.n_out, g, rw.n_out, G(ib + 1), 0, slabs, slab_bytes, st));
+    GS_TRY(transpose1(rw.w, rw.n_in, wlinT, rw.n_out, rw.n_out, rw.n_in));  // [n_in][n_out]
+    GS_TRY(dgrad(dyr, rw.n_out, wlinT, rw.n_out, dnext, rw.n_in, g, rw.n_in, rw.n_out, nullptr));
+    float *t = dcur;
+    dcur = dnext;
+    dnext = t;
+  }
+  // pool backward: dx_L
+  float *dx = dxa, *dx_other = dxb;
+  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)gs_ceil_div(g * (h / 4), 256)), dim3(256), 0, st, dcur,
+                     I(p.graph_ptr), g, n, h, dx, gs_row_split(h / 4));
+
+  // =========================== transposed CSR (rows grouped by source) ===========================
+  GS_TRY(launch_group_by_key(I(p.src), p.ep, n, rowptr_s, rows_s, grp_ws, group_by_key_workspace_bytes(n), st));
+
+  hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * h, 256)), dim3(256), 0, st, dcemb, C * h);
+
+  // =========================== layers, in reverse ===========================
+  for (int l = L - 1; l >= 0; --l) {
+    const LayerW &w = pw.layers[l];
+    const int base = pw.layer_base[l];
+    // table indices inside the layer: avg 0 | we 1 be 2 | pre0 w3 b4 | pre1 w5 b6 | post0 w7 b8 | post1 w9 b10 |
+    //                                lin w11 b12 | bn gamma 13 beta 14 (running stats 15,16, counter 17)
+    const float *x_l = F(p.x0) + l * p.sx, *pq_l = F(p.pq) + l * p.spq, *agg_l = F(p.agg) + l * p.sagg;
+    const float *u_l = F(p.u0) + l * p.su, *y_l = F(p.y) + l * p.sy;
+    const float *stat = F(p.bnstat) + (int64_t)l * 2 * h;
+    const float *rtab = F(p.rtab) + l * C * (int64_t)(2 * h);
+    const float *cenc = F(p.cenc) + l * C * (int64_t)h;
+
+    // x_{l+1} = relu(bn(y)) + x_l : dy through BN+ReLU; the skip gradient stays in dx
+    GS_TRY(bn_relu_backward(y_l, dx, stat, w.bn.gamma, w.bn.beta, n, h, G(base + 13), G(base + 14), dy, bnpart, st));
+    // lin
+    GS_TRY(launch_wgrad_plain(dy, h, u_l, h, 0, n, h, h, G(base + 11), h, 0, slabs, slab_bytes, st));
+    GS_TRY(launch_colsum(dy, h, n, h, G(base + 12), 0, slabs, slab_bytes, st));
+    GS_TRY(transpose1(w.wlin, h, wlinT, h, h, h));
+    GS_TRY(dgrad(dy, h, wlinT, h, du, h, n, h, h, nullptr));
+    // update wgrad / bias
+    for (int t = 0; t < 2; ++t) {
+      GS_TRY(launch_wgrad_post(du + t * (h / 2), h, x_l, agg_l + t * 4 * h, F(p.log_amp), F(p.log_att), w.avg, n, h,
+                               G(base + 7 + 2 * t), slabs, slab_bytes, st));
+      GS_TRY(launch_colsum(du + t * (h / 2), h, n, h / 2, G(base + 8 + 2 * t), 0, slabs, slab_bytes, st));
+    }
+    // update dgrad, x part: dx_in = (skip ? dx : 0) + du [N,F] x [W_x,0 ; W_x,1]
+    {
+      const float *ins[2] = {w.wpost[0][0], w.wpost[1][0]};
+      float *outs[2] = {wxT, wxT + h / 2};
+      const int64_t ldi[2] = {13 * (int64_t)h, 13 * (int64_t)h}, ldo[2] = {h, h};
+      GS_TRY(launch_transpose(2, ins, outs, ldi, ldo, h / 2, h, st));  // wxT[j][t*F/2 + o] = W_t[o][j]
+      GS_TRY(dgrad(du, h, wxT, h, dx_other, h, n, h, h, d->skip_connections ? dx : nullptr));
+    }
+    // update dgrad, aggregate part (degree-tiled, scalers folded): dagg[i,t,:] = du_t[i] W_A,eff(d_i, t)
+    {
+      PostPair pp{w.wpost[0][0], w.wpost[1][0]};
+      hipLaunchKernelGGL(k_fold_post_weights_t, dim3((unsigned)(4 * h / 32), (unsigned)(h / 2 / 32), kDegreeBuckets * 2),
+                         dim3(256), 0, st, pp, w.avg, I(p.hist3), h, wta);
+      const int64_t per_t = (int64_t)(4 * h) * (h / 2);
+      GemmBatchEntry e[2] = {{wta, nullptr, dagg, 0}, {wta + per_t, nullptr, dagg + 4 * h, h / 2}};
+      GS_TRY(launch_linear_degree_tiled(du, h, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap, 2 * per_t, 2, e,
+                                        h / 2, 8 * (int64_t)h, n, 4 * h, h / 2, h, st));
+    }
+    // aggregation backward: dm rows, dP; then dQ by source, dR by class
+    hipLaunchKernelGGL(k_agg_bwd, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, I(p.rowptr),
+                       I(p.src), I(p.combo), pq_l, rtab, agg_l, dagg, dm, dpq, n, h, gs_row_split(h / 2));
+    hipLaunchKernelGGL(k_gather_rows_sum, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, rowptr_s,
+                       rows_s, dm, dpq, n, h, gs_row_split(h / 2));
+    hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * 2 * h, 256)), dim3(256), 0, st, dr, C * 2 * h);
+    {
+      const size_t lds = (size_t)C * 2 * h * 4;
+      GS_REQUIRE(lds <= 160 * 1024 - 1024, GNNSAFT_ERR_UNSUPPORTED);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_class_reduce),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      const int64_t rpb = 512;
+      hipLaunchKernelGGL(k_class_reduce, dim3((unsigned)gs_ceil_div(p.ep, rpb)), dim3(256), lds, st, I(p.combo), dm,
+                         p.ep, rpb, (int)C, h, dr);
+    }
+    // message GEMMs: dx_in += [dP | dQ] W_pq ; dW_dst,t / dW_src,t = dP_t^T x / dQ_t^T x
+    {
+      const float *ins[4] = {w.wpre[0][0], w.wpre[1][0], w.wpre[0][0] + h, w.wpre[1][0] + h};
+      float *outs[4] = {wpqT, wpqT + h, wpqT + 2 * h, wpqT + 3 * h};
+      const int64_t ldi[4] = {3 * (int64_t)h, 3 * (int64_t)h, 3 * (int64_t)h, 3 * (int64_t)h};
+      const int64_t ldo[4] = {4 * (int64_t)h, 4 * (int64_t)h, 4 * (int64_t)h, 4 * (int64_t)h};
+      GS_TRY(launch_transpose(4, ins, outs, ldi, ldo, h, h, st));  // wpqT[j][blk*F + f] = pre_t[f][part*F + j]
+      GS_TRY(dgrad(dpq, 4 * (int64_t)h, wpqT, 4 * (int64_t)h, dx, h, n, h, 4 * h, dx_other));
+      for (int t = 0; t < 2; ++t) {
+        float *gw = G(base + 3 + 2 * t);
+        GS_TRY(launch_wgrad_plain(dpq + t * h, 4 * (int64_t)h, x_l, h, 0, n, h, h, gw, 3 * (int64_t)h, 0, slabs,
+                                  slab_bytes, st));
+        GS_TRY(launch_wgrad_plain(dpq + 2 * h + t * h, 4 * (int64_t)h, x_l, h, 0, n, h, h, gw + h, 3 * (int64_t)h, 0,
+                                  slabs, slab_bytes, st));
+      }
+    }
+    // edge-class table: rtab[c, tF:(t+1)F] = W_t[:,2F:3F] cenc[c] + b_t ; cenc = cemb W_e^T + b_e
+    for (int t = 0; t < 2; ++t) {
+      float *gw = G(base + 3 + 2 * t);
+      GS_TRY(launch_wgrad_plain(dr + t * h, 2 * (int64_t)h, cenc, h, 0, C, h, h, gw + 2 * h, 3 * (int64_t)h, 0, slabs,
+                                slab_bytes, st));
+      GS_TRY(launch_colsum(dr + t * h, 2 * (int64_t)h, C, h, G(base + 4 + 2 * t), 0, slabs, slab_bytes, st));
+    }
+    {
+      const float *ins[2] = {w.wpre[0][0] + 2 * h, w.wpre[1][0] + 2 * h};
+      float *outs[2] = {wcT, wcT + h};
+      const int64_t ldi[2] = {3 * (int64_t)h, 3 * (int64_t)h}, ldo[2] = {2 * (int64_t)h, 2 * (int64_t)h};
+      GS_TRY(launch_transpose(2, ins, outs, ldi, ldo, h, h, st));  // wcT[j][t*F + f] = pre_t[f][2F + j]
+      GS_TRY(dgrad(dr, 2 * (int64_t)h, wcT, 2 * (int64_t)h, dcenc, h, C, h, 2 * h, nullptr));
+      GS_TRY(launch_wgrad_plain(dcenc, h, F(p.cemb), h, 0, C, h, h, G(base + 1), h, 0, slabs, slab_bytes, st));
+      GS_TRY(launch_colsum(dcenc, h, C, h, G(base + 2), 0, slabs, slab_bytes, st));
+      GS_TRY(transpose1(w.we, h, weT, h, h, h));
+      GS_TRY(dgrad(dcenc, h, weT, h, dcemb, h, C, h, h, dcemb));  // accumulate over layers (in place)
+    }
+    // dx now holds dL/dx_l; dx_other is free again
+  }
+
+  // =========================== embeddings ===========================
+  {
+    TableGrads tg;
+    tg.n = d->num_bond_cols;
+    for (int k = 0; k < GNNSAFT_MAX_TABLES; ++k) {
+      tg.dims[k] = k < d->num_bond_cols ? d->bond_dims[k] : 1;
+      tg.grad[k] = k < d->num_bond_cols ? G(pw.bond0 + k) : nullptr;
+    }
+    int maxdim = 1;
+    for (int k = 0; k < d->num_bond_cols; ++k) maxdim = d->bond_dims[k] > maxdim ? d->bond_dims[k] : maxdim;
+    hipLaunchKernelGGL(k_combo_embed_bwd, dim3((unsigned)gs_ceil_div((int64_t)maxdim * (h / 4), 256),
+                                                 (unsigned)d->num_bond_cols),
+                       dim3(256), 0, st, dcemb, C, h, tg);
+  }
+  {
+    int total = 0;
+    for (int k = 0; k < d->num_atom_cols; ++k) total += d->atom_dims[k];
+    GS_REQUIRE(total <= vocab_pad, GNNSAFT_ERR_UNSUPPORTED);
+    GS_TRY(launch_wgrad_onehot(dx, h, x_idx, d->num_atom_cols, d->atom_dims, n, h, det, vocab_pad, slabs, slab_bytes,
+                               st));
+    TableGrads tg;
+    tg.n = d->num_atom_cols;
+    int off = 0;
+    for (int k = 0; k < GNNSAFT_MAX_TABLES; ++k) {
+      tg.dims[k] = k < d->num_atom_cols ? d->atom_dims[k] : 1;
+      tg.grad[k] = k < d->num_atom_cols ? G(pw.atom0 + k) : nullptr;
+    }
+    for (int k = 0; k < d->num_atom_cols; ++k) {
+      hipLaunchKernelGGL(k_unpack_embed_grad, dim3((unsigned)gs_ceil_div((int64_t)d->atom_dims[k] * h, 256)),
+                         dim3(256), 0, st, det, vocab_pad, h, tg, k, off);
+      off += d->atom_dims[k];
+    }
+  }
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}

@@ -98,6 +98,33 @@ int launch_pna_update_folded(const float *x, const float *agg, const int32_t *pe
 
 void debug_set_gemm_config(int cfg);
 
+// degree-tiled dgrad of the folded update: out[perm[slot], :] = a[perm[slot], a_off:a_off+k] x W(d)^T for the
+// rows of every degree tile; entries[t].w points at the (transposed, folded) weights of degree 0, the weights
+// of degree d sit w_stride floats further per degree
+int launch_linear_degree_tiled(const float *a, int64_t lda, const int32_t *perm, const int32_t *tiles,
+                               const int32_t *num_tiles, int64_t max_tiles, int64_t w_stride, int nbatch,
+                               const GemmBatchEntry *entries, int64_t ldw, int64_t ldo, int64_t n, int n_out, int k,
+                               int hidden /* the tile table was built for */, hipStream_t stream);
+
+// ---- backward building blocks (gemm_tn.hip, csr.hip)
+size_t tn_slab_bytes(int64_t m, int n_out, int k);
+int launch_wgrad_plain(const float *dy, int64_t ldy, const float *a, int64_t lda, int relu_a, int64_t m, int n_out,
+                       int k, float *out, int64_t ld_out, int accumulate, float *slabs, size_t slab_bytes,
+                       hipStream_t st);
+int launch_wgrad_post(const float *du_t, int64_t ldu, const float *x, const float *agg_t, const float *log_amp,
+                      const float *log_att, const float *avg, int64_t n, int hidden, float *dw, float *slabs,
+                      size_t slab_bytes, hipStream_t st);
+int launch_wgrad_onehot(const float *dx, int64_t ldx, const int64_t *idx, int ncol, const int32_t *dims_host, int64_t n,
+                        int hidden, float *dtab_t, int total_rows_padded, float *slabs, size_t slab_bytes,
+                        hipStream_t st);
+int launch_transpose(int count, const float *const *in, float *const *out, const int64_t *ld_in, const int64_t *ld_out,
+                     int rows, int cols, hipStream_t st);
+int launch_colsum(const float *a, int64_t lda, int64_t m, int cols, float *out, int accumulate, float *partial,
+                  size_t partial_bytes, hipStream_t st);
+size_t group_by_key_workspace_bytes(int64_t num_keys);
+int launch_group_by_key(const int32_t *keys, int64_t count, int64_t num_keys, int32_t *rowptr, int32_t *rows,
+                        void *workspace, size_t workspace_bytes, hipStream_t st);
+
 constexpr int kDegreeBuckets = 32;  // folded update: exact in-degree buckets 0..31
 
 }  // namespace gs

@@ -186,6 +186,76 @@ __global__ void k_batch_to_ptr(const int64_t *__restrict__ batch, int64_t n, int
   for (int64_t q = prev + 1; q <= cur && q <= g; ++q) ptr[q] = (int32_t)i;
 }
 
+// ---- group an int32 key array (e.g. the CSR rows' source node) by key: the transposed CSR that
+//      the backward pass uses to turn the scatter-add of message gradients into a gather
+__global__ void k_count_keys(const int32_t *__restrict__ keys, int64_t count, int64_t num_keys,
+                             int32_t *__restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int32_t k = keys[i];
+  if (k >= 0 && k < num_keys) atomicAdd(&counts[k], 1);
+}
+
+__global__ void k_fill_by_key(const int32_t *__restrict__ keys, int64_t count, int64_t num_keys,
+                              const int32_t *__restrict__ rowptr, int32_t *__restrict__ cursor,
+                              int32_t *__restrict__ rows) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int32_t k = keys[i];
+  if (k < 0 || k >= num_keys) return;
+  rows[rowptr[k] + atomicAdd(&cursor[k], 1)] = (int32_t)i;
+}
+
+__global__ void k_sort_segments(const int32_t *__restrict__ rowptr, int64_t num_keys, int32_t *__restrict__ rows) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= num_keys) return;
+  const int beg = rowptr[k], end = rowptr[k + 1];
+  for (int a = beg + 1; a < end; ++a) {  // ascending row id: fixed summation order downstream
+    const int key = rows[a];
+    int b = a - 1;
+    while (b >= beg && rows[b] > key) {
+      rows[b + 1] = rows[b];
+      --b;
+    }
+    rows[b + 1] = key;
+  }
+}
+
+size_t group_by_key_workspace_bytes(int64_t num_keys) {
+  const size_t tiles = (size_t)gs_ceil_div(num_keys > 0 ? num_keys : 1, kScanTile);
+  return gs_align_up((size_t)num_keys * 4, 256) * 2 + gs_align_up(tiles * 4, 256);
+}
+
+int launch_group_by_key(const int32_t *keys, int64_t count, int64_t num_keys, int32_t *rowptr, int32_t *rows,
+                        void *workspace, size_t workspace_bytes, hipStream_t st) {
+  GS_REQUIRE(keys && rowptr && rows && workspace, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(num_keys >= 1 && count >= 0, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(workspace_bytes >= group_by_key_workspace_bytes(num_keys), GNNSAFT_ERR_WORKSPACE);
+  char *ws = static_cast<char *>(workspace);
+  int32_t *counts = reinterpret_cast<int32_t *>(ws);
+  int32_t *cursor = reinterpret_cast<int32_t *>(ws + gs_align_up((size_t)num_keys * 4, 256));
+  int32_t *tile_sums = reinterpret_cast<int32_t *>(ws + 2 * gs_align_up((size_t)num_keys * 4, 256));
+  const int64_t zero_ints = 2 * (int64_t)gs_align_up((size_t)num_keys * 4, 256) / 4;
+  const int64_t tiles = gs_ceil_div(num_keys, kScanTile);
+  hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)gs_ceil_div(zero_ints, 256)), dim3(256), 0, st, counts, zero_ints);
+  if (count > 0)
+    hipLaunchKernelGGL(k_count_keys, dim3((unsigned)gs_ceil_div(count, 256)), dim3(256), 0, st, keys, count, num_keys,
+                       counts);
+  hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)tiles), dim3(kScanBlock), 0, st, counts, num_keys, 0, rowptr,
+                     tile_sums);
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kScanBlock), 0, st, tile_sums, tiles, rowptr, num_keys);
+  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)gs_ceil_div(num_keys, 256)), dim3(256), 0, st, rowptr, tile_sums,
+                     num_keys);
+  if (count > 0) {
+    hipLaunchKernelGGL(k_fill_by_key, dim3((unsigned)gs_ceil_div(count, 256)), dim3(256), 0, st, keys, count, num_keys,
+                       rowptr, cursor, rows);
+    hipLaunchKernelGGL(k_sort_segments, dim3((unsigned)gs_ceil_div(num_keys, 256)), dim3(256), 0, st, rowptr, num_keys,
+                       rows);
+  }
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
 __global__ void k_single_graph_ptr(int32_t *ptr, int32_t n) {
   ptr[0] = 0;
   ptr[1] = n;

@@ -189,6 +189,41 @@ struct PostFoldA {
   __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &, int, int) const { return w.v; }
 };
 
+// Plain rows addressed through the degree permutation, weights selected per degree tile (backward of
+// the folded update: dA_t[rows of degree d] = du_t[rows] W_eff(d,t)).
+struct PermPlainA {
+  const float *a;
+  int64_t lda;
+  const int32_t *perm;
+  const int32_t *tiles;
+  const int32_t *num_tiles;
+  int64_t w_stride;
+  int k;
+  struct Row {
+    const float *p;
+  };
+  struct Raw {
+    f32x4 v;
+  };
+  __device__ __forceinline__ TileInfo tile(int bx, int) const {
+    if (bx >= num_tiles[0]) return TileInfo{0, 0, 0};
+    const int32_t *t = tiles + 4 * (int64_t)bx;
+    return TileInfo{t[1], t[2], (int64_t)t[0] * w_stride};
+  }
+  __device__ __forceinline__ int64_t out_row(const TileInfo &t, int lr) const { return perm[t.row0 + lr]; }
+  __device__ __forceinline__ Row row(int64_t slot, int64_t a_off) const {
+    return Row{a + (int64_t)perm[slot] * lda + a_off};
+  }
+  __device__ __forceinline__ Raw load(const Row &r, int k0, int c) const {
+    const int kk = k0 + c;
+    return Raw{gs_ld4(r.p + (kk < k ? kk : 0))};
+  }
+  __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &, int k0, int c) const {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    return (k0 + c < k) ? w.v : zero;
+  }
+};
+
 struct GemmBatch {
   GemmBatchEntry e[kMaxGemmBatch];
 };
@@ -546,9 +581,12 @@ int launch_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *c
   return dispatch<EdgeA, false>(ap, 2, e, hidden, ldo, rows, hidden, hidden, epi, stream);
 }
 
+static int tiled_cfg_for(int hidden) { return pick_cfg(1 << 20, hidden / 2, 5 * hidden, false); }
+
 int pna_fold_tile_rows(int hidden) {
-  // rows per degree tile = BM of the configuration the folded update runs with (n_out = F/2 per tower)
-  return kCfgBM[pick_cfg(1 << 20, hidden / 2, 5 * hidden, false)];
+  // rows per degree tile = BM of the configuration the folded update runs with (n_out = F/2 per tower);
+  // every launch that walks the tile table must use a configuration with the same BM
+  return kCfgBM[tiled_cfg_for(hidden)];
 }
 
 int launch_pna_update_folded(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
@@ -566,7 +604,23 @@ int launch_pna_update_folded(const float *x, const float *agg, const int32_t *pe
   for (int i = 2; i < kMaxGemmBatch; ++i) b.e[i] = b.e[0];
   EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr};
   return launch_cfg<PostFoldA, false, false, false>(ap, 2, b, 5 * (int64_t)hidden, hidden, n, hidden / 2, 5 * hidden,
-                                                    ea, stream, pick_cfg(1 << 20, hidden / 2, 5 * hidden, false), max_tiles);
+                                                    ea, stream, tiled_cfg_for(hidden), max_tiles);
+}
+
+int launch_linear_degree_tiled(const float *a, int64_t lda, const int32_t *perm, const int32_t *tiles,
+                               const int32_t *num_tiles, int64_t max_tiles, int64_t w_stride, int nbatch,
+                               const GemmBatchEntry *entries, int64_t ldw, int64_t ldo, int64_t n, int n_out, int k,
+                               int hidden, hipStream_t stream) {
+  GS_REQUIRE(a && perm && tiles && num_tiles && entries, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(nbatch >= 1 && nbatch <= kMaxGemmBatch && (k % 4) == 0 && (ldw % 4) == 0 && (lda % 4) == 0,
+             GNNSAFT_ERR_SHAPE);
+  if (n == 0) return GNNSAFT_OK;
+  PermPlainA ap{a, lda, perm, tiles, num_tiles, w_stride, k};
+  GemmBatch b;
+  for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entries[i < nbatch ? i : 0];
+  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr};
+  return launch_cfg<PermPlainA, false, false, false>(ap, nbatch, b, ldw, ldo, n, n_out, k, ea, stream,
+                                                     tiled_cfg_for(hidden), max_tiles);
 }
 
 void debug_set_gemm_config(int cfg) { g_cfg_override = cfg; }

@@ -197,17 +197,17 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
   const int64_t m_beg = (int64_t)blockIdx.y * kTnChunk;
   int64_t m_end = m_beg + kTnChunk;
   if (m_end > m) m_end = m;
-  float s = 0.f;
-  for (int64_t r = m_beg; r < m_end; ++r) s += a[r * lda + c];
-  partial[(int64_t)blockIdx.y * cols + c] = s;
+  double s = 0.0;  // bias gradients in front of a train-mode BatchNorm are exactly zero: keep the sum exact
+  for (int64_t r = m_beg; r < m_end; ++r) s += (double)a[r * lda + c];
+  partial[(int64_t)blockIdx.y * cols + c] = (float)s;
 }
 __global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ partial, int64_t chunks, int cols,
                                                       float *__restrict__ out, int accumulate) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= cols) return;
-  float s = 0.f;
-  for (int64_t j = 0; j < chunks; ++j) s += partial[j * cols + c];
-  out[c] = accumulate ? out[c] + s : s;
+  double s = 0.0;
+  for (int64_t j = 0; j < chunks; ++j) s += (double)partial[j * cols + c];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 template <class AProv>

@@ -216,14 +216,13 @@ class PNAPCSAFT(nn.Module):
         if self.training and (self.pna_params.dropout > 0 or self.mlp_params.dropout > 0):
             raise NotImplementedError("dropout > 0 in training mode is not implemented (the reference always "
                                       "trains with dropout 0.0: train/utils.py:57-69, configs/default.py:41)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "the backward pass is not implemented yet (SURVEY.md section 8(f) rank 1): run the forward under "
-                "torch.no_grad() / torch.inference_mode()")
 
-    def run(self, data, target: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-        """Forward (+ MAPE loss when ``target`` [G,P] is given).  Returns
-        ``(pred [G,P], loss3)`` with ``loss3 = [mape, sum(ape), numel]`` on device."""
+    def _needs_grad(self) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def _launch(self, data, target: Optional[torch.Tensor], tape: bool):
+        """One gnnsaft_forward call.  Returns (pred, loss3, ctx) where ctx holds what gnnsaft_backward needs
+        when ``tape`` is set (the workspace doubles as the tape and is then private to this call)."""
         x = data.x
         edge_index = data.edge_index
         edge_attr = data.edge_attr
@@ -245,6 +244,13 @@ class PNAPCSAFT(nn.Module):
                 g = int(batch[-1]) + 1  # sorted by PyG collate; the reference syncs here too (batch.max())
             g = int(g)
         desc = self._model_desc()
+        if tape:
+            if not self.training:
+                raise NotImplementedError("backward is implemented for train-mode BatchNorm only (model.train())")
+            if desc.pre_layers != 1 or desc.post_layers != 1 or desc.hidden % 64 != 0 or desc.num_para > 8:
+                raise NotImplementedError("backward supports pre_layers == post_layers == 1, hidden_dim % 64 == 0 "
+                                          "(the reference's shipped default); run other shapes under torch.no_grad()")
+            desc.save_tape, desc.fold_degree_scalers, desc.fold_dst_term = 1, 1, 0
         if x.shape[1] != desc.num_atom_cols or edge_attr.shape[1] != desc.num_bond_cols:
             raise ValueError("x / edge_attr column counts do not match the embedding tables")
         if self.training and (n < 2 or g < 2):
@@ -253,7 +259,6 @@ class PNAPCSAFT(nn.Module):
         for t in weights:
             if t.device != dev or not t.is_contiguous():
                 raise RuntimeError("all parameters and buffers must be contiguous and on the input's device")
-        for t in weights:
             if t.dtype not in (torch.float32, torch.int64):
                 raise NotImplementedError("only float32 parameters are supported on the MI355X path "
                                           "(fp64 callers such as evaluate_ensemble.py:68 are out of scope)")
@@ -265,10 +270,14 @@ class PNAPCSAFT(nn.Module):
         need = lib.gnnsaft_forward_workspace_bytes(ctypes.byref(desc), n, e, g)
         if need == 0:
             raise _native.GnnsaftError("configuration outside the supported shape envelope")
-        if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need:
-            self._workspace = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=dev)
+        if tape:
+            ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+        else:
+            if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need + 256:
+                self._workspace = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=dev)
+            ws = self._workspace
+        if self._err_flag is None or self._err_flag.device != dev:
             self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
-            self._loss_buf = torch.zeros(3, dtype=torch.float32, device=dev)
         self._err_flag.zero_()
         out = torch.empty((g, desc.num_para), dtype=torch.float32, device=dev)
         tgt_ptr, loss_ptr, loss = None, None, None
@@ -279,21 +288,57 @@ class PNAPCSAFT(nn.Module):
             loss = torch.empty(3, dtype=torch.float32, device=dev)
             tgt_ptr, loss_ptr = target.data_ptr(), loss.data_ptr()
         stream = torch.cuda.current_stream(dev).cuda_stream
-        ws = self._workspace
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        ws_bytes = ws.numel() - (ws_ptr - ws.data_ptr())
         with torch.cuda.device(dev):
             rc = lib.gnnsaft_forward(ctypes.byref(desc), wtab, nw, x.data_ptr(), edge_index.data_ptr() if e else None,
                                      edge_attr.data_ptr() if e else None,
                                      None if batch is None else batch.data_ptr(), n, e, g, tgt_ptr, out.data_ptr(),
-                                     loss_ptr, self._err_flag.data_ptr(), ws_ptr,
-                                     ws.numel() - (ws_ptr - ws.data_ptr()), self._profile, stream)
+                                     loss_ptr, self._err_flag.data_ptr(), ws_ptr, ws_bytes, self._profile, stream)
         check(rc, "gnnsaft_forward")
+        ctx = None
+        if tape:
+            ctx = dict(desc=desc, weights=weights, x=x, batch=batch, n=n, e=e, g=g, ws=ws, ws_ptr=ws_ptr,
+                       ws_bytes=ws_bytes, dev=dev)
+        return out, loss, ctx
+
+    def _backward(self, ctx, grad_out: torch.Tensor):
+        """gnnsaft_backward: gradients of every float parameter of the weight table (None for buffers)."""
+        desc, weights, dev = ctx["desc"], ctx["weights"], ctx["dev"]
+        nw = len(weights)
+        grads = [torch.empty_like(t) if (t.dtype == torch.float32 and isinstance(t, nn.Parameter)) else None
+                 for t in weights]
+        wtab = (ctypes.c_void_p * nw)(*[t.data_ptr() for t in weights])
+        gtab = (ctypes.c_void_p * nw)(*[None if g is None else g.data_ptr() for g in grads])
+        need = lib.gnnsaft_backward_scratch_bytes(ctypes.byref(desc), ctx["n"], ctx["e"], ctx["g"])
+        scratch = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+        sp = (scratch.data_ptr() + 255) // 256 * 256
+        grad_out = grad_out.to(torch.float32).contiguous()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            rc = lib.gnnsaft_backward(ctypes.byref(desc), wtab, gtab, nw, ctx["x"].data_ptr(),
+                                      None if ctx["batch"] is None else ctx["batch"].data_ptr(), ctx["n"], ctx["e"],
+                                      ctx["g"], grad_out.data_ptr(), ctx["ws_ptr"], ctx["ws_bytes"], sp,
+                                      scratch.numel() - (sp - scratch.data_ptr()), stream)
+        check(rc, "gnnsaft_backward")
+        return grads
+
+    def run(self, data, target: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """Forward (+ MAPE loss when ``target`` [G,P] is given) WITHOUT autograd.  Returns
+        ``(pred [G,P], loss3)`` with ``loss3 = [mape, sum(ape), numel]`` on device."""
+        if self._needs_grad():
+            raise RuntimeError("run() is the no-grad entry point; call the module (forward) to build a graph, or "
+                               "wrap the call in torch.no_grad()")
+        out, loss, _ = self._launch(data, target, tape=False)
         return out, loss
 
     def forward(self, data) -> torch.Tensor:
         """models.py:105-135.  ``data``: anything with ``x``, ``edge_index``, ``edge_attr`` and optionally
         ``batch`` / ``num_graphs`` attributes (PyG ``Data`` / ``Batch``)."""
-        return self.run(data)[0]
+        if self._needs_grad():
+            params = [p for p in self.parameters() if p.requires_grad]
+            return _PNAForwardFunction.apply(self, data, *params)
+        return self._launch(data, None, tape=False)[0]
 
     def input_error_flags(self) -> int:
         """Synchronises and returns the OR of GNNSAFT_FLAG_* bits raised by the last forward
@@ -303,6 +348,55 @@ class PNAPCSAFT(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         self._workspace = None
         return super()._apply(fn, *args, **kwargs)
+
+
+class _PNAForwardFunction(torch.autograd.Function):
+    """Autograd node of the whole network: forward = gnnsaft_forward (tape kept), backward = gnnsaft_backward."""
+
+    @staticmethod
+    def forward(ctx, module, data, *params):
+        out, _, tape = module._launch(data, None, tape=True)
+        ctx.module, ctx.tape, ctx.params = module, tape, params
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        grads = ctx.module._backward(ctx.tape, grad_out)
+        by_id = {id(w): g for w, g in zip(ctx.tape["weights"], grads)}
+        ctx.tape = None  # the tape (workspace) can be freed now
+        return (None, None) + tuple(by_id.get(id(p)) for p in ctx.params)
+
+
+class _MapeFunction(torch.autograd.Function):
+    """torchmetrics MAPE (models.py:194) with its gradient: gnnsaft_mape / gnnsaft_mape_backward."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred = pred.contiguous()
+        target = target.reshape(pred.shape).to(torch.float32).contiguous()
+        out3 = torch.empty(3, dtype=torch.float32, device=pred.device)
+        stream = torch.cuda.current_stream(pred.device).cuda_stream
+        check(lib.gnnsaft_mape(pred.data_ptr(), target.data_ptr(), pred.numel(), out3.data_ptr(), stream),
+              "gnnsaft_mape")
+        ctx.save_for_backward(pred, target)
+        return out3[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dloss):
+        pred, target = ctx.saved_tensors
+        dpred = torch.empty_like(pred)
+        dloss = dloss.to(torch.float32).contiguous()
+        stream = torch.cuda.current_stream(pred.device).cuda_stream
+        check(lib.gnnsaft_mape_backward(pred.data_ptr(), target.data_ptr(), pred.shape[0], pred.shape[1],
+                                        dloss.data_ptr(), dpred.data_ptr(), stream), "gnnsaft_mape_backward")
+        return dpred, None
+
+
+def mape_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """mean(|pred - target| / max(|target|, 1.17e-6)) on the device, differentiable w.r.t. ``pred``."""
+    return _MapeFunction.apply(pred, target)
 
 
 class PNApcsaftL(nn.Module):
@@ -321,7 +415,10 @@ class PNApcsaftL(nn.Module):
 
     def training_step(self, graphs, batch_idx=None) -> torch.Tensor:
         """target = graphs.para.view(-1, num_para); returns mean |pred - target| / max(|target|, 1.17e-6)."""
-        _, loss = self.model.run(graphs, target=graphs.para.view(-1, _cfg(self.config, "num_para")))
+        target = graphs.para.view(-1, _cfg(self.config, "num_para"))
+        if self.model._needs_grad():   # builds the autograd graph: loss.backward() runs gnnsaft_backward
+            return mape_loss(self.model(graphs), target)
+        _, loss = self.model.run(graphs, target=target)
         return loss[0]
 
     def training_step_parts(self, graphs) -> torch.Tensor:

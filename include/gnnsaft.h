@@ -324,6 +324,35 @@ int gnnsaft_forward(const gnnsaft_model_desc *desc,
                     void *workspace, size_t workspace_bytes, gnnsaft_profile *profile /* or NULL */,
                     gnnsaft_stream_t stream);
 
+/* ------------------------------------------------------------------------ */
+/* Backward of the path (what autograd does when Lightning calls               */
+/* loss.backward() after training_step, models.py:191-202).  Run               */
+/* gnnsaft_forward with desc->save_tape = 1, training = 1, fold_degree_scalers  */
+/* = 1, fold_dst_term = 0 and keep its workspace (`tape`) untouched; then      */
+/* gnnsaft_backward writes dL/dparam for EVERY parameter into `grads_host`      */
+/* (HOST array of device pointers, same order and shapes as `weights_host`;     */
+/* entries of buffers -- avg_deg_log, running statistics, counters -- are       */
+/* ignored and may be NULL) given grad_out = dL/d(forward output) [G,P].        */
+/* Supported: pre_layers == post_layers == 1, hidden % 64 == 0.                 */
+/* ------------------------------------------------------------------------ */
+size_t gnnsaft_backward_scratch_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes,
+                                      int64_t num_edges, int64_t num_graphs);
+int gnnsaft_backward(const gnnsaft_model_desc *desc, const void *const *weights_host,
+                     void *const *grads_host, int32_t num_weights, const int64_t *x,
+                     const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
+                     const float *grad_out, void *tape, size_t tape_bytes, void *scratch,
+                     size_t scratch_bytes, gnnsaft_stream_t stream);
+/* d(MAPE)/d(pred) * dloss[0] (dloss NULL => 1): sign(p-t) / max(|t|,1.17e-6) / (G*P) */
+int gnnsaft_mape_backward(const float *pred, const float *target, int64_t num_graphs,
+                          int32_t num_para, const float *dloss, float *dpred,
+                          gnnsaft_stream_t stream);
+/* dW[n_out,k] (+)= dY^T A (deterministic slab reduction), dbias (+)= column sums of dY  */
+size_t gnnsaft_wgrad_scratch_bytes(int64_t m, int32_t n_out, int32_t k);
+int gnnsaft_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t lda, int32_t relu_a,
+                         int64_t m, int32_t n_out, int32_t k, float *dw, int64_t ld_dw,
+                         int32_t accumulate, float *dbias, void *scratch, size_t scratch_bytes,
+                         gnnsaft_stream_t stream);
+
 /* Debug / test taps: after gnnsaft_forward, byte offsets of intermediate      */
 /* tensors inside the workspace (node state after each layer etc.).            */
 typedef struct gnnsaft_workspace_map {

@@ -224,7 +224,7 @@ def test_cpu_tensors_and_autograd_fail_loudly():
         with torch.no_grad():
             hip(ethanol_heavy())                 # CPU batch: no fallback
     with pytest.raises(NotImplementedError):
-        hip(ethanol_heavy().to(DEV))             # grad mode: backward not implemented
+        hip(ethanol_heavy().to(DEV))             # grad mode in eval(): only train-mode BatchNorm has a backward
 
 
 @pytest.mark.parametrize("config_id", [2, 3])
