@@ -77,6 +77,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph (1) or launch eagerly (0)")
+    ap.add_argument("--train-steps", type=int, default=20, help="extra forward+backward steps timed (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -183,6 +184,41 @@ def main() -> None:
         model.model._profile = None
         final_loss = last if last is not None else loss
 
+    # ---- secondary measurement: a training step WITH backward (gnnsaft_backward), eager; for N > 1 followed by
+    # the single flat RCCL all-reduce of the gradients (what DDP does for the reference, train.py:142-145)
+    train = None
+    if args.train_steps > 0:
+        from gnn_epc_saft_amd.train.models import mape_loss
+        reducer = parallel.FlatGradientAllReduce(model.parameters()) if world > 1 else None
+        tgt = ddev.para.view(-1, 3)
+
+        def train_step():
+            for prm in model.parameters():
+                prm.grad = None
+            loss_t = mape_loss(model.model(ddev), tgt)
+            loss_t.backward()
+            if reducer is not None:
+                reducer()
+            return loss_t
+
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                train_step()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(args.train_steps):
+                train_step()
+            barrier()
+            el = time.perf_counter() - t2
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt[0])
+        train = {"what": "forward + MAPE + backward (all parameter gradients)" +
+                         (" + flat gradient all-reduce (RCCL)" if world > 1 else "") + ", eager, no optimizer step",
+                 "steps": args.train_steps, "ms_per_step": el / args.train_steps * 1e3,
+                 "graphs_per_s": cfg["graphs"] * world * args.train_steps / el}
+
     def kernel_ms(bit):
         cnt, tot = ctypes.c_int32(), ctypes.c_float()
         _native.check(_native.lib.gnnsaft_profile_summary(handle, bit, ctypes.byref(cnt), ctypes.byref(tot)),
@@ -250,6 +286,7 @@ def main() -> None:
             "eager_ms_per_step": elapsed_eager / args.steps * 1e3,
             "instrumented_ms_per_step": elapsed_instr / args.steps * 1e3,
             "final_loss": float(final_loss),
+            "train_step": train,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, data, deg, args.cpu_budget)

@@ -250,36 +250,47 @@ __global__ __launch_bounds__(256) void k_gather_rows_sum(const int32_t *__restri
   gs_st4(dpq + node * (int64_t)(4 * f) + 2 * f + c, acc);
 }
 
-// dr[class, :] += dm[row, :]: LDS accumulators per workgroup, then one global atomic per (class, column)
-__global__ __launch_bounds__(256) void k_class_reduce(const int32_t *__restrict__ combo, const float *__restrict__ dm,
-                                                      int64_t rows, int64_t rows_per_block, int classes, int f,
-                                                      float *__restrict__ dr) {
-  extern __shared__ float acc[];  // [classes][2F]
-  const int width = 2 * f;
-  for (int i = threadIdx.x; i < classes * width; i += blockDim.x) acc[i] = 0.f;
-  __syncthreads();
-  const int64_t r_beg = (int64_t)blockIdx.x * rows_per_block;
-  int64_t r_end = r_beg + rows_per_block;
+// dr[class, :] = sum of dm[row, :] over the rows of that edge class.  `rows_c` lists the CSR rows grouped by
+// class (built once per backward); a thread owns a float4 column slice of a 32-row chunk of that list, keeps a
+// running sum while the class stays the same and flushes with one atomic add per class change (chunks hold
+// one or two classes), so the 60-row table is not hammered.
+__global__ __launch_bounds__(256) void k_class_reduce(const int32_t *__restrict__ rows_c,
+                                                      const int32_t *__restrict__ combo, const float *__restrict__ dm,
+                                                      int64_t rows, int classes, int f, float *__restrict__ dr,
+                                                      RowSplit rs) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t chunk;
+  int lane;
+  gs_split(rs, slot, chunk, lane);
+  const int64_t r_beg = chunk * 32;
+  if (r_beg >= rows) return;
+  int64_t r_end = r_beg + 32;
   if (r_end > rows) r_end = rows;
-  const int per_row = width / 4;            // threads per row
-  const int rows_at_once = blockDim.x / per_row > 0 ? blockDim.x / per_row : 1;
-  const int rl = threadIdx.x / per_row, c = (threadIdx.x % per_row) * 4;
-  if (rl < rows_at_once) {
-    for (int64_t r = r_beg + rl; r < r_end; r += rows_at_once) {
-      const int cls = combo[r];
-      if (cls < 0 || cls >= classes) continue;
-      const f32x4 v = gs_ld4(dm + r * width + c);
-      float *a = acc + cls * width + c;
-      atomicAdd(a + 0, v.x);
-      atomicAdd(a + 1, v.y);
-      atomicAdd(a + 2, v.z);
-      atomicAdd(a + 3, v.w);
+  const int c = lane * 4, width = 2 * f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int cur = -1;
+  for (int64_t i = r_beg; i < r_end; ++i) {
+    const int r = rows_c[i];
+    const int cls = combo[r];
+    if (cls != cur) {
+      if (cur >= 0 && cur < classes) {
+        float *o = dr + (int64_t)cur * width + c;
+        atomicAdd(o + 0, acc.x);
+        atomicAdd(o + 1, acc.y);
+        atomicAdd(o + 2, acc.z);
+        atomicAdd(o + 3, acc.w);
+      }
+      acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      cur = cls;
     }
+    acc += gs_ld4(dm + (int64_t)r * width + c);
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < classes * width; i += blockDim.x) {
-    const float v = acc[i];
-    if (v != 0.f) atomicAdd(dr + i, v);
+  if (cur >= 0 && cur < classes) {
+    float *o = dr + (int64_t)cur * width + c;
+    atomicAdd(o + 0, acc.x);
+    atomicAdd(o + 1, acc.y);
+    atomicAdd(o + 2, acc.z);
+    atomicAdd(o + 3, acc.w);
   }
 }
 
@@ -385,7 +396,9 @@ static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
   add(h * 2 * h * 4);                                    // wcT
   add((nn + 1) * 4);                                     // rowptr_s
   add(ee * 4);                                           // rows_s
-  add(group_by_key_workspace_bytes(p.n));
+  add((size_t)(p.combos + 1) * 4);                        // rowptr_c
+  add(ee * 4);                                           // rows_c
+  add(group_by_key_workspace_bytes(p.n > p.combos ? p.n : p.combos));
   add(gg * h * 4 * 3);                                   // readout dcur, dnext, dyr
   add(gg * 8 * 4);                                       // padded dout
   add(h * 8 * 4);                                        // padded W3^T
@@ -458,7 +471,9 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   float *wcT = sc.take<float>((size_t)h * 2 * h);
   int32_t *rowptr_s = sc.take<int32_t>(n + 1);
   int32_t *rows_s = sc.take<int32_t>(p.ep > 0 ? p.ep : 1);
-  char *grp_ws = sc.take<char>(group_by_key_workspace_bytes(n));
+  int32_t *rowptr_c = sc.take<int32_t>(C + 1);
+  int32_t *rows_c = sc.take<int32_t>(p.ep > 0 ? p.ep : 1);
+  char *grp_ws = sc.take<char>(group_by_key_workspace_bytes(n > C ? n : C));
   float *dcur = sc.take<float>(g * h), *dnext = sc.take<float>(g * h), *dyr = sc.take<float>(g * h);
   float *dout_pad = sc.take<float>(g * 8);
   float *w3T = sc.take<float>((size_t)h * 8);
@@ -521,7 +536,10 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
                      I(p.graph_ptr), g, n, h, dx, gs_row_split(h / 4));
 
   // =========================== transposed CSR (rows grouped by source) ===========================
-  GS_TRY(launch_group_by_key(I(p.src), p.ep, n, rowptr_s, rows_s, grp_ws, group_by_key_workspace_bytes(n), st));
+  GS_TRY(launch_group_by_key(I(p.src), p.ep, n, rowptr_s, rows_s, grp_ws, group_by_key_workspace_bytes(n), 1, st));
+  // ... and grouped by edge class (for the edge-table gradient)
+  GS_TRY(launch_group_by_key(I(p.combo), p.ep, C, rowptr_c, rows_c, grp_ws, group_by_key_workspace_bytes(n > C ? n : C),
+                             0, st));
 
   hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * h, 256)), dim3(256), 0, st, dcemb, C * h);
 
@@ -574,16 +592,8 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     hipLaunchKernelGGL(k_gather_rows_sum, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, rowptr_s,
                        rows_s, dm, dpq, n, h, gs_row_split(h / 2));
     hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * 2 * h, 256)), dim3(256), 0, st, dr, C * 2 * h);
-    {
-      const size_t lds = (size_t)C * 2 * h * 4;
-      GS_REQUIRE(lds <= 160 * 1024 - 1024, GNNSAFT_ERR_UNSUPPORTED);
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_class_reduce),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      const int64_t rpb = 512;
-      hipLaunchKernelGGL(k_class_reduce, dim3((unsigned)gs_ceil_div(p.ep, rpb)), dim3(256), lds, st, I(p.combo), dm,
-                         p.ep, rpb, (int)C, h, dr);
-    }
+    hipLaunchKernelGGL(k_class_reduce, dim3((unsigned)gs_ceil_div(gs_ceil_div(p.ep, 32) * (h / 2), 256)), dim3(256),
+                       0, st, rows_c, I(p.combo), dm, p.ep, (int)C, h, dr, gs_row_split(h / 2));
     // message GEMMs: dx_in += [dP | dQ] W_pq ; dW_dst,t / dW_src,t = dP_t^T x / dQ_t^T x
     {
       const float *ins[4] = {w.wpre[0][0], w.wpre[1][0], w.wpre[0][0] + h, w.wpre[1][0] + h};

@@ -123,7 +123,7 @@ int launch_colsum(const float *a, int64_t lda, int64_t m, int cols, float *out, 
                   size_t partial_bytes, hipStream_t st);
 size_t group_by_key_workspace_bytes(int64_t num_keys);
 int launch_group_by_key(const int32_t *keys, int64_t count, int64_t num_keys, int32_t *rowptr, int32_t *rows,
-                        void *workspace, size_t workspace_bytes, hipStream_t st);
+                        void *workspace, size_t workspace_bytes, int sort_segments, hipStream_t st);
 
 constexpr int kDegreeBuckets = 32;  // folded update: exact in-degree buckets 0..31
 

@@ -191,19 +191,37 @@ __global__ void k_batch_to_ptr(const int64_t *__restrict__ batch, int64_t n, int
 __global__ void k_count_keys(const int32_t *__restrict__ keys, int64_t count, int64_t num_keys,
                              int32_t *__restrict__ counts) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const int32_t k = keys[i];
-  if (k >= 0 && k < num_keys) atomicAdd(&counts[k], 1);
+  const int32_t k = i < count ? keys[i] : -1;
+  const bool live = k >= 0 && k < num_keys;
+  // one atomic per (wave, distinct key): a few hot keys (edge classes) would otherwise serialise
+  unsigned long long todo = __ballot(live);
+  while (todo != 0ull) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int kl = __shfl(k, leader);
+    const unsigned long long same = __ballot(live && k == kl);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&counts[kl], __popcll(same));
+    todo &= ~same;
+  }
 }
 
 __global__ void k_fill_by_key(const int32_t *__restrict__ keys, int64_t count, int64_t num_keys,
                               const int32_t *__restrict__ rowptr, int32_t *__restrict__ cursor,
                               int32_t *__restrict__ rows) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const int32_t k = keys[i];
-  if (k < 0 || k >= num_keys) return;
-  rows[rowptr[k] + atomicAdd(&cursor[k], 1)] = (int32_t)i;
+  const int32_t k = i < count ? keys[i] : -1;
+  const bool live = k >= 0 && k < num_keys;
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(live);
+  while (todo != 0ull) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int kl = __shfl(k, leader);
+    const unsigned long long same = __ballot(live && k == kl);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&cursor[kl], __popcll(same));
+    base = __shfl(base, leader);
+    if (live && k == kl) rows[rowptr[kl] + base + __popcll(same & ((1ull << lane) - 1ull))] = (int32_t)i;
+    todo &= ~same;
+  }
 }
 
 __global__ void k_sort_segments(const int32_t *__restrict__ rowptr, int64_t num_keys, int32_t *__restrict__ rows) {
@@ -227,7 +245,7 @@ size_t group_by_key_workspace_bytes(int64_t num_keys) {
 }
 
 int launch_group_by_key(const int32_t *keys, int64_t count, int64_t num_keys, int32_t *rowptr, int32_t *rows,
-                        void *workspace, size_t workspace_bytes, hipStream_t st) {
+                        void *workspace, size_t workspace_bytes, int sort_segments, hipStream_t st) {
   GS_REQUIRE(keys && rowptr && rows && workspace, GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_keys >= 1 && count >= 0, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(workspace_bytes >= group_by_key_workspace_bytes(num_keys), GNNSAFT_ERR_WORKSPACE);
@@ -249,8 +267,10 @@ int launch_group_by_key(const int32_t *keys, int64_t count, int64_t num_keys, in
   if (count > 0) {
     hipLaunchKernelGGL(k_fill_by_key, dim3((unsigned)gs_ceil_div(count, 256)), dim3(256), 0, st, keys, count, num_keys,
                        rowptr, cursor, rows);
-    hipLaunchKernelGGL(k_sort_segments, dim3((unsigned)gs_ceil_div(num_keys, 256)), dim3(256), 0, st, rowptr, num_keys,
-                       rows);
+    // insertion sort per segment: only for short segments (node degrees), never for the few huge edge classes
+    if (sort_segments)
+      hipLaunchKernelGGL(k_sort_segments, dim3((unsigned)gs_ceil_div(num_keys, 256)), dim3(256), 0, st, rowptr,
+                         num_keys, rows);
   }
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;

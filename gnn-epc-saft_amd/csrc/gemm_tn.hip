@@ -17,7 +17,7 @@
 
 namespace gs {
 
-constexpr int kTnChunk = 1024;  // rows per slab
+constexpr int kTnChunk = 256;   // rows per slab (small: the output tiles alone cannot fill 256 CUs)
 constexpr int kTnBK = 32;       // rows per LDS stage
 constexpr int kTnTile = 64;     // output tile (n and k)
 constexpr int kTnLd = kTnTile + 4;
@@ -80,14 +80,14 @@ struct TnOneHot {
 
 template <class AProv>
 __global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dy, int64_t ldy, AProv ap, int64_t m,
-                                                 int n_out, int k, float *__restrict__ slabs) {
+                                                 int n_out, int k, float *__restrict__ slabs, int64_t rows_per_z) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kTnBK * kTnLd];  // [buf][dy | a][32][68]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;  // 2 x 2 waves, 32 x 32 each
   const int n0 = blockIdx.y * kTnTile, k0 = blockIdx.x * kTnTile;
-  const int64_t m_beg = (int64_t)blockIdx.z * kTnChunk;
-  int64_t m_end = m_beg + kTnChunk;
+  const int64_t m_beg = (int64_t)blockIdx.z * rows_per_z;
+  int64_t m_end = m_beg + rows_per_z;
   if (m_end > m) m_end = m;
 
   // staging: 32 rows x 16 float4; thread -> (row tid>>4 (+16), float4 column tid&15)
@@ -149,13 +149,20 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dy, i
   }
 }
 
-// out[i] (+)= sum over chunks of slabs[c][i]; fixed chunk order
+// out[i] (+)= sum over the slabs; 8 slab lanes per output float4, combined in a fixed order
 __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ slabs, int64_t per_slab, int64_t chunks,
                                                    float *__restrict__ out, int64_t ld_out, int cols, int accumulate) {
-  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i4 >= per_slab) return;
+  __shared__ f32x4 red[8][32];
+  const int il = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t i4 = ((int64_t)blockIdx.x * 32 + il) * 4;
+  const bool ok = i4 < per_slab;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t c = 0; c < chunks; ++c) s += gs_ld4(slabs + c * per_slab + i4);
+  if (ok)
+    for (int64_t c = sl; c < chunks; c += 8) s += gs_ld4(slabs + c * per_slab + i4);
+  red[sl][il] = s;
+  __syncthreads();
+  if (sl != 0 || !ok) return;
+  for (int o = 1; o < 8; ++o) s += red[o][il];
   const int64_t r = i4 / cols, cc = i4 - r * cols;  // slab is dense [rows, cols]; out may be a column block
   float *o = out + r * ld_out + cc;
   if (accumulate) s += gs_ld4(o);
@@ -189,17 +196,26 @@ __global__ __launch_bounds__(256) void k_transpose(TransposeBatch tb, int rows, 
   }
 }
 
-// column sums (bias gradients): partial[chunk][col] then fixed-order sum
+// column sums (bias gradients): partial[chunk][col] then fixed-order sum.  32 columns x 8 row lanes per
+// workgroup, kColChunk rows per chunk.
+constexpr int kColChunk = 1024;
 __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ a, int64_t lda, int64_t m, int cols,
                                                         float *__restrict__ partial) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  const int64_t m_beg = (int64_t)blockIdx.y * kTnChunk;
-  int64_t m_end = m_beg + kTnChunk;
+  __shared__ double red[8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int cc = c < cols ? c : cols - 1;
+  const int64_t m_beg = (int64_t)blockIdx.y * kColChunk;
+  int64_t m_end = m_beg + kColChunk;
   if (m_end > m) m_end = m;
   double s = 0.0;  // bias gradients in front of a train-mode BatchNorm are exactly zero: keep the sum exact
-  for (int64_t r = m_beg; r < m_end; ++r) s += (double)a[r * lda + c];
-  partial[(int64_t)blockIdx.y * cols + c] = (float)s;
+  for (int64_t r = m_beg + rl; r < m_end; r += 8) s += (double)a[r * lda + cc];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    for (int o = 1; o < 8; ++o) s += red[o][cl];
+    partial[(int64_t)blockIdx.y * cols + c] = (float)s;
+  }
 }
 __global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ partial, int64_t chunks, int cols,
                                                       float *__restrict__ out, int accumulate) {
@@ -216,12 +232,19 @@ static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, i
   GS_REQUIRE(dy && out && slabs, GNNSAFT_ERR_NULL);
   GS_REQUIRE(m >= 1 && n_out >= 1 && k >= 4 && (k % 4) == 0 && (ldy % 4) == 0 && (ld_out % 4) == 0,
              GNNSAFT_ERR_SHAPE);
-  const int64_t chunks = gs_ceil_div(m, kTnChunk);
+  // number of row slabs: enough workgroups to fill the chip (~1024), never finer than kTnChunk rows
+  const int64_t tiles = gs_ceil_div(k, kTnTile) * gs_ceil_div(n_out, kTnTile);
+  int64_t chunks = gs_ceil_div(1024, tiles);
+  const int64_t max_chunks = gs_ceil_div(m, kTnChunk);
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  int64_t rows_per_z = gs_ceil_div(gs_ceil_div(m, chunks), kTnBK) * kTnBK;
+  chunks = gs_ceil_div(m, rows_per_z);
   GS_REQUIRE(slab_bytes >= (size_t)chunks * n_out * k * 4, GNNSAFT_ERR_WORKSPACE);
   const dim3 grid((unsigned)gs_ceil_div(k, kTnTile), (unsigned)gs_ceil_div(n_out, kTnTile), (unsigned)chunks);
-  hipLaunchKernelGGL((k_gemm_tn<AProv>), grid, dim3(256), 0, st, dy, ldy, ap, m, n_out, k, slabs);
+  hipLaunchKernelGGL((k_gemm_tn<AProv>), grid, dim3(256), 0, st, dy, ldy, ap, m, n_out, k, slabs, rows_per_z);
   const int64_t per_slab = (int64_t)n_out * k;
-  hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)gs_ceil_div(per_slab / 4, 256)), dim3(256), 0, st, slabs, per_slab,
+  hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)gs_ceil_div(per_slab / 4, 32)), dim3(256), 0, st, slabs, per_slab,
                      chunks, out, ld_out, k, accumulate);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
@@ -286,9 +309,9 @@ int launch_transpose(int count, const float *const *in, float *const *out, const
 int launch_colsum(const float *a, int64_t lda, int64_t m, int cols, float *out, int accumulate, float *partial,
                   size_t partial_bytes, hipStream_t st) {
   GS_REQUIRE(a && out && partial, GNNSAFT_ERR_NULL);
-  const int64_t chunks = gs_ceil_div(m > 0 ? m : 1, kTnChunk);
+  const int64_t chunks = gs_ceil_div(m > 0 ? m : 1, kColChunk);
   GS_REQUIRE(partial_bytes >= (size_t)chunks * cols * 4, GNNSAFT_ERR_WORKSPACE);
-  hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)gs_ceil_div(cols, 256), (unsigned)chunks), dim3(256), 0, st, a,
+  hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)gs_ceil_div(cols, 32), (unsigned)chunks), dim3(256), 0, st, a,
                      lda, m, cols, partial);
   hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)gs_ceil_div(cols, 256)), dim3(256), 0, st, partial, chunks, cols,
                      out, accumulate);

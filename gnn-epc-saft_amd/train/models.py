@@ -306,8 +306,13 @@ class PNAPCSAFT(nn.Module):
         """gnnsaft_backward: gradients of every float parameter of the weight table (None for buffers)."""
         desc, weights, dev = ctx["desc"], ctx["weights"], ctx["dev"]
         nw = len(weights)
-        grads = [torch.empty_like(t) if (t.dtype == torch.float32 and isinstance(t, nn.Parameter)) else None
-                 for t in weights]
+        # one flat buffer, gradients are views into it (one allocation; also the layout a flat all-reduce wants)
+        sizes = [t.numel() if (t.dtype == torch.float32 and isinstance(t, nn.Parameter)) else 0 for t in weights]
+        flat = torch.empty(sum((s + 63) // 64 * 64 for s in sizes), dtype=torch.float32, device=dev)
+        grads, off = [], 0
+        for t, sz in zip(weights, sizes):
+            grads.append(flat[off:off + sz].view(t.shape) if sz else None)
+            off += (sz + 63) // 64 * 64
         wtab = (ctypes.c_void_p * nw)(*[t.data_ptr() for t in weights])
         gtab = (ctypes.c_void_p * nw)(*[None if g is None else g.data_ptr() for g in grads])
         need = lib.gnnsaft_backward_scratch_bytes(ctypes.byref(desc), ctx["n"], ctx["e"], ctx["g"])

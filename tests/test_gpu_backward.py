@@ -169,3 +169,35 @@ def test_unsupported_shapes_fail_loudly_in_grad_mode():
         hip(data.to(DEV))
     with torch.no_grad():
         assert hip(data.to(DEV)).shape == (8, 3)
+
+
+def test_min_max_ties_split_the_gradient_evenly():
+    """Duplicate edges give bit-identical messages, i.e. ties in the min / max aggregators: torch's
+    scatter_reduce backward distributes the gradient evenly among the tied elements, and so must k_agg_bwd."""
+    from gnn_epc_saft_amd.data.synthetic import GraphData, degree_histogram, make_synthetic_batch
+    from gnn_epc_saft_amd.train.models import mape_loss
+    for attempt in range(16):
+        base = make_synthetic_batch(24, 4242 + attempt, num_para=3)
+        e = base.edge_index.shape[1]
+        dup = torch.arange(0, e, 7)                                    # every 7th directed edge twice
+        data = GraphData(base.x, torch.cat([base.edge_index, base.edge_index[:, dup]], dim=1),
+                         torch.cat([base.edge_attr, base.edge_attr[dup]]), base.batch, base.ptr, base.para,
+                         base.num_graphs)
+        oracle = oracle_model(64, 2, 1, 1, 1, 3, True, True, degree_histogram(base), seed=3).train()
+        with torch.no_grad():
+            want64 = copy.deepcopy(oracle).double()(data)
+            probe = hip_twin(copy.deepcopy(oracle))
+            probe.fold_dst_term = False
+            got = probe(data.to(DEV)).cpu()
+        if float((got.double() - want64).abs().max()) <= 1e-5 * float(want64.abs().max()):
+            break
+    else:
+        pytest.skip("no flip-free batch found")
+    loss64, g64 = grads_of(oracle, data, 3, torch.float64)
+    hip = hip_twin(copy.deepcopy(oracle))
+    dd = data.to(DEV)
+    mape_loss(hip(dd), dd.para.view(-1, 3)).backward()
+    gscale = max(float(g.abs().max()) for g in g64.values())
+    for name, p in hip.named_parameters():
+        scale = max(float(g64[name].abs().max()), 1e-3 * gscale)
+        assert float((p.grad.double().cpu() - g64[name]).abs().max()) / scale < 2e-4, name
