@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
                                                         float momentum, float eps,
                                                         const float *__restrict__ residual, float *__restrict__ out,
                                                         int64_t rows_per_chunk, float *__restrict__ save_stat) {
-  __shared__ double s_n[kBnGroupLanes][kBnCols], s_mean[kBnGroupLanes][kBnCols], s_m2[kBnGroupLanes][kBnCols];
+  __shared__ double s_mean[kBnGroupLanes][kBnCols], s_m2[kBnGroupLanes][kBnCols];
   __shared__ float s_scale[kBnCols], s_shift[kBnCols];
   const int c0 = blockIdx.x * kBnCols;
   const int cl = threadIdx.x & (kBnCols - 1);
@@ -32,8 +32,14 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
 
   // ---- phase 1: batch statistics of this slab's columns
   const int64_t groups = (rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  constexpr int kUnroll = 8;  // independent loads in flight per thread (the combine itself is a serial chain)
+  // Division-free combine around a pivot K = mean of group 0 (any value near the column mean):
+  //   S1 = sum n_g (mean_g - K),  S2 = sum (M2_g + n_g (mean_g - K)^2)   in f64
+  //   mean = K + S1/N,  M2 = S2 - N (S1/N)^2
+  // The differences are of the size of the between-group scatter, so the final subtraction is benign even
+  // for columns with |mean| >> std (the case Chan's pairwise update protects against).
+  const double pivot = (double)stats[colc];
+  double s1 = 0.0, s2 = 0.0;
+  constexpr int kUnroll = 8;  // independent loads in flight per thread
   for (int64_t g0 = gl; g0 < groups; g0 += kBnGroupLanes * kUnroll) {
     float gm[kUnroll], g2[kUnroll];
 #pragma unroll
@@ -49,30 +55,25 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
       if (g < groups) {
         const int64_t left = rows - g * kBnRowsPerGroup;
         const double gn = (double)(left < kBnRowsPerGroup ? left : kBnRowsPerGroup);
-        const double tot = n + gn;
-        const double w = gn / tot;
-        const double delta = (double)gm[u] - mean;
-        mean += delta * w;
-        m2 += (double)g2[u] + delta * delta * (n * w);
-        n = tot;
+        const double m = (double)gm[u] - pivot;
+        s1 += gn * m;
+        s2 += (double)g2[u] + gn * m * m;
       }
     }
   }
-  s_n[gl][cl] = n;
-  s_mean[gl][cl] = mean;
-  s_m2[gl][cl] = m2;
+  s_mean[gl][cl] = s1;
+  s_m2[gl][cl] = s2;
   __syncthreads();
   if (gl == 0) {
     for (int o = 1; o < kBnGroupLanes; ++o) {
-      const double nb = s_n[o][cl];
-      const double tot = n + nb;
-      if (tot > 0.0) {
-        const double delta = s_mean[o][cl] - mean;
-        mean += delta * (nb / tot);
-        m2 += s_m2[o][cl] + delta * delta * (n * nb / tot);
-        n = tot;
-      }
+      s1 += s_mean[o][cl];
+      s2 += s_m2[o][cl];
     }
+    const double n = (double)rows;
+    const double dmean = s1 / n;
+    const double mean = pivot + dmean;
+    double m2 = s2 - n * dmean * dmean;
+    m2 = m2 > 0.0 ? m2 : 0.0;
     const float mean_f = (float)mean;
     const float var_f = (float)(m2 / n);  // biased: used for normalisation
     const float rstd = 1.f / sqrtf(var_f + eps);
