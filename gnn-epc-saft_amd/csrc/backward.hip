@@ -435,8 +435,8 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   (void)batch;
   GS_REQUIRE(d && weights_host && grads_host && grad_out && tape && scratch && x_idx, GNNSAFT_ERR_NULL);
   GS_REQUIRE(d->save_tape && d->training, GNNSAFT_ERR_UNSUPPORTED);
-  GS_REQUIRE(d->pre_layers == 1 && d->post_layers == 1 && (d->hidden % 64) == 0 && d->fold_degree_scalers &&
-                 !d->fold_dst_term,
+  GS_REQUIRE(d->pre_layers == 1 && d->post_layers >= 1 && d->post_layers <= 8 && (d->hidden % 64) == 0 &&
+                 d->fold_degree_scalers && !d->fold_dst_term,
              GNNSAFT_ERR_UNSUPPORTED);
   Plan p;
   GS_TRY(make_plan(d, num_nodes, num_edges, num_graphs, p));
@@ -547,26 +547,54 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   for (int l = L - 1; l >= 0; --l) {
     const LayerW &w = pw.layers[l];
     const int base = pw.layer_base[l];
-    // table indices inside the layer: avg 0 | we 1 be 2 | pre0 w3 b4 | pre1 w5 b6 | post0 w7 b8 | post1 w9 b10 |
-    //                                lin w11 b12 | bn gamma 13 beta 14 (running stats 15,16, counter 17)
+    // table indices inside the layer (q = post_layers): avg 0 | we 1 be 2 | pre0 w3 b4 | pre1 w5 b6 |
+    //   post0 (w,b) x q from 7 | post1 (w,b) x q from 7+2q | lin w,b | bn gamma, beta (running stats, counter)
+    const int q = d->post_layers;
+    const int i_post0 = base + 7, i_post1 = base + 7 + 2 * q, i_lin = base + 7 + 4 * q, i_bn = i_lin + 2;
     const float *x_l = F(p.x0) + l * p.sx, *pq_l = F(p.pq) + l * p.spq, *agg_l = F(p.agg) + l * p.sagg;
-    const float *u_l = F(p.u0) + l * p.su, *y_l = F(p.y) + l * p.sy;
+    const float *u_first = F(p.u0) + l * p.su;                        // output of post layer 0
+    const float *u_l = u_first + (int64_t)(q - 1) * n * h;            // output of the last post layer = lin's input
+    const float *y_l = F(p.y) + l * p.sy;
     const float *stat = F(p.bnstat) + (int64_t)l * 2 * h;
     const float *rtab = F(p.rtab) + l * C * (int64_t)(2 * h);
     const float *cenc = F(p.cenc) + l * C * (int64_t)h;
 
     // x_{l+1} = relu(bn(y)) + x_l : dy through BN+ReLU; the skip gradient stays in dx
-    GS_TRY(bn_relu_backward(y_l, dx, stat, w.bn.gamma, w.bn.beta, n, h, G(base + 13), G(base + 14), dy, bnpart, st));
+    GS_TRY(bn_relu_backward(y_l, dx, stat, w.bn.gamma, w.bn.beta, n, h, G(i_bn), G(i_bn + 1), dy, bnpart, st));
     // lin
-    GS_TRY(launch_wgrad_plain(dy, h, u_l, h, 0, n, h, h, G(base + 11), h, 0, slabs, slab_bytes, st));
-    GS_TRY(launch_colsum(dy, h, n, h, G(base + 12), 0, slabs, slab_bytes, st));
+    GS_TRY(launch_wgrad_plain(dy, h, u_l, h, 0, n, h, h, G(i_lin), h, 0, slabs, slab_bytes, st));
+    GS_TRY(launch_colsum(dy, h, n, h, G(i_lin + 1), 0, slabs, slab_bytes, st));
     GS_TRY(transpose1(w.wlin, h, wlinT, h, h, h));
     GS_TRY(dgrad(dy, h, wlinT, h, du, h, n, h, h, nullptr));
+    // extra post layers (Linear(F/2,F/2) after a ReLU, per tower), last to first: du_j -> du_{j-1}
+    for (int j = q - 1; j >= 1; --j) {
+      const float *u_prev = u_first + (int64_t)(j - 1) * n * h;  // pre-ReLU input of post layer j
+      float *du_prev = dy;                                        // dy is free after the lin dgrad
+      for (int t = 0; t < 2; ++t) {
+        const float *wj = w.wpost[t][j];
+        const int iw = (t == 0 ? i_post0 : i_post1) + 2 * j;
+        GS_TRY(launch_wgrad_plain(du + t * (h / 2), h, u_prev + t * (h / 2), h, 1, n, h / 2, h / 2, G(iw), h / 2, 0,
+                                  slabs, slab_bytes, st));
+        GS_TRY(launch_colsum(du + t * (h / 2), h, n, h / 2, G(iw + 1), 0, slabs, slab_bytes, st));
+        GS_TRY(transpose1(wj, h / 2, wlinT, h / 2, h / 2, h / 2));
+        // d(relu input) = (du_t W_j) masked by u_prev > 0
+        GemmBatchEntry e{wlinT, nullptr, du_prev + t * (h / 2), t * (int64_t)(h / 2)};
+        LinearEpilogue epi;
+        epi.residual = u_prev + t * (h / 2);
+        epi.ldr = h;
+        epi.residual_is_mask = 1;
+        GS_TRY(launch_linear(du, h, 0, 1, &e, h / 2, h, n, h / 2, h / 2, epi, st));
+      }
+      float *tsw = du;
+      du = du_prev;
+      dy = tsw;
+    }
     // update wgrad / bias
     for (int t = 0; t < 2; ++t) {
       GS_TRY(launch_wgrad_post(du + t * (h / 2), h, x_l, agg_l + t * 4 * h, F(p.log_amp), F(p.log_att), w.avg, n, h,
-                               G(base + 7 + 2 * t), slabs, slab_bytes, st));
-      GS_TRY(launch_colsum(du + t * (h / 2), h, n, h / 2, G(base + 8 + 2 * t), 0, slabs, slab_bytes, st));
+                               G(t == 0 ? i_post0 : i_post1), slabs, slab_bytes, st));
+      GS_TRY(launch_colsum(du + t * (h / 2), h, n, h / 2, G((t == 0 ? i_post0 : i_post1) + 1), 0, slabs, slab_bytes,
+                           st));
     }
     // update dgrad, x part: dx_in = (skip ? dx : 0) + du [N,F] x [W_x,0 ; W_x,1]
     {

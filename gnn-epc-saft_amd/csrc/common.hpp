@@ -76,6 +76,7 @@ struct LinearEpilogue {
   const float *residual = nullptr;
   int64_t ldr = 0;
   float *stats = nullptr;         // [groups, 2, n_out] (mean, M2) partials
+  int residual_is_mask = 0;       // out = residual > 0 ? v : 0 (ReLU backward) instead of v + residual
 };
 
 int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const GemmBatchEntry *entries,

@@ -18,9 +18,10 @@ constexpr int kScanBlock = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanBlock * kScanItems;  // 2048 counts per workgroup
 
-__global__ void k_zero_i32(int32_t *p, int64_t n) {
+__global__ void k_zero_i32(int32_t *p, int64_t n, int32_t *also = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0;
+  if (i == 0 && also != nullptr) also[0] = 0;
 }
 
 __global__ void k_count_in_degree(const int64_t *__restrict__ edge_index, int64_t n, int64_t e,

@@ -443,6 +443,7 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
       GS_TRY(launch_pna_update(xc, agg_l, F(p.log_amp), F(p.log_att), avg, n, h, e, h, st));
     }
     for (int j = 1; j < d->post_layers; ++j) {
+      if (tape) ub = u_l + (int64_t)j * n * h;  // keep every intermediate for the backward
       GemmBatchEntry e2[2] = {{wpost[0][j], bpost[0][j], ub, 0}, {wpost[1][j], bpost[1][j], ub + h / 2, h / 2}};
       LinearEpilogue epi;
       GS_TRY(launch_linear(ua, h, 1, 2, e2, h / 2, h, n, h / 2, h / 2, epi, st));

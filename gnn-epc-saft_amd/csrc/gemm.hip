@@ -235,6 +235,7 @@ struct EpiArgs {
   const float *residual;
   int64_t ldr;
   float *stats;
+  int residual_is_mask;  // 1: out = residual > 0 ? v : 0 (ReLU backward) instead of v + residual
 };
 
 // --------------------------------------------------------------------------
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
         float v = acc[i][j][r] + bias;
         if (AFFINE) v = v * sc + sh;
         v = epi.relu_out ? fmaxf(v, 0.f) : v;
-        if (RESID) v += res[r];
+        if (RESID) v = epi.residual_is_mask ? (res[r] > 0.f ? v : 0.f) : v + res[r];
         if (lr < ti.count && col_ok) ent.out[grow[r] * ldo + col] = v;
       }
     }
@@ -528,7 +529,7 @@ static int dispatch(const AProv &ap, int nbatch, const GemmBatchEntry *entries, 
     GS_REQUIRE(entries[i].w != nullptr && entries[i].out != nullptr, GNNSAFT_ERR_NULL);
     GS_REQUIRE((reinterpret_cast<uintptr_t>(entries[i].w) & 15) == 0, GNNSAFT_ERR_SHAPE);
   }
-  EpiArgs ea{epi.scale, epi.shift, epi.relu_out, epi.residual, epi.ldr, epi.stats};
+  EpiArgs ea{epi.scale, epi.shift, epi.relu_out, epi.residual, epi.ldr, epi.stats, epi.residual_is_mask};
   GS_REQUIRE((epi.scale == nullptr) == (epi.shift == nullptr), GNNSAFT_ERR_NULL);
   GS_REQUIRE(epi.stats == nullptr || nbatch == 1, GNNSAFT_ERR_SHAPE);
   const bool st = epi.stats != nullptr, af = epi.scale != nullptr, rs = epi.residual != nullptr;
@@ -602,7 +603,7 @@ int launch_pna_update_folded(const float *x, const float *agg, const int32_t *pe
   b.e[0] = GemmBatchEntry{w_eff, b_post0, u, 0};
   b.e[1] = GemmBatchEntry{w_eff + per_tower, b_post1, u + hidden / 2, 4 * (int64_t)hidden};
   for (int i = 2; i < kMaxGemmBatch; ++i) b.e[i] = b.e[0];
-  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr};
+  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
   return launch_cfg<PostFoldA, false, false, false>(ap, 2, b, 5 * (int64_t)hidden, hidden, n, hidden / 2, 5 * hidden,
                                                     ea, stream, tiled_cfg_for(hidden), max_tiles);
 }
@@ -618,7 +619,7 @@ int launch_linear_degree_tiled(const float *a, int64_t lda, const int32_t *perm,
   PermPlainA ap{a, lda, perm, tiles, num_tiles, w_stride, k};
   GemmBatch b;
   for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entries[i < nbatch ? i : 0];
-  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr};
+  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
   return launch_cfg<PermPlainA, false, false, false>(ap, nbatch, b, ldw, ldo, n, n_out, k, ea, stream,
                                                      tiled_cfg_for(hidden), max_tiles);
 }

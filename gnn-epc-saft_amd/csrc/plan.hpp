@@ -67,13 +67,14 @@ static inline int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, i
   p.sx = tape ? (int64_t)(nn * h) : 0;
   p.spq = tape ? (int64_t)(nn * 4 * h) : 0;
   p.sagg = tape ? (int64_t)(nn * 8 * h) : 0;
-  p.su = tape ? (int64_t)(nn * h) : 0;
+  // tape: every post layer keeps its (pre-ReLU) output: layer l, post layer j at u0 + (l*q + j) * nn*h
+  p.su = tape ? (int64_t)(nn * h) * d->post_layers : 0;
   p.sy = tape ? (int64_t)(nn * h) : 0;
   p.x0 = take((tape ? nlay + 1 : 1) * nn * h * 4);  // tape: x_0 .. x_L contiguous
   p.x1 = tape ? p.x0 : take(nn * h * 4);
   p.pq = take(rep * nn * 4 * h * 4);
   p.agg = take(rep * nn * 8 * h * 4);
-  p.u0 = take(rep * nn * h * 4);
+  p.u0 = take(rep * (tape ? (size_t)d->post_layers : 1) * nn * h * 4);
   p.u1 = d->post_layers > 1 ? take(nn * h * 4) : p.u0;
   p.y = take(rep * nn * h * 4);
   p.bnstat = take(nlay * 2 * h * 4);
