@@ -55,6 +55,7 @@ SIGNATURES = {
     "gnnsaft_pna_node_terms": (c_int32, [P, c_int64, c_int32, P, P, P, P]),
     "gnnsaft_pna_edge_table": (c_int32, [P, c_int32, c_int32, P, P, P, P, P, P, P, P, P]),
     "gnnsaft_pna_edge_mlp": (c_int32, [P, P, P, c_int64, c_int32, P, P, P, P, P, P, P, P]),
+    "gnnsaft_pna_edge_preact": (c_int32, [P, P, P, c_int64, c_int32, P, P, P, P]),
     "gnnsaft_pna_aggregate": (c_int32, [P, P, P, c_int64, c_int32, P, P, P, P, P]),
     "gnnsaft_pna_update": (c_int32, [P, P, P, P, P, c_int64, c_int32, P, P, P, P, P, P]),
     "gnnsaft_degree_buckets": (c_int32, []),

@@ -129,6 +129,23 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict
   gs_st4(o + 3 * f, sd);
 }
 
+// h1pre[r, c] = pq[dst_r, c] + pq[src_r, 2F + c] + rtab[combo_r, c]: pre-activation of the first pre layer per
+// CSR row, materialised only on the tape path of pre_layers >= 2 (the backward needs it as ReLU mask / wgrad operand)
+__global__ __launch_bounds__(256) void k_edge_preact(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                                     const int32_t *__restrict__ combo, const float *__restrict__ pq,
+                                                     const float *__restrict__ rtab, float *__restrict__ out,
+                                                     int64_t rows, int f, RowSplit rs) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t r;
+  int lane;
+  gs_split(rs, slot, r, lane);
+  if (r >= rows) return;
+  const int c = lane * 4;
+  const f32x4 p = gs_ld4(pq + (int64_t)dst[r] * (4 * f) + c), q = gs_ld4(pq + (int64_t)src[r] * (4 * f) + 2 * f + c),
+              t = gs_ld4(rtab + (int64_t)combo[r] * (2 * f) + c);
+  gs_st4(out + r * (int64_t)(2 * f) + c, (p + q) + t);
+}
+
 static int launch_aggregate(int mode, const int32_t *rowptr, const int32_t *src, const int32_t *combo,
                             int64_t num_nodes, int32_t hidden, const float *pq, const float *rtab, const float *msgs,
                             float *agg, hipStream_t st) {
@@ -169,4 +186,17 @@ extern "C" int gnnsaft_pna_aggregate_src(const int32_t *rowptr, const int32_t *s
                                          float *agg, gnnsaft_stream_t stream) {
   return gs::launch_aggregate(gs::kFusedQ, rowptr, src, combo, num_nodes, hidden, q, rtab, nullptr, agg,
                               static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gnnsaft_pna_edge_preact(const int32_t *src, const int32_t *dst, const int32_t *combo, int64_t num_rows,
+                                       int32_t hidden, const float *pq, const float *rtab, float *out,
+                                       gnnsaft_stream_t stream) {
+  GS_REQUIRE(src && dst && combo && pq && rtab && out, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0 && num_rows >= 0, GNNSAFT_ERR_SHAPE);
+  if (num_rows == 0) return GNNSAFT_OK;
+  hipLaunchKernelGGL(gs::k_edge_preact, dim3((unsigned)gs_ceil_div(num_rows * (hidden / 2), 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, dst, combo, pq, rtab, out, num_rows, hidden,
+                     gs_row_split(hidden / 2));
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
 }

@@ -179,11 +179,13 @@ static int bn_relu_backward(const float *y, const float *dout, const float *stat
 // For node i, column slice c: recompute its in-edge messages exactly as the forward did, then
 //   dm_e = dmean/cnt + [m_e == min] dmin/#ties + [m_e == max] dmax/#ties + dstd (m_e - mean)/(cnt std)
 // (std term only where the forward left std unmasked).  dm rows are written in CSR order, dP_i = sum_e dm_e.
+template <bool MSGS>  // MSGS: the messages are a materialised [E',2F] tensor (pre_layers >= 2), dP comes later
 __global__ __launch_bounds__(256) void k_agg_bwd(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ src,
                                                  const int32_t *__restrict__ combo, const float *__restrict__ pq,
-                                                 const float *__restrict__ rtab, const float *__restrict__ agg,
-                                                 const float *__restrict__ dagg, float *__restrict__ dm,
-                                                 float *__restrict__ dp, int64_t num_nodes, int f, RowSplit rs) {
+                                                 const float *__restrict__ rtab, const float *__restrict__ msgs,
+                                                 const float *__restrict__ agg, const float *__restrict__ dagg,
+                                                 float *__restrict__ dm, float *__restrict__ dp, int64_t num_nodes,
+                                                 int f, RowSplit rs) {
   const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t node;
   int lane;
@@ -201,11 +203,15 @@ __global__ __launch_bounds__(256) void k_agg_bwd(const int32_t *__restrict__ row
                 sd = gs_ld4(agg + ao + 3 * f);
     const f32x4 dmean = gs_ld4(dagg + ao), dmn = gs_ld4(dagg + ao + f), dmx = gs_ld4(dagg + ao + 2 * f),
                 dsd = gs_ld4(dagg + ao + 3 * f);
-    const f32x4 p = gs_ld4(pq + node * (int64_t)(4 * f) + c);
+    f32x4 p = {0.f, 0.f, 0.f, 0.f};
+    if (!MSGS) p = gs_ld4(pq + node * (int64_t)(4 * f) + c);
+    auto message = [&](int r) -> f32x4 {
+      if (MSGS) return gs_ld4(msgs + (int64_t)r * (2 * f) + c);
+      return (p + gs_ld4(pq + (int64_t)src[r] * (4 * f) + 2 * f + c)) + gs_ld4(rtab + (int64_t)combo[r] * (2 * f) + c);
+    };
     f32x4 nmin = {0.f, 0.f, 0.f, 0.f}, nmax = {0.f, 0.f, 0.f, 0.f};
     for (int r = beg; r < end; ++r) {
-      const f32x4 m = (p + gs_ld4(pq + (int64_t)src[r] * (4 * f) + 2 * f + c)) +
-                      gs_ld4(rtab + (int64_t)combo[r] * (2 * f) + c);
+      const f32x4 m = message(r);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         nmin[j] += m[j] == mn[j] ? 1.f : 0.f;
@@ -217,8 +223,7 @@ __global__ __launch_bounds__(256) void k_agg_bwd(const int32_t *__restrict__ row
 #pragma unroll
     for (int j = 0; j < 4; ++j) cs[j] = sd[j] > 0.f ? dsd[j] / (fc * sd[j]) : 0.f;
     for (int r = beg; r < end; ++r) {
-      const f32x4 m = (p + gs_ld4(pq + (int64_t)src[r] * (4 * f) + 2 * f + c)) +
-                      gs_ld4(rtab + (int64_t)combo[r] * (2 * f) + c);
+      const f32x4 m = message(r);
       f32x4 d;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -231,7 +236,21 @@ __global__ __launch_bounds__(256) void k_agg_bwd(const int32_t *__restrict__ row
       dpacc += d;
     }
   }
-  gs_st4(dp + node * (int64_t)(4 * f) + c, dpacc);  // dPQ[:, 0:2F]
+  if (!MSGS) gs_st4(dp + node * (int64_t)(4 * f) + c, dpacc);  // dPQ[:, 0:2F]
+}
+
+// dP_i = sum of the row gradients of node i's in-edges (CSR rows are contiguous per destination)
+__global__ __launch_bounds__(256) void k_segment_sum(const int32_t *__restrict__ rowptr, const float *__restrict__ dm,
+                                                     float *__restrict__ dpq, int64_t num_nodes, int f, RowSplit rs) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t node;
+  int lane;
+  gs_split(rs, slot, node, lane);
+  if (node >= num_nodes) return;
+  const int c = lane * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int r = rowptr[node]; r < rowptr[node + 1]; ++r) acc += gs_ld4(dm + (int64_t)r * (2 * f) + c);
+  gs_st4(dpq + node * (int64_t)(4 * f) + c, acc);
 }
 
 // dq[j, :] = sum over the CSR rows whose source is j (ascending row id) -> dPQ[:, 2F:4F]
@@ -375,7 +394,7 @@ static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
   const size_t rows = nn > gg ? nn : gg;
   size_t slab = tn_slab_bytes(p.n, (int)(h / 2), (int)(13 * h));       // dW_post
   const size_t s2 = tn_slab_bytes(p.n, (int)h, 176 + 16);                 // one-hot (atom vocabulary rows)
-  const size_t s3 = tn_slab_bytes(rows, (int)h, (int)h);
+  const size_t s3 = tn_slab_bytes(rows > ee ? rows : ee, (int)h, (int)h);
   slab = slab > s2 ? slab : s2;
   slab = slab > s3 ? slab : s3;
   size_t tot = 0;
@@ -386,6 +405,7 @@ static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
   add(nn * h * 4);                                       // du
   add(nn * 8 * h * 4);                                   // dagg
   add(ee * 2 * h * 4);                                   // dm
+  if (d->pre_layers > 1) add(ee * 2 * h * 4);            // dm2
   add(nn * 4 * h * 4);                                   // dpq
   add((size_t)p.combos * 2 * h * 4);                     // dr
   add((size_t)p.combos * h * 4 * 2);                     // dcenc, dcemb
@@ -435,8 +455,8 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   (void)batch;
   GS_REQUIRE(d && weights_host && grads_host && grad_out && tape && scratch && x_idx, GNNSAFT_ERR_NULL);
   GS_REQUIRE(d->save_tape && d->training, GNNSAFT_ERR_UNSUPPORTED);
-  GS_REQUIRE(d->pre_layers == 1 && d->post_layers >= 1 && d->post_layers <= 8 && (d->hidden % 64) == 0 &&
-                 d->fold_degree_scalers && !d->fold_dst_term,
+  GS_REQUIRE(d->pre_layers >= 1 && d->pre_layers <= 8 && d->post_layers >= 1 && d->post_layers <= 8 &&
+                 (d->hidden % 64) == 0 && d->fold_degree_scalers && !d->fold_dst_term,
              GNNSAFT_ERR_UNSUPPORTED);
   Plan p;
   GS_TRY(make_plan(d, num_nodes, num_edges, num_graphs, p));
@@ -460,6 +480,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   float *dy = sc.take<float>(n * h), *du = sc.take<float>(n * h);
   float *dagg = sc.take<float>(n * 8 * h);
   float *dm = sc.take<float>((p.ep > 0 ? p.ep : 1) * 2 * h);
+  float *dm2 = d->pre_layers > 1 ? sc.take<float>((p.ep > 0 ? p.ep : 1) * 2 * h) : dm;
   float *dpq = sc.take<float>(n * 4 * h);
   float *dr = sc.take<float>(C * 2 * h);
   float *dcenc = sc.take<float>(C * h), *dcemb = sc.take<float>(C * h);
@@ -549,8 +570,9 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     const int base = pw.layer_base[l];
     // table indices inside the layer (q = post_layers): avg 0 | we 1 be 2 | pre0 w3 b4 | pre1 w5 b6 |
     //   post0 (w,b) x q from 7 | post1 (w,b) x q from 7+2q | lin w,b | bn gamma, beta (running stats, counter)
-    const int q = d->post_layers;
-    const int i_post0 = base + 7, i_post1 = base + 7 + 2 * q, i_lin = base + 7 + 4 * q, i_bn = i_lin + 2;
+    const int q = d->post_layers, pl = d->pre_layers;
+    const int i_pre0 = base + 3, i_pre1 = base + 3 + 2 * pl;
+    const int i_post0 = base + 3 + 4 * pl, i_post1 = i_post0 + 2 * q, i_lin = i_post1 + 2 * q, i_bn = i_lin + 2;
     const float *x_l = F(p.x0) + l * p.sx, *pq_l = F(p.pq) + l * p.spq, *agg_l = F(p.agg) + l * p.sagg;
     const float *u_first = F(p.u0) + l * p.su;                        // output of post layer 0
     const float *u_l = u_first + (int64_t)(q - 1) * n * h;            // output of the last post layer = lin's input
@@ -615,8 +637,45 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
                                         h / 2, 8 * (int64_t)h, n, 4 * h, h / 2, h, st));
     }
     // aggregation backward: dm rows, dP; then dQ by source, dR by class
-    hipLaunchKernelGGL(k_agg_bwd, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, I(p.rowptr),
-                       I(p.src), I(p.combo), pq_l, rtab, agg_l, dagg, dm, dpq, n, h, gs_row_split(h / 2));
+    if (pl == 1) {
+      hipLaunchKernelGGL(k_agg_bwd<false>, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st,
+                         I(p.rowptr), I(p.src), I(p.combo), pq_l, rtab, nullptr, agg_l, dagg, dm, dpq, n, h,
+                         gs_row_split(h / 2));
+    } else {
+      // extra pre layers: messages = output of the last one (materialised per CSR row on the tape)
+      const int64_t ms = p.ep * (int64_t)(2 * h);
+      const float *m_l = F(p.msg0) + l * p.smsg;
+      hipLaunchKernelGGL(k_agg_bwd<true>, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st,
+                         I(p.rowptr), I(p.src), I(p.combo), pq_l, rtab, m_l + (pl - 1) * ms, agg_l, dagg, dm, dpq, n,
+                         h, gs_row_split(h / 2));
+      float *dcur_m = dm, *dnext_m = dm2;
+      for (int j = pl - 1; j >= 1; --j) {
+        const float *a_prev = m_l + (j - 1) * ms;  // pre-ReLU input of pre layer j
+        for (int t = 0; t < 2; ++t) {
+          const int iw = (t == 0 ? i_pre0 : i_pre1) + 2 * j;
+          GS_TRY(launch_wgrad_plain(dcur_m + t * h, 2 * (int64_t)h, a_prev + t * h, 2 * (int64_t)h, 1, p.ep, h, h, G(iw), h,
+                                    0, slabs, slab_bytes, st));
+          GS_TRY(launch_colsum(dcur_m + t * h, 2 * (int64_t)h, p.ep, h, G(iw + 1), 0, slabs, slab_bytes, st));
+          GS_TRY(transpose1(w.wpre[t][j], h, wlinT, h, h, h));
+          GemmBatchEntry e{wlinT, nullptr, dnext_m + t * h, t * (int64_t)h};
+          LinearEpilogue epi;
+          epi.residual = a_prev + t * h;
+          epi.ldr = 2 * (int64_t)h;
+          epi.residual_is_mask = 1;
+          GS_TRY(launch_linear(dcur_m, 2 * (int64_t)h, 0, 1, &e, h, 2 * (int64_t)h, p.ep, h, h, epi, st));
+        }
+        float *tsw = dcur_m;
+        dcur_m = dnext_m;
+        dnext_m = tsw;
+      }
+      if (dcur_m != dm) {  // the downstream kernels read `dm`
+        float *tsw = dm;
+        dm = dm2;
+        dm2 = tsw;
+      }
+      hipLaunchKernelGGL(k_segment_sum, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, I(p.rowptr), dm,
+                         dpq, n, h, gs_row_split(h / 2));
+    }
     hipLaunchKernelGGL(k_gather_rows_sum, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, rowptr_s,
                        rows_s, dm, dpq, n, h, gs_row_split(h / 2));
     hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * 2 * h, 256)), dim3(256), 0, st, dr, C * 2 * h);
@@ -631,7 +690,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       GS_TRY(launch_transpose(4, ins, outs, ldi, ldo, h, h, st));  // wpqT[j][blk*F + f] = pre_t[f][part*F + j]
       GS_TRY(dgrad(dpq, 4 * (int64_t)h, wpqT, 4 * (int64_t)h, dx, h, n, h, 4 * h, dx_other));
       for (int t = 0; t < 2; ++t) {
-        float *gw = G(base + 3 + 2 * t);
+        float *gw = G(t == 0 ? i_pre0 : i_pre1);
         GS_TRY(launch_wgrad_plain(dpq + t * h, 4 * (int64_t)h, x_l, h, 0, n, h, h, gw, 3 * (int64_t)h, 0, slabs,
                                   slab_bytes, st));
         GS_TRY(launch_wgrad_plain(dpq + 2 * h + t * h, 4 * (int64_t)h, x_l, h, 0, n, h, h, gw + h, 3 * (int64_t)h, 0,
@@ -640,10 +699,10 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     }
     // edge-class table: rtab[c, tF:(t+1)F] = W_t[:,2F:3F] cenc[c] + b_t ; cenc = cemb W_e^T + b_e
     for (int t = 0; t < 2; ++t) {
-      float *gw = G(base + 3 + 2 * t);
+      float *gw = G(t == 0 ? i_pre0 : i_pre1);
       GS_TRY(launch_wgrad_plain(dr + t * h, 2 * (int64_t)h, cenc, h, 0, C, h, h, gw + 2 * h, 3 * (int64_t)h, 0, slabs,
                                 slab_bytes, st));
-      GS_TRY(launch_colsum(dr + t * h, 2 * (int64_t)h, C, h, G(base + 4 + 2 * t), 0, slabs, slab_bytes, st));
+      GS_TRY(launch_colsum(dr + t * h, 2 * (int64_t)h, C, h, G((t == 0 ? i_pre0 : i_pre1) + 1), 0, slabs, slab_bytes, st));
     }
     {
       const float *ins[2] = {w.wpre[0][0] + 2 * h, w.wpre[1][0] + 2 * h};

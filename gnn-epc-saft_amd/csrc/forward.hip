@@ -409,7 +409,19 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
         GS_TRY(node_terms(xc, n, h, wpre[0][0], wpre[1][0], pq_l, st));
     }
     const float *msgs = nullptr;
-    if (d->pre_layers > 1) {
+    if (d->pre_layers > 1 && tape) {
+      // keep every edge-level tensor: h1pre, then the output of each extra pre layer
+      float *m_l = F(p.msg0) + l * p.smsg;
+      const int64_t ms = p.ep * (int64_t)(2 * h);
+      GS_TRY(gnnsaft_pna_edge_preact(I(p.src), I(p.dst), I(p.combo), p.ep, h, pq_l, rtab, m_l, st));
+      for (int j = 1; j < d->pre_layers; ++j) {
+        float *in = m_l + (j - 1) * ms, *outp = m_l + j * ms;
+        GemmBatchEntry e2[2] = {{wpre[0][j], bpre[0][j], outp, 0}, {wpre[1][j], bpre[1][j], outp + h, h}};
+        LinearEpilogue epi;
+        GS_TRY(launch_linear(in, 2 * (int64_t)h, 1, 2, e2, h, 2 * (int64_t)h, p.ep, h, h, epi, st));
+      }
+      msgs = m_l + (d->pre_layers - 1) * ms;
+    } else if (d->pre_layers > 1) {
       float *ma = F(p.msg0), *mb = F(p.msg1);
       GemmBatchEntry e[2] = {{wpre[0][1], bpre[0][1], ma, 0}, {wpre[1][1], bpre[1][1], ma + h, 0}};
       GS_TRY(launch_pna_edge_mlp(I(p.src), I(p.dst), I(p.combo), p.ep, h, pq_l, rtab, e, 2 * (int64_t)h, st));

@@ -16,7 +16,7 @@ struct Plan {
   size_t perm, tiles, num_tiles, hist3, weff, gfold;
   int64_t tile_cap;
   // per-layer strides in floats (0 unless desc->save_tape: then every layer keeps its own tensors for backward)
-  int64_t sx, spq, sagg, su, sy;
+  int64_t sx, spq, sagg, su, sy, smsg;
   size_t bnstat;          // [L][2][H] batch mean, rstd of the node BatchNorms
   size_t ry, ro, rstat;   // readout blocks: pre-BN [nb][G,H], output [nb][G,H], (mean, rstd) [nb][2][H]
   int nb;                 // BatchNorm blocks in the readout = num_mlp_layers + 2
@@ -82,7 +82,10 @@ static inline int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, i
   p.ry = take((size_t)p.nb * gg * h * 4);
   p.ro = take((size_t)p.nb * gg * h * 4);
   p.rstat = take((size_t)p.nb * 2 * h * 4);
-  p.msg0 = d->pre_layers > 1 ? take(ee * 2 * h * 4) : 0;
+  // edge-level tensors of the extra pre layers.  Tape: per conv layer, buffer 0 = pre-activation of the first
+  // pre layer (P[dst] + Q[src] + R[class]), buffer j = (pre-ReLU) output of pre layer j: msg0 + (l*p + j) * ee*2h
+  p.smsg = tape ? (int64_t)(ee * 2 * h) * d->pre_layers : 0;
+  p.msg0 = d->pre_layers > 1 ? take((tape ? rep * (size_t)d->pre_layers : 1) * ee * 2 * h * 4) : 0;
   p.msg1 = d->pre_layers > 2 ? take(ee * 2 * h * 4) : p.msg0;
   p.cemb = take((size_t)p.combos * h * 4);
   const size_t nl = (size_t)(d->num_layers > 0 ? d->num_layers : 1);

@@ -247,10 +247,9 @@ class PNAPCSAFT(nn.Module):
         if tape:
             if not self.training:
                 raise NotImplementedError("backward is implemented for train-mode BatchNorm only (model.train())")
-            if desc.pre_layers != 1 or desc.hidden % 64 != 0 or desc.num_para > 8:
-                raise NotImplementedError("backward supports pre_layers == 1 and hidden_dim % 64 == 0 (the "
-                                          "reference's shipped default and its post_layers variants); run other "
-                                          "shapes under torch.no_grad()")
+            if desc.hidden % 64 != 0 or desc.num_para > 8:
+                raise NotImplementedError("backward needs hidden_dim % 64 == 0 and num_para <= 8 (the reference's "
+                                          "envelope: 64 / 128 / 256, 3 or 5); run other shapes under torch.no_grad()")
             desc.save_tape, desc.fold_degree_scalers, desc.fold_dst_term = 1, 1, 0
         if x.shape[1] != desc.num_atom_cols or edge_attr.shape[1] != desc.num_bond_cols:
             raise ValueError("x / edge_attr column counts do not match the embedding tables")

@@ -149,6 +149,12 @@ int gnnsaft_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *
                          const float *w2_t1, const float *b2_t1,
                          float *msgs /* [E',2F] */, gnnsaft_stream_t stream);
 
+/* pre-activation of the first pre layer per CSR row, out[r,:] = pq[dst_r] + pq[src_r] + rtab[combo_r]  */
+/* ([E',2F]); materialised only when the backward of pre_layers >= 2 needs it.                          */
+int gnnsaft_pna_edge_preact(const int32_t *src, const int32_t *dst, const int32_t *combo,
+                            int64_t num_rows, int32_t hidden, const float *pq, const float *rtab,
+                            float *out, gnnsaft_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* K4 (the measured "scatter-add" kernel): PyG MultiAggregation               */
 /* [mean,min,max,std] over the in-edges of every node (models.py:59,128):      */
@@ -333,7 +339,7 @@ int gnnsaft_forward(const gnnsaft_model_desc *desc,
 /* (HOST array of device pointers, same order and shapes as `weights_host`;     */
 /* entries of buffers -- avg_deg_log, running statistics, counters -- are       */
 /* ignored and may be NULL) given grad_out = dL/d(forward output) [G,P].        */
-/* Supported: pre_layers == post_layers == 1, hidden % 64 == 0.                 */
+/* Supported: 1 <= pre_layers, post_layers <= 8, hidden % 64 == 0.              */
 /* ------------------------------------------------------------------------ */
 size_t gnnsaft_backward_scratch_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes,
                                       int64_t num_edges, int64_t num_graphs);

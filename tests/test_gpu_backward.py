@@ -52,14 +52,17 @@ def grads_of(model, data, num_para, dtype):
 
 
 CASES = [
-    # hidden, depth, mlp, P, skip, loops, graphs, post_layers
-    (64, 2, 1, 3, True, True, 48, 1),
-    (128, 3, 1, 3, True, True, 24, 1),
-    (64, 2, 0, 5, False, False, 48, 1),
-    (64, 1, 2, 5, True, False, 40, 1),
-    (256, 2, 1, 3, False, True, 24, 1),
-    (128, 2, 1, 3, True, True, 24, 3),      # compare.ipynb "model6": post_layers = 3
-    (64, 2, 1, 5, True, True, 32, 2),
+    # hidden, depth, mlp, P, skip, loops, graphs, post_layers, pre_layers
+    (64, 2, 1, 3, True, True, 48, 1, 1),
+    (128, 3, 1, 3, True, True, 24, 1, 1),
+    (64, 2, 0, 5, False, False, 48, 1, 1),
+    (64, 1, 2, 5, True, False, 40, 1, 1),
+    (256, 2, 1, 3, False, True, 24, 1, 1),
+    (128, 2, 1, 3, True, True, 24, 3, 1),      # compare.ipynb "model6": post_layers = 3
+    (64, 2, 1, 5, True, True, 32, 2, 1),
+    (64, 2, 1, 3, True, True, 32, 1, 2),       # tuner.py search space: pre_layers in {1, 2}
+    (128, 2, 1, 3, False, False, 24, 2, 2),
+    (64, 1, 1, 3, True, True, 24, 1, 3),
 ]
 
 
@@ -67,13 +70,13 @@ CASES = [
 def test_parameter_gradients_match_oracle_autograd(cfg):
     from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
     from gnn_epc_saft_amd.train.models import mape_loss
-    hidden, depth, mlp, num_para, skip, loops, graphs, post = cfg
+    hidden, depth, mlp, num_para, skip, loops, graphs, post, pre = cfg
     # A std-threshold flip in the forward (tests/test_gpu_forward.py) also moves the gradients discontinuously
     # (~1e-2 on the flipped tower's message weights).  Take the first batch on which neither the f32 oracle nor
     # the HIP forward flips w.r.t. the f64 oracle, so that the gradient comparison is well defined.
     for attempt in range(32):
         data = make_synthetic_batch(graphs, 900 + hidden + depth + 1000 * attempt, num_para=num_para)
-        oracle = oracle_model(hidden, depth, 1, post, mlp, num_para, skip, loops, degree_histogram(data),
+        oracle = oracle_model(hidden, depth, pre, post, mlp, num_para, skip, loops, degree_histogram(data),
                               seed=depth).train()
         with torch.no_grad():
             want64 = copy.deepcopy(oracle).double()(data)
@@ -162,7 +165,7 @@ def test_backward_is_reproducible_and_optimizer_step_reduces_loss():
 def test_unsupported_shapes_fail_loudly_in_grad_mode():
     from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
     data = make_synthetic_batch(8, 3)
-    oracle = oracle_model(64, 1, 2, 1, 0, 3, False, True, degree_histogram(data)).train()   # pre_layers = 2
+    oracle = oracle_model(32, 1, 2, 1, 0, 3, False, True, degree_histogram(data)).train()   # hidden % 64 != 0
     hip = hip_twin(oracle)
     with pytest.raises(NotImplementedError):
         hip(data.to(DEV))
