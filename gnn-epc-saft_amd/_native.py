@@ -66,7 +66,9 @@ SIGNATURES = {
     "gnnsaft_pna_update_folded": (c_int32, [P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
     "gnnsaft_debug_set_gemm_config": (None, [c_int32]),
     "gnnsaft_bn_finalize": (c_int32, [P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, c_int32, P, P, P]),
-    "gnnsaft_bn_train_apply": (c_int32, [P, P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, P, P, P, P]),
+    "gnnsaft_bn_train_scratch_bytes": (c_size_t, [c_int64, c_int32]),
+    "gnnsaft_bn_train_apply": (c_int32, [P, P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, P, P, P, P, c_size_t,
+                                         P]),
     "gnnsaft_pna_fold_post_weights_multi": (c_int32, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                                       POINTER(c_void_p), POINTER(c_void_p), P, P, c_int32, P, c_int64,
                                                       P]),
@@ -79,7 +81,9 @@ SIGNATURES = {
     "gnnsaft_forward_workspace_bytes": (c_size_t, [POINTER(ModelDesc), c_int64, c_int64, c_int64]),
     "gnnsaft_forward_workspace_map": (c_int32, [POINTER(ModelDesc), c_int64, c_int64, c_int64, POINTER(WorkspaceMap)]),
     "gnnsaft_forward": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), c_int32, P, P, P, P, c_int64, c_int64,
-                                  c_int64, P, P, P, P, P, c_size_t, P, P]),
+                                  c_int64, P, P, P, P, P, c_size_t, P, P, P]),
+    "gnnsaft_aux_create": (c_int32, [POINTER(c_void_p)]),
+    "gnnsaft_aux_destroy": (None, [P]),
     "gnnsaft_backward_scratch_bytes": (c_size_t, [POINTER(ModelDesc), c_int64, c_int64, c_int64]),
     "gnnsaft_backward": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), POINTER(c_void_p), c_int32, P, P, c_int64,
                                    c_int64, c_int64, P, P, c_size_t, P, c_size_t, P]),
@@ -123,3 +127,20 @@ def check(code: int, what: str) -> None:
     if code != 0:
         msg = lib.gnnsaft_error_string(code)
         raise GnnsaftError(f"{what} failed: {msg.decode() if msg else code} (code {code})")
+
+
+_AUX = {}
+
+
+def aux_for(device_index: int):
+    """gnnsaft_aux handle (side stream + fork/join events) of a device; created on first use, with that device
+    current, and kept for the life of the process.  One per device: the boundary contract is one forward at a
+    time per process per device ("Threading"), and the handle must exist before a hipGraph
+    capture starts (stream creation is not capturable) -- the warm-up forward every capture needs creates it."""
+    key = int(device_index)
+    h = _AUX.get(key)
+    if h is None:
+        out = c_void_p()
+        check(lib.gnnsaft_aux_create(ctypes.byref(out)), "gnnsaft_aux_create")
+        h = _AUX[key] = out
+    return h

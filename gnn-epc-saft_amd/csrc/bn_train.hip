@@ -6,12 +6,73 @@
 // few tens of KB of L2 reads per workgroup, cheaper than a separate finalize launch), then
 // streams its rows:  out = relu(y * scale + shift) (+ residual).  Row chunk 0 also updates
 // running_mean / running_var (unbiased) / num_batches_tracked.
+// With more than kBnFusedGroups partials that redundant fold costs more L2 traffic than the pass over y itself
+// (every workgroup re-reads all partials of its slab), so k_bn_combine first folds them into <= 64 segment sums
+// (f64, same pivot) in its own small launch and the apply workgroups fold only those.
 #include "common.hpp"
 
 namespace gs {
 
 constexpr int kBnCols = 32;
 constexpr int kBnGroupLanes = 8;  // 256 threads = 8 partial-lanes x 32 columns
+constexpr int kBnFusedGroups = 64;  // up to this many partials: single launch
+constexpr int kBnMaxSegments = 64;
+constexpr int kBnSegGroups = 64;    // partials folded per segment (8 per thread, one round of loads)
+
+// (S1, S2) of one thread's share of the partials [g_beg, g_end) of column colc around `pivot`
+__device__ __forceinline__ void bn_fold_partials(const float *__restrict__ stats, int64_t g_beg, int64_t g_end,
+                                                 int64_t rows, int ch, int colc, int gl, double pivot, double &s1,
+                                                 double &s2) {
+  constexpr int kUnroll = 8;  // independent loads in flight per thread
+  for (int64_t g0 = g_beg + gl; g0 < g_end; g0 += kBnGroupLanes * kUnroll) {
+    float gm[kUnroll], g2[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      int64_t g = g0 + (int64_t)u * kBnGroupLanes;
+      g = g < g_end ? g : g_end - 1;
+      gm[u] = stats[(g * 2 + 0) * ch + colc];
+      g2[u] = stats[(g * 2 + 1) * ch + colc];
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t g = g0 + (int64_t)u * kBnGroupLanes;
+      if (g < g_end) {
+        const int64_t left = rows - g * kBnRowsPerGroup;
+        const double gn = (double)(left < kBnRowsPerGroup ? left : kBnRowsPerGroup);
+        const double m = (double)gm[u] - pivot;
+        s1 += gn * m;
+        s2 += (double)g2[u] + gn * m * m;
+      }
+    }
+  }
+}
+
+// segment sums: seg[(s*2 + {0,1}) * ch + col] = (S1, S2) of partials [s*kBnSegGroups, (s+1)*kBnSegGroups)
+__global__ __launch_bounds__(256) void k_bn_combine(const float *__restrict__ stats, int64_t rows, int ch,
+                                                    double *__restrict__ seg) {
+  __shared__ double s_a[kBnGroupLanes][kBnCols], s_b[kBnGroupLanes][kBnCols];
+  const int cl = threadIdx.x & (kBnCols - 1), gl = threadIdx.x / kBnCols;
+  const int col = blockIdx.x * kBnCols + cl;
+  const int colc = col < ch ? col : ch - 1;
+  const int64_t groups = (rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup;
+  const int64_t per_seg = (groups + gridDim.y - 1) / gridDim.y;
+  const int64_t g_beg = (int64_t)blockIdx.y * per_seg;
+  int64_t g_end = g_beg + per_seg;
+  if (g_end > groups) g_end = groups;
+  double s1 = 0.0, s2 = 0.0;
+  if (g_beg < g_end) bn_fold_partials(stats, g_beg, g_end, rows, ch, colc, gl, (double)stats[colc], s1, s2);
+  s_a[gl][cl] = s1;
+  s_b[gl][cl] = s2;
+  __syncthreads();
+  if (gl == 0 && col < ch) {
+    for (int o = 1; o < kBnGroupLanes; ++o) {
+      s1 += s_a[o][cl];
+      s2 += s_b[o][cl];
+    }
+    seg[((int64_t)blockIdx.y * 2 + 0) * ch + col] = s1;
+    seg[((int64_t)blockIdx.y * 2 + 1) * ch + col] = s2;
+  }
+}
 
 __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict__ stats, const float *__restrict__ y,
                                                         int64_t rows, int ch, const float *__restrict__ gamma,
@@ -20,7 +81,8 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
                                                         float *__restrict__ running_var, int64_t *nbt,
                                                         float momentum, float eps,
                                                         const float *__restrict__ residual, float *__restrict__ out,
-                                                        int64_t rows_per_chunk, float *__restrict__ save_stat) {
+                                                        int64_t rows_per_chunk, float *__restrict__ save_stat,
+                                                        const double *__restrict__ seg, int num_seg) {
   __shared__ double s_mean[kBnGroupLanes][kBnCols], s_m2[kBnGroupLanes][kBnCols];
   __shared__ float s_scale[kBnCols], s_shift[kBnCols];
   const int c0 = blockIdx.x * kBnCols;
@@ -39,27 +101,13 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
   // for columns with |mean| >> std (the case Chan's pairwise update protects against).
   const double pivot = (double)stats[colc];
   double s1 = 0.0, s2 = 0.0;
-  constexpr int kUnroll = 8;  // independent loads in flight per thread
-  for (int64_t g0 = gl; g0 < groups; g0 += kBnGroupLanes * kUnroll) {
-    float gm[kUnroll], g2[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      int64_t g = g0 + (int64_t)u * kBnGroupLanes;
-      g = g < groups ? g : groups - 1;
-      gm[u] = stats[(g * 2 + 0) * ch + colc];
-      g2[u] = stats[(g * 2 + 1) * ch + colc];
+  if (seg != nullptr) {
+    for (int sg = gl; sg < num_seg; sg += kBnGroupLanes) {
+      s1 += seg[((int64_t)sg * 2 + 0) * ch + colc];
+      s2 += seg[((int64_t)sg * 2 + 1) * ch + colc];
     }
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int64_t g = g0 + (int64_t)u * kBnGroupLanes;
-      if (g < groups) {
-        const int64_t left = rows - g * kBnRowsPerGroup;
-        const double gn = (double)(left < kBnRowsPerGroup ? left : kBnRowsPerGroup);
-        const double m = (double)gm[u] - pivot;
-        s1 += gn * m;
-        s2 += (double)g2[u] + gn * m * m;
-      }
-    }
+  } else {
+    bn_fold_partials(stats, 0, groups, rows, ch, colc, gl, pivot, s1, s2);
   }
   s_mean[gl][cl] = s1;
   s_m2[gl][cl] = s2;
@@ -131,15 +179,36 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
 
 }  // namespace gs
 
+extern "C" size_t gnnsaft_bn_train_scratch_bytes(int64_t num_rows, int32_t channels) {
+  if (num_rows <= 0 || channels <= 0) return 0;
+  const int64_t groups = gs_ceil_div(num_rows, (int64_t)gs::kBnRowsPerGroup);
+  if (groups <= gs::kBnFusedGroups) return 0;
+  return (size_t)gs::kBnMaxSegments * 2 * (size_t)channels * sizeof(double);
+}
+
 extern "C" int gnnsaft_bn_train_apply(const float *stats, const float *y, int64_t num_rows, int32_t channels,
                                       const float *gamma, const float *beta, float *running_mean,
                                       float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
-                                      const float *residual, float *out, float *save_mean_rstd,
-                                      gnnsaft_stream_t stream) {
+                                      const float *residual, float *out, float *save_mean_rstd, void *scratch,
+                                      size_t scratch_bytes, gnnsaft_stream_t stream) {
   GS_REQUIRE(stats && y && out, GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_rows >= 2, GNNSAFT_ERR_SHAPE);  // torch: "Expected more than 1 value per channel"
   GS_REQUIRE(channels >= 4 && (channels % 4) == 0, GNNSAFT_ERR_SHAPE);
   const int slabs = (channels + gs::kBnCols - 1) / gs::kBnCols;
+  const int64_t groups = gs_ceil_div(num_rows, (int64_t)gs::kBnRowsPerGroup);
+  double *seg = nullptr;
+  int num_seg = 0;
+  if (groups > gs::kBnFusedGroups) {
+    GS_REQUIRE(scratch != nullptr && scratch_bytes >= gnnsaft_bn_train_scratch_bytes(num_rows, channels) &&
+                   (reinterpret_cast<uintptr_t>(scratch) & 7) == 0,
+               GNNSAFT_ERR_WORKSPACE);
+    seg = static_cast<double *>(scratch);
+    num_seg = (int)gs_ceil_div(groups, (int64_t)gs::kBnSegGroups);
+    if (num_seg > gs::kBnMaxSegments) num_seg = gs::kBnMaxSegments;
+    hipLaunchKernelGGL(gs::k_bn_combine, dim3((unsigned)slabs, (unsigned)num_seg), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), stats, num_rows, channels, seg);
+    GS_CHECK_LAUNCH();
+  }
   // ~1024 workgroups in total, at least 64 rows each
   int64_t chunks = 1024 / slabs;
   const int64_t max_chunks = gs_ceil_div(num_rows, 64);
@@ -150,7 +219,8 @@ extern "C" int gnnsaft_bn_train_apply(const float *stats, const float *y, int64_
   chunks = gs_ceil_div(num_rows, rows_per_chunk);
   hipLaunchKernelGGL(gs::k_bn_train_apply, dim3((unsigned)slabs, (unsigned)chunks), dim3(256), 0,
                      static_cast<hipStream_t>(stream), stats, y, num_rows, channels, gamma, beta, running_mean,
-                     running_var, num_batches_tracked, momentum, eps, residual, out, rows_per_chunk, save_mean_rstd);
+                     running_var, num_batches_tracked, momentum, eps, residual, out, rows_per_chunk, save_mean_rstd, seg,
+                     num_seg);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }

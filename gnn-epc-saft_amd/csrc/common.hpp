@@ -7,6 +7,11 @@
 
 #define GS_WAVE 64
 
+#define GS_HIP(expr)                          \
+  do {                                        \
+    const hipError_t gs_e_ = (expr);          \
+    if (gs_e_ != hipSuccess) return (int)gs_e_; \
+  } while (0)
 #define GS_CHECK_LAUNCH()                         \
   do {                                            \
     hipError_t e__ = hipGetLastError();           \
@@ -79,6 +84,28 @@ struct LinearEpilogue {
   int residual_is_mask = 0;       // out = residual > 0 ? v : 0 (ReLU backward) instead of v + residual
 };
 
+struct GemmBatch {
+  GemmBatchEntry e[kMaxGemmBatch];
+};
+
+struct EpiArgs {
+  const float *scale;
+  const float *shift;
+  int relu_out;
+  const float *residual;
+  int64_t ldr;
+  float *stats;
+  int residual_is_mask;  // 1: out = residual > 0 ? v : 0 (ReLU backward) instead of v + residual
+};
+
+__device__ __forceinline__ f32x4 gs_relu4(f32x4 v) {
+  v.x = fmaxf(v.x, 0.f);
+  v.y = fmaxf(v.y, 0.f);
+  v.z = fmaxf(v.z, 0.f);
+  v.w = fmaxf(v.w, 0.f);
+  return v;
+}
+
 int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const GemmBatchEntry *entries,
                   int64_t ldw, int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi,
                   hipStream_t stream);
@@ -127,5 +154,61 @@ int launch_group_by_key(const int32_t *keys, int64_t count, int64_t num_keys, in
                         void *workspace, size_t workspace_bytes, int sort_segments, hipStream_t st);
 
 constexpr int kDegreeBuckets = 32;  // folded update: exact in-degree buckets 0..31
+constexpr int kDegBlock = 1024;     // nodes per workgroup in the degree bucketing passes (16 waves)
+
+__device__ __forceinline__ int clamp_degree(int d, int32_t *err) {
+  if (d >= kDegreeBuckets) {
+    if (err) atomicOr(err, GNNSAFT_FLAG_BAD_DEGREE);
+    d = kDegreeBuckets - 1;
+  }
+  return d;
+}
+
+// Per-wave counts of every degree among this wave's nodes -> wcount[wave][bucket] (LDS), and
+// the lane's rank among the wave's nodes of the same degree.  No atomics: deterministic.
+__device__ __forceinline__ int wave_degree_ranks(int d, bool live, int32_t (*wcount)[kDegreeBuckets]) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  int rank = 0;
+  unsigned long long todo = __ballot(live);
+  while (todo != 0ull) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int dl = __shfl(d, leader);
+    const unsigned long long same = __ballot(live && d == dl);
+    if (lane == leader) wcount[wave][dl] = __popcll(same);
+    if (live && d == dl) rank = __popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  return rank;
+}
+
+// block_hist[block][d] = number of nodes with (clamped) in-degree d among the kDegBlock nodes of this workgroup;
+// every thread of a kDegBlock-wide workgroup must call it (d ignored where !live)
+__device__ __forceinline__ void block_degree_hist(int d, bool live, int32_t *__restrict__ block_hist) {
+  __shared__ int32_t wcount[kDegBlock / 64][kDegreeBuckets];
+  for (int t = threadIdx.x; t < (kDegBlock / 64) * kDegreeBuckets; t += kDegBlock) (&wcount[0][0])[t] = 0;
+  __syncthreads();
+  wave_degree_ranks(d, live, wcount);
+  __syncthreads();
+  if (threadIdx.x < kDegreeBuckets) {
+    int tot = 0;
+    for (int w = 0; w < kDegBlock / 64; ++w) tot += wcount[w][threadIdx.x];
+    block_hist[(int64_t)blockIdx.x * kDegreeBuckets + threadIdx.x] = tot;
+  }
+}
+
+// internal fused launchers used by gnnsaft_forward (the C entry points keep the one-job-per-call form)
+int launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_t num_nodes, int64_t num_edges,
+                     int32_t num_bond_cols, const int32_t *bond_dims_host, int32_t self_loops, int32_t *rowptr,
+                     int32_t *src, int32_t *dst, int32_t *combo, float *log_amp, float *log_att, int32_t *err_flag,
+                     void *workspace, size_t workspace_bytes, const int64_t *batch, int64_t num_graphs,
+                     int32_t *graph_ptr, int32_t *degree_block_hist, hipStream_t st);
+int launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm, int32_t *tiles,
+                        int32_t *num_tiles, int32_t *scratch, int32_t *err_flag, bool have_block_hist, hipStream_t st);
+int launch_fold_post_weights(int32_t num_layers, const float *const *w_post0_host, const float *const *w_post1_host,
+                             const float *const *avg_deg_log_host, const float *const *w_pre0_host,
+                             const float *const *w_pre1_host, float *g_scratch, const int32_t *hist, int32_t hidden,
+                             float *w_eff, int64_t layer_stride, int phases /* 1: dst fold, 2: degree fold */,
+                             hipStream_t st);
 
 }  // namespace gs

@@ -24,9 +24,24 @@ __global__ void k_zero_i32(int32_t *p, int64_t n, int32_t *also = nullptr) {
   if (i == 0 && also != nullptr) also[0] = 0;
 }
 
+__device__ __forceinline__ void batch_to_ptr_slot(const int64_t *__restrict__ batch, int64_t n, int64_t g,
+                                                  int32_t *__restrict__ ptr, int32_t *err, int64_t i);
+
+// in-degree histogram; the same launch optionally converts the PyG `batch` vector to graph offsets (an
+// independent job with the same parallel shape: one thread per node)
 __global__ void k_count_in_degree(const int64_t *__restrict__ edge_index, int64_t n, int64_t e,
-                                  int32_t *__restrict__ counts, int32_t *err) {
+                                  int32_t *__restrict__ counts, int32_t *err,
+                                  const int64_t *__restrict__ batch = nullptr, int64_t g = 0,
+                                  int32_t *__restrict__ graph_ptr = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (graph_ptr != nullptr) {
+    if (batch != nullptr) {
+      batch_to_ptr_slot(batch, n, g, graph_ptr, err, i);
+    } else if (i == 0) {  // un-batched Data: one graph spanning all nodes
+      graph_ptr[0] = 0;
+      graph_ptr[1] = (int32_t)n;
+    }
+  }
   if (i >= e) return;
   const int64_t s = edge_index[i];
   const int64_t d = edge_index[e + i];
@@ -107,6 +122,55 @@ __global__ void k_scan_add(int32_t *__restrict__ rowptr, const int32_t *__restri
   if (i < n) rowptr[i] += tile_sums[i / kScanTile];
 }
 
+// phases 2 + 3 in one launch when there are few tiles: every workgroup sums the tile totals in front of its own
+// tile (its 256 entries lie in one tile); the last workgroup also writes the grand total to rowptr[n]
+constexpr int kScanFusedTiles = 4096;
+__global__ __launch_bounds__(256) void k_scan_add_fused(int32_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ tile_sums, int64_t num_tiles,
+                                                        int64_t n) {
+  __shared__ int lds[4];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t tile = ((int64_t)blockIdx.x * blockDim.x) / kScanTile;
+  const bool last = blockIdx.x == gridDim.x - 1;
+  const int64_t upto = last ? num_tiles : tile;
+  int before = 0, all = 0;
+  for (int64_t t = threadIdx.x; t < upto; t += blockDim.x) {
+    const int v = tile_sums[t];
+    all += v;
+    if (t < tile) before += v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    before += __shfl_xor(before, o);
+    all += __shfl_xor(all, o);
+  }
+  __shared__ int lds_all[4];
+  if ((threadIdx.x & 63) == 0) {
+    lds[threadIdx.x >> 6] = before;
+    lds_all[threadIdx.x >> 6] = all;
+  }
+  __syncthreads();
+  before = lds[0] + lds[1] + lds[2] + lds[3];
+  if (i < n) rowptr[i] += before;
+  if (last && threadIdx.x == 0) rowptr[n] = lds_all[0] + lds_all[1] + lds_all[2] + lds_all[3];
+}
+
+// exclusive scan of (counts + extra) into rowptr[0..n], rowptr[n] = total
+static void launch_exclusive_scan(const int32_t *counts, int64_t n, int extra, int32_t *rowptr, int32_t *tile_sums,
+                                  hipStream_t st) {
+  const int64_t tiles = gs_ceil_div(n > 0 ? n : 1, kScanTile);
+  hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)tiles), dim3(kScanBlock), 0, st, counts, n, extra, rowptr,
+                     tile_sums);
+  if (tiles <= kScanFusedTiles) {
+    hipLaunchKernelGGL(k_scan_add_fused, dim3((unsigned)gs_ceil_div(n > 0 ? n : 1, 256)), dim3(256), 0, st, rowptr,
+                       tile_sums, tiles, n);
+  } else {
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kScanBlock), 0, st, tile_sums, tiles, rowptr, n);
+    if (n > 0)
+      hipLaunchKernelGGL(k_scan_add, dim3((unsigned)gs_ceil_div(n, 256)), dim3(256), 0, st, rowptr, tile_sums, n);
+  }
+}
+
 __global__ void k_fill_edge_ids(const int64_t *__restrict__ edge_index, int64_t n, int64_t e,
                                 const int32_t *__restrict__ rowptr, int32_t *__restrict__ cursor,
                                 int32_t *__restrict__ eid) {
@@ -125,14 +189,13 @@ struct BondDims {
 };
 
 // one thread per node: order the segment, emit src / dst / combo rows and the degree scaler logs
-__global__ void k_finish_rows(const int64_t *__restrict__ edge_index, const int64_t *__restrict__ edge_attr,
-                              int64_t n, int64_t e, BondDims bd, int self_loops,
-                              const int32_t *__restrict__ rowptr, const int32_t *__restrict__ counts,
-                              int32_t *__restrict__ eid, int32_t *__restrict__ src, int32_t *__restrict__ dst,
-                              int32_t *__restrict__ combo, float *__restrict__ log_amp,
-                              float *__restrict__ log_att, int32_t *err) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ int finish_row(const int64_t *__restrict__ edge_index,
+                                          const int64_t *__restrict__ edge_attr, int64_t i, const BondDims &bd,
+                                          int self_loops, const int32_t *__restrict__ rowptr,
+                                          const int32_t *__restrict__ counts, int32_t *__restrict__ eid,
+                                          int32_t *__restrict__ src, int32_t *__restrict__ dst,
+                                          int32_t *__restrict__ combo, float *__restrict__ log_amp,
+                                          float *__restrict__ log_att, int32_t *err) {
   const int beg = rowptr[i];
   const int cnt = counts[i];
   // insertion sort, ascending edge id (stable wrt. the edge list)
@@ -169,11 +232,27 @@ __global__ void k_finish_rows(const int64_t *__restrict__ edge_index, const int6
   }
   log_amp[i] = logf((float)deg + 1.f);
   log_att[i] = logf(fmaxf((float)deg, 1.f) + 1.f);
+  return deg;
 }
 
-__global__ void k_batch_to_ptr(const int64_t *__restrict__ batch, int64_t n, int64_t g, int32_t *__restrict__ ptr,
-                               int32_t *err) {
+__global__ void k_finish_rows(const int64_t *__restrict__ edge_index, const int64_t *__restrict__ edge_attr,
+                              int64_t n, int64_t e, BondDims bd, int self_loops,
+                              const int32_t *__restrict__ rowptr, const int32_t *__restrict__ counts,
+                              int32_t *__restrict__ eid, int32_t *__restrict__ src, int32_t *__restrict__ dst,
+                              int32_t *__restrict__ combo, float *__restrict__ log_amp,
+                              float *__restrict__ log_att, int32_t *err, int32_t *__restrict__ block_hist) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  int deg = 0;
+  if (live)
+    deg = finish_row(edge_index, edge_attr, i, bd, self_loops, rowptr, counts, eid, src, dst, combo, log_amp, log_att,
+                     err);
+  // first pass of the degree bucketing (degree.hip) for free: launched with kDegBlock threads in that case
+  if (block_hist != nullptr) block_degree_hist(live ? clamp_degree(deg, err) : 0, live, block_hist);
+}
+
+__device__ __forceinline__ void batch_to_ptr_slot(const int64_t *__restrict__ batch, int64_t n, int64_t g,
+                                                  int32_t *__restrict__ ptr, int32_t *err, int64_t i) {
   if (i > n) return;
   // thread i in [0,n) closes the gap between batch[i-1] and batch[i]; thread n closes the tail
   int64_t prev = i == 0 ? -1 : batch[i - 1];
@@ -185,6 +264,11 @@ __global__ void k_batch_to_ptr(const int64_t *__restrict__ batch, int64_t n, int
   if (prev < -1) prev = -1;
   if (prev >= g) return;
   for (int64_t q = prev + 1; q <= cur && q <= g; ++q) ptr[q] = (int32_t)i;
+}
+
+__global__ void k_batch_to_ptr(const int64_t *__restrict__ batch, int64_t n, int64_t g, int32_t *__restrict__ ptr,
+                               int32_t *err) {
+  batch_to_ptr_slot(batch, n, g, ptr, err, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---- group an int32 key array (e.g. the CSR rows' source node) by key: the transposed CSR that
@@ -255,16 +339,11 @@ int launch_group_by_key(const int32_t *keys, int64_t count, int64_t num_keys, in
   int32_t *cursor = reinterpret_cast<int32_t *>(ws + gs_align_up((size_t)num_keys * 4, 256));
   int32_t *tile_sums = reinterpret_cast<int32_t *>(ws + 2 * gs_align_up((size_t)num_keys * 4, 256));
   const int64_t zero_ints = 2 * (int64_t)gs_align_up((size_t)num_keys * 4, 256) / 4;
-  const int64_t tiles = gs_ceil_div(num_keys, kScanTile);
   hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)gs_ceil_div(zero_ints, 256)), dim3(256), 0, st, counts, zero_ints);
   if (count > 0)
     hipLaunchKernelGGL(k_count_keys, dim3((unsigned)gs_ceil_div(count, 256)), dim3(256), 0, st, keys, count, num_keys,
                        counts);
-  hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)tiles), dim3(kScanBlock), 0, st, counts, num_keys, 0, rowptr,
-                     tile_sums);
-  hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kScanBlock), 0, st, tile_sums, tiles, rowptr, num_keys);
-  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)gs_ceil_div(num_keys, 256)), dim3(256), 0, st, rowptr, tile_sums,
-                     num_keys);
+  launch_exclusive_scan(counts, num_keys, 0, rowptr, tile_sums, st);
   if (count > 0) {
     hipLaunchKernelGGL(k_fill_by_key, dim3((unsigned)gs_ceil_div(count, 256)), dim3(256), 0, st, keys, count, num_keys,
                        rowptr, cursor, rows);
@@ -291,18 +370,18 @@ extern "C" size_t gnnsaft_csr_workspace_bytes(int64_t num_nodes, int64_t num_edg
          gs_align_up((size_t)(num_edges + num_nodes + 1) * 4, 256);  // eid lives in the loop-padded row space
 }
 
-extern "C" int gnnsaft_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_t num_nodes,
-                                 int64_t num_edges, int32_t num_bond_cols, const int32_t *bond_dims_host,
-                                 int32_t self_loops, int32_t *rowptr, int32_t *src, int32_t *dst, int32_t *combo,
-                                 float *log_amp, float *log_att, int32_t *err_flag, void *workspace,
-                                 size_t workspace_bytes, gnnsaft_stream_t stream) {
+int gs::launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_t num_nodes, int64_t num_edges,
+                         int32_t num_bond_cols, const int32_t *bond_dims_host, int32_t self_loops, int32_t *rowptr,
+                         int32_t *src, int32_t *dst, int32_t *combo, float *log_amp, float *log_att,
+                         int32_t *err_flag, void *workspace, size_t workspace_bytes, const int64_t *batch,
+                         int64_t num_graphs, int32_t *graph_ptr, int32_t *degree_block_hist, hipStream_t st) {
   GS_REQUIRE(rowptr && src && dst && combo && log_amp && log_att && workspace, GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_edges == 0 || (edge_index != nullptr && edge_attr != nullptr), GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_nodes >= 0 && num_edges >= 0, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(num_nodes + num_edges < ((int64_t)1 << 31) - 1, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(num_bond_cols >= 0 && num_bond_cols <= GNNSAFT_MAX_TABLES, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(workspace_bytes >= gnnsaft_csr_workspace_bytes(num_nodes, num_edges), GNNSAFT_ERR_WORKSPACE);
-  hipStream_t st = static_cast<hipStream_t>(stream);
+  GS_REQUIRE(graph_ptr == nullptr || batch != nullptr || num_graphs == 1, GNNSAFT_ERR_SHAPE);
   const int64_t n = num_nodes, e = num_edges;
   const int64_t tiles = gs_ceil_div(n > 0 ? n : 1, gs::kScanTile);
   char *ws = static_cast<char *>(workspace);
@@ -328,25 +407,35 @@ extern "C" int gnnsaft_csr_build(const int64_t *edge_index, const int64_t *edge_
   if (n > 0) {
     // counts and cursor are adjacent up to alignment: zero both
     hipLaunchKernelGGL(gs::k_zero_i32, dim3((unsigned)gs_ceil_div(2 * (int64_t)gs_align_up((size_t)n * 4, 256) / 4, tb)),
-                       dim3(tb), 0, st, counts, 2 * (int64_t)gs_align_up((size_t)n * 4, 256) / 4);
+                       dim3(tb), 0, st, counts, 2 * (int64_t)gs_align_up((size_t)n * 4, 256) / 4, nullptr);
   }
-  if (e > 0 && n > 0)
-    hipLaunchKernelGGL(gs::k_count_in_degree, dim3((unsigned)gs_ceil_div(e, tb)), dim3(tb), 0, st, edge_index, n, e,
-                       counts, err_flag);
-  hipLaunchKernelGGL(gs::k_scan_tiles, dim3((unsigned)tiles), dim3(gs::kScanBlock), 0, st, counts, n,
-                     self_loops ? 1 : 0, rowptr, tile_sums);
-  hipLaunchKernelGGL(gs::k_scan_tile_sums, dim3(1), dim3(gs::kScanBlock), 0, st, tile_sums, tiles, rowptr, n);
+  // in-degree histogram (+ graph offsets from `batch` in the same launch when asked for)
+  const int64_t count_threads = graph_ptr != nullptr ? (e > n + 1 ? e : n + 1) : e;
+  if (n > 0 && count_threads > 0)
+    hipLaunchKernelGGL(gs::k_count_in_degree, dim3((unsigned)gs_ceil_div(count_threads, tb)), dim3(tb), 0, st,
+                       edge_index, n, e, counts, err_flag, batch, num_graphs, graph_ptr);
+  gs::launch_exclusive_scan(counts, n, self_loops ? 1 : 0, rowptr, tile_sums, st);
   if (n > 0) {
-    hipLaunchKernelGGL(gs::k_scan_add, dim3((unsigned)gs_ceil_div(n, tb)), dim3(tb), 0, st, rowptr, tile_sums, n);
     if (e > 0)
       hipLaunchKernelGGL(gs::k_fill_edge_ids, dim3((unsigned)gs_ceil_div(e, tb)), dim3(tb), 0, st, edge_index, n, e,
                          rowptr, cursor, eid);
-    hipLaunchKernelGGL(gs::k_finish_rows, dim3((unsigned)gs_ceil_div(n, tb)), dim3(tb), 0, st, edge_index, edge_attr,
+    const int fb = degree_block_hist != nullptr ? gs::kDegBlock : tb;
+    hipLaunchKernelGGL(gs::k_finish_rows, dim3((unsigned)gs_ceil_div(n, fb)), dim3(fb), 0, st, edge_index, edge_attr,
                        n, e, bd, self_loops ? 1 : 0, rowptr, counts, eid, src, dst, combo, log_amp, log_att,
-                       err_flag);
+                       err_flag, degree_block_hist);
   }
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_t num_nodes,
+                                 int64_t num_edges, int32_t num_bond_cols, const int32_t *bond_dims_host,
+                                 int32_t self_loops, int32_t *rowptr, int32_t *src, int32_t *dst, int32_t *combo,
+                                 float *log_amp, float *log_att, int32_t *err_flag, void *workspace,
+                                 size_t workspace_bytes, gnnsaft_stream_t stream) {
+  return gs::launch_csr_build(edge_index, edge_attr, num_nodes, num_edges, num_bond_cols, bond_dims_host, self_loops,
+                              rowptr, src, dst, combo, log_amp, log_att, err_flag, workspace, workspace_bytes, nullptr,
+                              0, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gnnsaft_batch_to_ptr(const int64_t *batch, int64_t num_nodes, int64_t num_graphs, int32_t *graph_ptr,

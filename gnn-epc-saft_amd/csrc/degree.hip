@@ -14,67 +14,58 @@
 
 namespace gs {
 
-__device__ __forceinline__ int clamp_degree(int d, int32_t *err) {
-  if (d >= kDegreeBuckets) {
-    if (err) atomicOr(err, GNNSAFT_FLAG_BAD_DEGREE);
-    d = kDegreeBuckets - 1;
-  }
-  return d;
-}
-
-constexpr int kDegBlock = 1024;  // nodes per workgroup in the bucketing passes (16 waves)
-
-// Per-wave counts of every degree among this wave's nodes -> wcount[wave][bucket] (LDS), and
-// the lane's rank among the wave's nodes of the same degree.  No atomics: deterministic.
-__device__ __forceinline__ int wave_degree_ranks(int d, bool live, int32_t (*wcount)[kDegreeBuckets]) {
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  int rank = 0;
-  unsigned long long todo = __ballot(live);
-  while (todo != 0ull) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int dl = __shfl(d, leader);
-    const unsigned long long same = __ballot(live && d == dl);
-    if (lane == leader) wcount[wave][dl] = __popcll(same);
-    if (live && d == dl) rank = __popcll(same & ((1ull << lane) - 1ull));
-    todo &= ~same;
-  }
-  return rank;
-}
-
 // pass 1: block_hist[b][d] = number of nodes with (clamped) in-degree d in block b
 __global__ __launch_bounds__(kDegBlock) void k_degree_block_hist(const int32_t *__restrict__ rowptr, int64_t n,
                                                                  int32_t *__restrict__ block_hist, int32_t *err) {
-  __shared__ int32_t wcount[kDegBlock / 64][kDegreeBuckets];
-  for (int t = threadIdx.x; t < (kDegBlock / 64) * kDegreeBuckets; t += kDegBlock) (&wcount[0][0])[t] = 0;
-  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * kDegBlock + threadIdx.x;
   const bool live = i < n;
   const int d = live ? clamp_degree(rowptr[i + 1] - rowptr[i], err) : 0;
-  wave_degree_ranks(d, live, wcount);
-  __syncthreads();
-  if (threadIdx.x < kDegreeBuckets) {
-    int tot = 0;
-    for (int w = 0; w < kDegBlock / 64; ++w) tot += wcount[w][threadIdx.x];
-    block_hist[(int64_t)blockIdx.x * kDegreeBuckets + threadIdx.x] = tot;
-  }
+  block_degree_hist(d, live, block_hist);
 }
 
-// pass 2 (one workgroup): per-bucket exclusive scan over blocks (in place), bucket starts, tile table
+// pass 2 (one workgroup): per-bucket exclusive scan over blocks (in place), bucket starts, tile table.
+// 8 lanes x 32 buckets: every lane scans a contiguous run of blocks, the lane totals are chained through LDS.
 __global__ __launch_bounds__(256) void k_degree_plan(int32_t *__restrict__ block_hist, int64_t num_blocks,
                                                      int tile_rows, int32_t *__restrict__ hist,
                                                      int32_t *__restrict__ start, int32_t *__restrict__ tiles,
                                                      int32_t *__restrict__ num_tiles) {
+  constexpr int kLanes = 256 / kDegreeBuckets;
+  __shared__ int32_t s_lane[kLanes][kDegreeBuckets];
   __shared__ int32_t s_cnt[kDegreeBuckets], s_start[kDegreeBuckets], s_tile0[kDegreeBuckets + 1];
-  if (threadIdx.x < kDegreeBuckets) {
-    int run = 0;
-    for (int64_t b = 0; b < num_blocks; ++b) {
-      const int c = block_hist[b * kDegreeBuckets + threadIdx.x];
-      block_hist[b * kDegreeBuckets + threadIdx.x] = run;
-      run += c;
+  const int bucket = threadIdx.x % kDegreeBuckets, lane = threadIdx.x / kDegreeBuckets;
+  const int64_t per_lane = (num_blocks + kLanes - 1) / kLanes;
+  const int64_t b_beg = lane * per_lane;
+  int64_t b_end = b_beg + per_lane;
+  if (b_end > num_blocks) b_end = num_blocks;
+  int sum = 0;
+  for (int64_t b0 = b_beg; b0 < b_end; b0 += 8) {
+    int c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = b0 + u < b_end ? block_hist[(b0 + u) * kDegreeBuckets + bucket] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += c[u];
+  }
+  s_lane[lane][bucket] = sum;
+  __syncthreads();
+  int run = 0, total = 0;
+  for (int l = 0; l < kLanes; ++l) {
+    const int v = s_lane[l][bucket];
+    if (l < lane) run += v;
+    total += v;
+  }
+  for (int64_t b0 = b_beg; b0 < b_end; b0 += 8) {
+    int c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = b0 + u < b_end ? block_hist[(b0 + u) * kDegreeBuckets + bucket] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (b0 + u < b_end) block_hist[(b0 + u) * kDegreeBuckets + bucket] = run;
+      run += c[u];
     }
-    s_cnt[threadIdx.x] = run;
-    hist[threadIdx.x] = run;
+  }
+  if (lane == 0) {
+    s_cnt[bucket] = total;
+    hist[bucket] = total;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -213,16 +204,16 @@ extern "C" size_t gnnsaft_degree_scratch_ints(int64_t num_nodes) {
   return (size_t)(2 + gs_ceil_div(num_nodes > 0 ? num_nodes : 1, gs::kDegBlock)) * gs::kDegreeBuckets;
 }
 
-extern "C" int gnnsaft_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm,
-                                    int32_t *tiles, int32_t *num_tiles, int32_t *scratch, int32_t *err_flag,
-                                    gnnsaft_stream_t stream) {
+int gs::launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm, int32_t *tiles,
+                            int32_t *num_tiles, int32_t *scratch, int32_t *err_flag, bool have_block_hist,
+                            hipStream_t st) {
   GS_REQUIRE(rowptr && perm && tiles && num_tiles && scratch, GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_nodes >= 1 && hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   int32_t *hist = scratch, *start = scratch + gs::kDegreeBuckets, *block_hist = scratch + 2 * gs::kDegreeBuckets;
   const int64_t nb = gs_ceil_div(num_nodes, gs::kDegBlock);
-  hipLaunchKernelGGL(gs::k_degree_block_hist, dim3((unsigned)nb), dim3(gs::kDegBlock), 0, st, rowptr, num_nodes,
-                     block_hist, err_flag);
+  if (!have_block_hist)  // otherwise launch_csr_build's last kernel already left it there
+    hipLaunchKernelGGL(gs::k_degree_block_hist, dim3((unsigned)nb), dim3(gs::kDegBlock), 0, st, rowptr, num_nodes,
+                       block_hist, err_flag);
   hipLaunchKernelGGL(gs::k_degree_plan, dim3(1), dim3(256), 0, st, block_hist, nb, gs::pna_fold_tile_rows(hidden),
                      hist, start, tiles, num_tiles);
   hipLaunchKernelGGL(gs::k_degree_fill, dim3((unsigned)nb), dim3(gs::kDegBlock), 0, st, rowptr, num_nodes,
@@ -231,12 +222,29 @@ extern "C" int gnnsaft_degree_tiles(const int32_t *rowptr, int64_t num_nodes, in
   return GNNSAFT_OK;
 }
 
+extern "C" int gnnsaft_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm,
+                                    int32_t *tiles, int32_t *num_tiles, int32_t *scratch, int32_t *err_flag,
+                                    gnnsaft_stream_t stream) {
+  return gs::launch_degree_tiles(rowptr, num_nodes, hidden, perm, tiles, num_tiles, scratch, err_flag, false,
+                                 static_cast<hipStream_t>(stream));
+}
+
 extern "C" int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const float *const *w_post0_host,
                                                    const float *const *w_post1_host,
                                                    const float *const *avg_deg_log_host,
                                                    const float *const *w_pre0_host, const float *const *w_pre1_host,
                                                    float *g_scratch, const int32_t *hist, int32_t hidden,
                                                    float *w_eff, int64_t layer_stride, gnnsaft_stream_t stream) {
+  return gs::launch_fold_post_weights(num_layers, w_post0_host, w_post1_host, avg_deg_log_host, w_pre0_host,
+                                      w_pre1_host, g_scratch, hist, hidden, w_eff, layer_stride, 3,
+                                      static_cast<hipStream_t>(stream));
+}
+
+int gs::launch_fold_post_weights(int32_t num_layers, const float *const *w_post0_host,
+                                 const float *const *w_post1_host, const float *const *avg_deg_log_host,
+                                 const float *const *w_pre0_host, const float *const *w_pre1_host, float *g_scratch,
+                                 const int32_t *hist, int32_t hidden, float *w_eff, int64_t layer_stride, int phases,
+                                 hipStream_t st) {
   GS_REQUIRE(w_post0_host && w_post1_host && avg_deg_log_host && hist && w_eff, GNNSAFT_ERR_NULL);
   GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(num_layers >= 1 && num_layers <= GNNSAFT_MAX_FOLD_LAYERS, GNNSAFT_ERR_SHAPE);
@@ -254,15 +262,16 @@ extern "C" int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const flo
     GS_REQUIRE(fl.w0[i] && fl.w1[i] && fl.avg[i], GNNSAFT_ERR_NULL);
     GS_REQUIRE(!fold_dst || (fl.pre0[i] && fl.pre1[i]), GNNSAFT_ERR_NULL);
   }
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (fold_dst) {
+  if (fold_dst && (phases & 1)) {
     const dim3 gridg((unsigned)(hidden / 32), (unsigned)(hidden / 2 / 32), (unsigned)(6 * num_layers));
     hipLaunchKernelGGL(gs::k_dst_fold, gridg, dim3(256), 0, st, fl, hidden, g_scratch);
   }
-  const int64_t threads = (int64_t)(hidden / 2) * (5 * hidden / 4);
-  const dim3 grid((unsigned)gs_ceil_div(threads, 256), 2, (unsigned)(gs::kDegreeBuckets * num_layers));
-  hipLaunchKernelGGL(gs::k_fold_post_weights, grid, dim3(256), 0, st, fl, hist, hidden, w_eff, layer_stride,
-                     fold_dst ? g_scratch : nullptr);
+  if (phases & 2) {
+    const int64_t threads = (int64_t)(hidden / 2) * (5 * hidden / 4);
+    const dim3 grid((unsigned)gs_ceil_div(threads, 256), 2, (unsigned)(gs::kDegreeBuckets * num_layers));
+    hipLaunchKernelGGL(gs::k_fold_post_weights, grid, dim3(256), 0, st, fl, hist, hidden, w_eff, layer_stride,
+                       fold_dst ? g_scratch : nullptr);
+  }
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }

@@ -27,6 +27,37 @@ struct gnnsaft_profile {
   std::vector<uint32_t> kind;
 };
 
+// Side stream for the structure chain (K0: CSR, graph ptr, degree tiles, folded weights).  It depends only on
+// edge_index / batch / weights, the embedding + edge-table + first message GEMM chain only on x / weights, so the
+// two run concurrently between a fork and a join event (captured as parallel branches under hipGraph capture).
+struct gnnsaft_aux {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+
+extern "C" int gnnsaft_aux_create(gnnsaft_aux **out) {
+  if (out == nullptr) return GNNSAFT_ERR_NULL;
+  gnnsaft_aux *a = new (std::nothrow) gnnsaft_aux();
+  if (a == nullptr) return GNNSAFT_ERR_WORKSPACE;
+  hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&a->fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&a->join, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    gnnsaft_aux_destroy(a);
+    return (int)e;
+  }
+  *out = a;
+  return GNNSAFT_OK;
+}
+
+extern "C" void gnnsaft_aux_destroy(gnnsaft_aux *a) {
+  if (a == nullptr) return;
+  if (a->fork) (void)hipEventDestroy(a->fork);
+  if (a->join) (void)hipEventDestroy(a->join);
+  if (a->stream) (void)hipStreamDestroy(a->stream);
+  delete a;
+}
+
 namespace gs {
 
 struct ProfScope {
@@ -65,7 +96,7 @@ static int linear_bn_relu(const float *a, int64_t lda, const float *w, const flo
       GS_TRY(launch_linear(a, lda, 0, 1, &ent, k, n_out, rows, n_out, k, epi, st));
     }
     GS_TRY(gnnsaft_bn_train_apply(stats, y_tmp, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt,
-                                  d->bn_momentum, d->bn_eps, residual, out, save_stat, st));
+                                  d->bn_momentum, d->bn_eps, residual, out, save_stat, ws + p.bnseg, p.bnseg_bytes, st));
   } else {
     GS_TRY(gnnsaft_bn_finalize(nullptr, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, nullptr, d->bn_momentum,
                                d->bn_eps, 0, scale, shift, st));
@@ -281,7 +312,8 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
                                const int64_t *x_idx, const int64_t *edge_index, const int64_t *edge_attr,
                                const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
                                const float *target, float *out, float *loss3, int32_t *err_flag, void *workspace,
-                               size_t workspace_bytes, gnnsaft_profile *prof, gnnsaft_stream_t stream) {
+                               size_t workspace_bytes, gnnsaft_profile *prof, gnnsaft_aux *aux,
+                               gnnsaft_stream_t stream) {
   GS_REQUIRE(d && weights_host && out && workspace, GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_weights == gnnsaft_num_weights(d), GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(num_nodes >= 1 && num_graphs >= 1 && x_idx != nullptr, GNNSAFT_ERR_SHAPE);
@@ -302,17 +334,6 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
   for (int k = 0; k < d->num_atom_cols; ++k) atom_tab[k] = wc.f();
   for (int k = 0; k < d->num_bond_cols; ++k) bond_tab[k] = wc.f();
   GS_REQUIRE(wc.ok, GNNSAFT_ERR_NULL);
-
-  // ---- K0 structure, K1 embeddings
-  GS_TRY(gnnsaft_csr_build(edge_index, edge_attr, n, num_edges, d->num_bond_cols, d->bond_dims, d->self_loops,
-                           I(p.rowptr), I(p.src), I(p.dst), I(p.combo), F(p.log_amp), F(p.log_att), err_flag,
-                           ws + p.csr_ws, gnnsaft_csr_workspace_bytes(n, num_edges), st));
-  // batch == NULL (un-batched Data, models.py:116): one graph spanning all nodes
-  GS_TRY(gnnsaft_batch_to_ptr(batch, n, g, I(p.graph_ptr), err_flag, st));
-  if (d->fold_degree_scalers)
-    GS_TRY(gnnsaft_degree_tiles(I(p.rowptr), n, h, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3), err_flag, st));
-  GS_TRY(gnnsaft_embed_sum(x_idx, n, d->num_atom_cols, atom_tab, d->atom_dims, h, F(p.x0), err_flag, st));
-  GS_TRY(gnnsaft_bond_combo_embed(d->num_bond_cols, bond_tab, d->bond_dims, h, F(p.cemb), st));
 
   // ---- parse every layer's weights, then do the x-independent prologue work of ALL layers in a
   //      few batched launches: edge-class tables (edge_encoder + pre_nns[t][0] edge block) and the
@@ -349,6 +370,48 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
   const int64_t cstride = p.combos * (int64_t)h;          // floats per layer in cenc
   const int64_t rstride = p.combos * (int64_t)(2 * h);    // floats per layer in rtab
   const int64_t wstride = (int64_t)kDegreeBuckets * 5 * h * h;  // floats per layer in weff
+  // ---- K0 structure chain, on the side stream when the caller lends one: destination-term fold (weights only),
+  //      CSR, graph offsets, degree tiles, degree-folded update weights
+  hipStream_t sa = st;
+  if (aux != nullptr) {
+    sa = aux->stream;
+    GS_HIP(hipEventRecord(aux->fork, st));
+    GS_HIP(hipStreamWaitEvent(sa, aux->fork, 0));
+  }
+  auto fold_weights = [&](int phases) -> int {
+    for (int l0 = 0; l0 < d->num_layers; l0 += GNNSAFT_MAX_FOLD_LAYERS) {
+      const int nl = d->num_layers - l0 < GNNSAFT_MAX_FOLD_LAYERS ? d->num_layers - l0 : GNNSAFT_MAX_FOLD_LAYERS;
+      const float *w0[GNNSAFT_MAX_FOLD_LAYERS], *w1[GNNSAFT_MAX_FOLD_LAYERS], *av[GNNSAFT_MAX_FOLD_LAYERS];
+      const float *p0[GNNSAFT_MAX_FOLD_LAYERS], *p1[GNNSAFT_MAX_FOLD_LAYERS];
+      for (int i = 0; i < nl; ++i) {
+        w0[i] = lw[l0 + i].wpost[0][0];
+        w1[i] = lw[l0 + i].wpost[1][0];
+        av[i] = lw[l0 + i].avg;
+        p0[i] = lw[l0 + i].wpre[0][0];
+        p1[i] = lw[l0 + i].wpre[1][0];
+      }
+      GS_TRY(launch_fold_post_weights(nl, w0, w1, av, fold_dst ? p0 : nullptr, fold_dst ? p1 : nullptr,
+                                      fold_dst ? F(p.gfold) + (int64_t)l0 * 6 * (h / 2) * h : nullptr, I(p.hist3), h,
+                                      F(p.weff) + l0 * wstride, wstride, phases, sa));
+    }
+    return GNNSAFT_OK;
+  };
+  if (d->fold_degree_scalers && fold_dst) GS_TRY(fold_weights(1));
+  // CSR + graph offsets (batch == NULL: un-batched Data, models.py:116, one graph spanning all nodes) + the first
+  // pass of the degree bucketing, in 6 launches
+  GS_REQUIRE(batch != nullptr || g == 1, GNNSAFT_ERR_SHAPE);
+  GS_TRY(launch_csr_build(edge_index, edge_attr, n, num_edges, d->num_bond_cols, d->bond_dims, d->self_loops,
+                          I(p.rowptr), I(p.src), I(p.dst), I(p.combo), F(p.log_amp), F(p.log_att), err_flag,
+                          ws + p.csr_ws, gnnsaft_csr_workspace_bytes(n, num_edges), batch, g, I(p.graph_ptr),
+                          d->fold_degree_scalers ? I(p.hist3) + 2 * kDegreeBuckets : nullptr, sa));
+  if (d->fold_degree_scalers)
+    GS_TRY(launch_degree_tiles(I(p.rowptr), n, h, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3), err_flag, true,
+                               sa));
+  if (d->fold_degree_scalers) GS_TRY(fold_weights(2));
+  // ---- K1 embeddings and the edge-class tables of all layers, on the caller's stream
+  GS_TRY(gnnsaft_embed_sum(x_idx, n, d->num_atom_cols, atom_tab, d->atom_dims, h, F(p.x0), err_flag, st));
+  GS_TRY(gnnsaft_bond_combo_embed(d->num_bond_cols, bond_tab, d->bond_dims, h, F(p.cemb), st));
+
   for (int l0 = 0; l0 < d->num_layers; l0 += kMaxGemmBatch) {
     const int nl = d->num_layers - l0 < kMaxGemmBatch ? d->num_layers - l0 : kMaxGemmBatch;
     GemmBatchEntry e[kMaxGemmBatch];
@@ -366,23 +429,15 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     LinearEpilogue epi;
     GS_TRY(launch_linear(F(p.cenc), h, 0, ne, e, 3 * (int64_t)h, 2 * (int64_t)h, p.combos, h, h, epi, st));
   }
-  if (d->fold_degree_scalers) {
-    for (int l0 = 0; l0 < d->num_layers; l0 += GNNSAFT_MAX_FOLD_LAYERS) {
-      const int nl = d->num_layers - l0 < GNNSAFT_MAX_FOLD_LAYERS ? d->num_layers - l0 : GNNSAFT_MAX_FOLD_LAYERS;
-      const float *w0[GNNSAFT_MAX_FOLD_LAYERS], *w1[GNNSAFT_MAX_FOLD_LAYERS], *av[GNNSAFT_MAX_FOLD_LAYERS];
-      const float *p0[GNNSAFT_MAX_FOLD_LAYERS], *p1[GNNSAFT_MAX_FOLD_LAYERS];
-      for (int i = 0; i < nl; ++i) {
-        w0[i] = lw[l0 + i].wpost[0][0];
-        w1[i] = lw[l0 + i].wpost[1][0];
-        av[i] = lw[l0 + i].avg;
-        p0[i] = lw[l0 + i].wpre[0][0];
-        p1[i] = lw[l0 + i].wpre[1][0];
-      }
-      GS_TRY(gnnsaft_pna_fold_post_weights_multi(nl, w0, w1, av, fold_dst ? p0 : nullptr, fold_dst ? p1 : nullptr,
-                                                 fold_dst ? F(p.gfold) + (int64_t)l0 * 6 * (h / 2) * h : nullptr,
-                                                 I(p.hist3), h, F(p.weff) + l0 * wstride, wstride, st));
+  bool joined = aux == nullptr;
+  auto join_structure = [&]() -> int {  // everything below this call may read the CSR / tiles / folded weights
+    if (!joined) {
+      GS_HIP(hipEventRecord(aux->join, sa));
+      GS_HIP(hipStreamWaitEvent(st, aux->join, 0));
+      joined = true;
     }
-  }
+    return GNNSAFT_OK;
+  };
 
   const bool tape = d->save_tape != 0;
   float *xc = F(p.x0), *xn = tape ? F(p.x0) + p.sx : F(p.x1);
@@ -408,6 +463,7 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
       else
         GS_TRY(node_terms(xc, n, h, wpre[0][0], wpre[1][0], pq_l, st));
     }
+    GS_TRY(join_structure());
     const float *msgs = nullptr;
     if (d->pre_layers > 1 && tape) {
       // keep every edge-level tensor: h1pre, then the output of each extra pre layer

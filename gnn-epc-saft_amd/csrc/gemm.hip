@@ -30,14 +30,6 @@ namespace gs {
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-__device__ __forceinline__ f32x4 gs_relu4(f32x4 v) {
-  v.x = fmaxf(v.x, 0.f);
-  v.y = fmaxf(v.y, 0.f);
-  v.z = fmaxf(v.z, 0.f);
-  v.w = fmaxf(v.w, 0.f);
-  return v;
-}
-
 // --------------------------------------------------------------------------
 // A operand providers.  Every load is UNCONDITIONAL (hipcc branches around a
 // guarded load and waits for it on the spot, serialising one L2 round trip per
@@ -222,20 +214,6 @@ struct PermPlainA {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     return (k0 + c < k) ? w.v : zero;
   }
-};
-
-struct GemmBatch {
-  GemmBatchEntry e[kMaxGemmBatch];
-};
-
-struct EpiArgs {
-  const float *scale;
-  const float *shift;
-  int relu_out;
-  const float *residual;
-  int64_t ldr;
-  float *stats;
-  int residual_is_mask;  // 1: out = residual > 0 ? v : 0 (ReLU backward) instead of v + residual
 };
 
 // --------------------------------------------------------------------------
@@ -470,7 +448,8 @@ static int pick_cfg(int64_t m, int n_out, int k, bool stats) {
     return g_cfg_override;
   // measured on MI355X (tools/gemm_tune.py, profiles/r01_gemm_tile_sweep.txt)
   if (n_out <= 32) return stats ? kCfg256x32 : kCfg128x32;
-  if (stats) return n_out <= 64 ? kCfg128x64 : kCfg128x128;
+  // stats tiles have 64-row waves; up to ~40k rows the 64-row workgroups of 64x128 spread over more CUs than 128x128
+  if (stats) return n_out <= 64 ? kCfg128x64 : (m < 40000 ? kCfg64x128 : kCfg128x128);
   if (n_out >= 128 && k >= 1024) return kCfg128x128;  // long-K update at H = 256
   return kCfg64x64;
 }

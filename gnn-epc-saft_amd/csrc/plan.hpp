@@ -12,7 +12,7 @@ struct Plan {
   int h;
   // byte offsets into the workspace
   size_t csr_ws, rowptr, src, dst, combo, log_amp, log_att, graph_ptr;
-  size_t x0, x1, pq, agg, u0, u1, y, msg0, msg1, cemb, cenc, rtab, stats, scale, shift, pooled, m0, m1, m2;
+  size_t x0, x1, pq, agg, u0, u1, y, msg0, msg1, cemb, cenc, rtab, stats, bnseg, bnseg_bytes, scale, shift, pooled, m0, m1, m2;
   size_t perm, tiles, num_tiles, hist3, weff, gfold;
   int64_t tile_cap;
   // per-layer strides in floats (0 unless desc->save_tape: then every layer keeps its own tensors for backward)
@@ -93,6 +93,8 @@ static inline int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, i
   p.rtab = take(nl * (size_t)p.combos * 2 * h * 4);
   const size_t max_rows = nn > gg ? nn : gg;
   p.stats = take(((max_rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup) * 2 * h * 4);
+  p.bnseg_bytes = gnnsaft_bn_train_scratch_bytes((int64_t)max_rows, (int32_t)h);
+  p.bnseg = take(p.bnseg_bytes + 8);
   p.scale = take(h * 4);
   p.shift = take(h * 4);
   p.pooled = take(gg * h * 4);

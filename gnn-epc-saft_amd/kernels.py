@@ -216,9 +216,11 @@ def debug_set_gemm_config(cfg: int) -> None:
 def bn_train_apply(stats, y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum: float, eps: float,
                    residual=None) -> torch.Tensor:
     out = torch.empty_like(y)
+    need = lib.gnnsaft_bn_train_scratch_bytes(y.shape[0], y.shape[1])
+    scratch = torch.empty(max(need, 8) // 8, dtype=torch.float64, device=y.device)
     check(lib.gnnsaft_bn_train_apply(_p(stats), _p(y), y.shape[0], y.shape[1], _p(gamma), _p(beta), _p(running_mean),
                                      _p(running_var), _p(num_batches_tracked), momentum, eps, _p(residual), _p(out),
-                                     None, _stream(y)), "gnnsaft_bn_train_apply")
+                                     None, _p(scratch), need, _stream(y)), "gnnsaft_bn_train_apply")
     return out
 
 

@@ -15,13 +15,14 @@ from __future__ import annotations
 import ctypes
 import dataclasses
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
 from torch import nn
 
 from .. import _native
-from .._native import ModelDesc, check, lib
+from .._native import ModelDesc, aux_for, check, lib
 
 ATOM_FEATURE_DIMS = (119, 5, 12, 12, 10, 6, 6, 2, 2)  # ogb >= 1.3
 BOND_FEATURE_DIMS = (5, 6, 2)
@@ -159,6 +160,7 @@ class PNAPCSAFT(nn.Module):
         # to std) into those weights: removes half of the message GEMM and a quarter of K4's reads.  Used when
         # fold_degree_scalers is on, pre_layers == 1 and hidden_dim % 64 == 0; otherwise ignored.
         self.fold_dst_term = True
+        self.use_side_stream = os.environ.get("GNNSAFT_SINGLE_STREAM", "0") != "1"
         self._profile = None  # gnnsaft_profile* (bench.py attaches one to time kernels with HIP events)
 
     # ------------------------------------------------------------------ host glue
@@ -291,10 +293,12 @@ class PNAPCSAFT(nn.Module):
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
         ws_bytes = ws.numel() - (ws_ptr - ws.data_ptr())
         with torch.cuda.device(dev):
+            aux = aux_for(dev.index if dev.index is not None else torch.cuda.current_device()) \
+                if self.use_side_stream else None
             rc = lib.gnnsaft_forward(ctypes.byref(desc), wtab, nw, x.data_ptr(), edge_index.data_ptr() if e else None,
                                      edge_attr.data_ptr() if e else None,
                                      None if batch is None else batch.data_ptr(), n, e, g, tgt_ptr, out.data_ptr(),
-                                     loss_ptr, self._err_flag.data_ptr(), ws_ptr, ws_bytes, self._profile, stream)
+                                     loss_ptr, self._err_flag.data_ptr(), ws_ptr, ws_bytes, self._profile, aux, stream)
         check(rc, "gnnsaft_forward")
         ctx = None
         if tape:

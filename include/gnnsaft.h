@@ -248,14 +248,18 @@ int gnnsaft_bn_finalize(const float *stats, int64_t num_rows, int32_t channels,
                         float momentum, float eps, int32_t training,
                         float *scale, float *shift, gnnsaft_stream_t stream);
 
-/* Train-mode BatchNorm + ReLU (+ residual) in ONE launch: folds the (mean, M2) partials */
-/* of gnnsaft_linear, normalises y, updates the running statistics and the counter.      */
+/* Train-mode BatchNorm + ReLU (+ residual): folds the (mean, M2) partials of            */
+/* gnnsaft_linear, normalises y, updates the running statistics and the counter.  One    */
+/* launch up to 4096 rows; above that a small pre-combine launch folds the partials into  */
+/* <= 64 f64 segment sums in `scratch` (8-byte aligned, gnnsaft_bn_train_scratch_bytes).  */
+size_t gnnsaft_bn_train_scratch_bytes(int64_t num_rows, int32_t channels);
 int gnnsaft_bn_train_apply(const float *stats, const float *y, int64_t num_rows, int32_t channels,
                            const float *gamma, const float *beta, float *running_mean,
                            float *running_var, int64_t *num_batches_tracked, float momentum,
                            float eps, const float *residual, float *out,
                            float *save_mean_rstd /* [2*channels] or NULL: kept for backward */,
-                           gnnsaft_stream_t stream);
+                           void *scratch /* may be NULL when the size above is 0 */,
+                           size_t scratch_bytes, gnnsaft_stream_t stream);
 
 /* out = relu(y*scale + shift) (+ residual)   (models.py:128-131) */
 int gnnsaft_bn_relu_residual(const float *y, const float *scale, const float *shift,
@@ -316,6 +320,15 @@ void gnnsaft_profile_destroy(gnnsaft_profile *prof);
 int gnnsaft_profile_reset(gnnsaft_profile *prof);
 int gnnsaft_profile_summary(gnnsaft_profile *prof, uint32_t kernel_bit, int32_t *count, float *total_ms);
 
+/* Optional side stream (+ fork / join events) lent to gnnsaft_forward: the structure chain  */
+/* (CSR, graph ptr, degree tiles, folded weights) runs there, concurrently with the embedding */
+/* / edge-table / first message GEMM chain on `stream`, and is joined back before the first   */
+/* aggregation; capturable (the two chains become parallel branches of the hipGraph).  One    */
+/* handle per concurrently running forward; create it on the device it will be used on.       */
+typedef struct gnnsaft_aux gnnsaft_aux;
+int gnnsaft_aux_create(gnnsaft_aux **out);
+void gnnsaft_aux_destroy(gnnsaft_aux *aux);
+
 size_t gnnsaft_forward_workspace_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes,
                                        int64_t num_edges, int64_t num_graphs);
 
@@ -328,7 +341,7 @@ int gnnsaft_forward(const gnnsaft_model_desc *desc,
                     float *out /* [G,P] */, float *loss3 /* [3] or NULL */,
                     int32_t *err_flag /* device int32, zeroed by the caller, or NULL */,
                     void *workspace, size_t workspace_bytes, gnnsaft_profile *profile /* or NULL */,
-                    gnnsaft_stream_t stream);
+                    gnnsaft_aux *aux /* or NULL: single stream */, gnnsaft_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* Backward of the path (what autograd does when Lightning calls               */

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-step timeline of a rocprofv3 --kernel-trace CSV (kernel_trace.csv): a step ends at each k_mape.
+Prints, for the median step: wall time, summed kernel time, busy (union) time, idle gaps, and every kernel
+with its start offset, duration and the gap to the previous kernel's end.
+usage: timeline.py kernel_trace.csv [step_index_from_end]"""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda t: t[0])
+steps, cur = [], []
+for k in ks:
+    cur.append(k)
+    if "k_mape" in k[2] and "bwd" not in k[2]:
+        steps.append(cur)
+        cur = []
+if not steps:
+    sys.exit("no k_mape kernel in the trace")
+lens = [len(s) for s in steps]
+common = max(set(lens), key=lens.count)
+steps = [s for s in steps if len(s) == common]
+walls = sorted((s[-1][1] - s[0][0], i) for i, s in enumerate(steps))
+pick = walls[len(walls) // 2][1] if len(sys.argv) < 3 else len(steps) - 1 - int(sys.argv[2])
+s = steps[pick]
+t0 = s[0][0]
+busy, end = 0, t0
+for a, b, _ in s:
+    if b > end:
+        busy += b - max(a, end)
+        end = b
+wall = s[-1][1] - t0
+print(f"steps with {common} kernels: {len(steps)}; step {pick}: wall {wall / 1e3:.1f} us, kernel sum "
+      f"{sum(b - a for a, b, _ in s) / 1e3:.1f} us, busy {busy / 1e3:.1f} us, idle {(wall - busy) / 1e3:.1f} us")
+prev_end = t0
+for a, b, n in s:
+    print(f"{(a - t0) / 1e3:8.1f} +{(b - a) / 1e3:7.1f}  gap {(a - prev_end) / 1e3:6.1f}  {n[:100]}")
+    prev_end = max(prev_end, b)
