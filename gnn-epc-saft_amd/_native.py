@@ -82,6 +82,9 @@ SIGNATURES = {
     "gnnsaft_forward_workspace_map": (c_int32, [POINTER(ModelDesc), c_int64, c_int64, c_int64, POINTER(WorkspaceMap)]),
     "gnnsaft_forward": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), c_int32, P, P, P, P, c_int64, c_int64,
                                   c_int64, P, P, P, P, P, c_size_t, P, P, P]),
+    "gnnsaft_adamw_step": (c_int32, [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
+                                     c_float, P]),
+    "gnnsaft_sgd_step": (c_int32, [P, P, P, c_int64, c_float, c_float, c_float, c_int32, c_float, P]),
     "gnnsaft_aux_create": (c_int32, [POINTER(c_void_p)]),
     "gnnsaft_aux_destroy": (None, [P]),
     "gnnsaft_backward_scratch_bytes": (c_size_t, [POINTER(ModelDesc), c_int64, c_int64, c_int64]),

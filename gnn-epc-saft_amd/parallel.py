@@ -77,6 +77,31 @@ def global_mape_async(loss3: torch.Tensor) -> PendingMape:
     return PendingMape(parts, work)
 
 
+def allreduce_flat_sum(flat: torch.Tensor) -> float:
+    """SUM all-reduce of one flat gradient buffer, in place; returns the factor that turns the sum into the
+    mean (1 / world) so that the caller can fold it into its next kernel (the fused optimizers' ``grad_scale``)
+    instead of spending a launch on the division."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return 1.0 / world
+
+
+def common_gradient_buffer(params: Iterable[torch.nn.Parameter]) -> Optional[torch.Tensor]:
+    """The one flat tensor every ``.grad`` is a view of (what ``gnnsaft_backward`` leaves behind), or None."""
+    base = None
+    for p in params:
+        g = p.grad
+        b = None if g is None else getattr(g, "_base", None)
+        if b is None or b.dim() != 1 or not g.is_contiguous():
+            return None
+        if base is None:
+            base = b
+        elif b.data_ptr() != base.data_ptr():
+            return None
+    return base
+
+
 class FlatGradientAllReduce:
     """Averages gradients across ranks with a single collective over one flat buffer."""
 
@@ -88,6 +113,12 @@ class FlatGradientAllReduce:
 
     def __call__(self) -> None:
         world = dist.get_world_size() if dist.is_initialized() else 1
+        shared = common_gradient_buffer(self.params)
+        if shared is not None:     # gradients already live in one buffer: reduce it where it is
+            if world > 1:
+                dist.all_reduce(shared, op=dist.ReduceOp.SUM)
+                shared.div_(world)
+            return
         off = 0
         for p in self.params:
             n = p.numel()

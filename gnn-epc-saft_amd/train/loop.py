@@ -1,0 +1,97 @@
+"""Training-step host loop around the hot path: what Lightning's ``Trainer.fit``
+does with ``PNApcsaftL`` in ``/root/reference/gnnepcsaft/train/train.py:142-185`` -- ``max_steps`` optimizer steps,
+scheduler stepped per batch (``models.py:181-188``), ``train_mape`` logged every ``log_every_steps`` with
+``sync_dist=True`` (mean over ranks, ``models.py:195-201``), a checkpoint every ``checkpoint_every_steps``
+(``train.py:86-107``) -- without Lightning or Ray (both absent from the image; their callbacks, loggers and the
+``feos``-based validation are out of scope).
+
+One step = ``gnnsaft_forward`` (tape) -> ``gnnsaft_mape`` / ``gnnsaft_mape_backward`` -> ``gnnsaft_backward``
+(every gradient into ONE flat buffer) -> [data-parallel: one RCCL all-reduce(SUM) of that buffer; the 1/world
+average is folded into the optimizer kernel] -> ``gnnsaft_adamw_step`` / ``gnnsaft_sgd_step`` on the flat parameter
+buffer.  No host synchronisation inside a step; the loss is read back only when it is logged.
+"""
+
+from __future__ import annotations
+
+import os
+from typing import Callable, Iterable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from ..parallel import allreduce_flat_sum
+from .checkpoint import lightning_checkpoint, resume, save_checkpoint
+from .models import PNApcsaftL, _cfg
+
+
+def _world() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def allreduce_gradients(optimizer) -> None:
+    """Data-parallel exchange of one step: SUM all-reduce of the flat gradient buffer, averaging deferred to the
+    optimizer kernel (``grad_scale``).  One collective of 2-28 MB for the reference's model sizes."""
+    optimizer.grad_scale = allreduce_flat_sum(optimizer._flat_grad())
+
+
+def training_loop(lit: PNApcsaftL, batches: Iterable, max_steps: Optional[int] = None, *,
+                  log_every_steps: Optional[int] = None, checkpoint_every_steps: Optional[int] = None,
+                  workdir: Optional[str] = None, resume_from=None,
+                  on_log: Optional[Callable[[int, float, float], None]] = None) -> List[Tuple[int, float]]:
+    """Runs ``max_steps`` (default ``config.num_train_steps``) training steps over ``batches`` (any re-iterable of
+    device-resident PyG-like batches with ``para``; iterated again when exhausted, i.e. epochs) and returns the
+    logged ``(step, train_mape)`` pairs.  Rank 0 writes Lightning-dialect checkpoints under
+    ``workdir/train/checkpoints`` when asked to."""
+    cfg = lit.config
+    if max_steps is None:
+        max_steps = int(_cfg(cfg, "num_train_steps"))
+    if log_every_steps is None:
+        log_every_steps = int(_get(cfg, "log_every_steps", 50))
+    if checkpoint_every_steps is None:
+        checkpoint_every_steps = int(_get(cfg, "checkpoint_every_steps", 0))
+    conf = lit.configure_optimizers()
+    opt, sched = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    step = 0
+    if resume_from is not None:
+        step = resume(resume_from, opt, sched)
+    lit.train()
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = _world()
+    history: List[Tuple[int, float]] = []
+    epoch = 0
+    while step < max_steps:
+        seen = 0
+        for batch in batches:
+            if step >= max_steps:
+                break
+            seen += 1
+            opt.zero_grad(set_to_none=True)
+            loss = lit.training_step(batch, seen - 1)
+            loss.backward()
+            allreduce_gradients(opt)
+            opt.step()
+            sched.step()
+            step += 1
+            if log_every_steps and step % log_every_steps == 0:
+                logged = loss.detach().clone()
+                if world > 1:   # sync_dist=True: mean of the per-rank means
+                    dist.all_reduce(logged, op=dist.ReduceOp.SUM)
+                    logged /= world
+                value = float(logged)   # the only host sync of the loop
+                history.append((step, value))
+                if on_log is not None and rank == 0:
+                    on_log(step, value, float(opt.param_groups[0]["lr"]))
+            if checkpoint_every_steps and workdir and step % checkpoint_every_steps == 0 and rank == 0:
+                save_checkpoint(lightning_checkpoint(lit, opt, sched, step, epoch),
+                                os.path.join(workdir, "train", "checkpoints", f"step={step}.ckpt"))
+        if seen == 0:
+            raise ValueError("training_loop got an empty batch iterable")
+        epoch += 1
+    return history
+
+
+def _get(cfg, name, default):
+    try:
+        return _cfg(cfg, name)
+    except (KeyError, AttributeError):
+        return default

@@ -161,6 +161,8 @@ class PNAPCSAFT(nn.Module):
         # fold_degree_scalers is on, pre_layers == 1 and hidden_dim % 64 == 0; otherwise ignored.
         self.fold_dst_term = True
         self.use_side_stream = os.environ.get("GNNSAFT_SINGLE_STREAM", "0") != "1"
+        # backward fast path: set .grad to views of the one flat gradient buffer when every .grad is None
+        self.direct_grads = True
         self._profile = None  # gnnsaft_profile* (bench.py attaches one to time kernels with HIP events)
 
     # ------------------------------------------------------------------ host glue
@@ -306,13 +308,27 @@ class PNAPCSAFT(nn.Module):
                        ws_bytes=ws_bytes, dev=dev)
         return out, loss, ctx
 
+    def flat_layout(self):
+        """``(params, offsets, total)``: the slice of ONE flat f32 buffer each trainable tensor of the weight table
+        owns (weight-table order, 64-float aligned).  ``gnnsaft_backward`` writes its gradients in this layout; the
+        fused optimizers (train/optim.py) and the gradient all-reduce (parallel.py) adopt it, so that a training
+        step touches one gradient buffer and one parameter buffer instead of ~50 tensors."""
+        params, offsets, off = [], [], 0
+        for t in self._weight_tensors():
+            if t.dtype == torch.float32 and isinstance(t, nn.Parameter):
+                params.append(t)
+                offsets.append(off)
+                off += (t.numel() + 63) // 64 * 64
+        return params, offsets, off
+
     def _backward(self, ctx, grad_out: torch.Tensor):
         """gnnsaft_backward: gradients of every float parameter of the weight table (None for buffers)."""
         desc, weights, dev = ctx["desc"], ctx["weights"], ctx["dev"]
         nw = len(weights)
-        # one flat buffer, gradients are views into it (one allocation; also the layout a flat all-reduce wants)
+        # one flat buffer, gradients are views into it (one allocation; also the layout a flat all-reduce wants);
+        # zero-filled so that the alignment gaps hold no garbage for whoever consumes the buffer whole
         sizes = [t.numel() if (t.dtype == torch.float32 and isinstance(t, nn.Parameter)) else 0 for t in weights]
-        flat = torch.empty(sum((s + 63) // 64 * 64 for s in sizes), dtype=torch.float32, device=dev)
+        flat = torch.zeros(sum((s + 63) // 64 * 64 for s in sizes), dtype=torch.float32, device=dev)
         grads, off = [], 0
         for t, sz in zip(weights, sizes):
             grads.append(flat[off:off + sz].view(t.shape) if sz else None)
@@ -374,7 +390,15 @@ class _PNAForwardFunction(torch.autograd.Function):
         grads = ctx.module._backward(ctx.tape, grad_out)
         by_id = {id(w): g for w, g in zip(ctx.tape["weights"], grads)}
         ctx.tape = None  # the tape (workspace) can be freed now
-        return (None, None) + tuple(by_id.get(id(p)) for p in ctx.params)
+        out = [by_id.get(id(p)) for p in ctx.params]
+        if ctx.module.direct_grads and all(p.grad is None and not p._backward_hooks for p in ctx.params):
+            # Every .grad is unset (zero_grad(set_to_none=True), torch's and Lightning's default): hand the views of
+            # the flat gradient buffer over as they are.  Returning them to autograd instead would make
+            # AccumulateGrad clone each one (~50 copy launches) and scatter them over separate allocations.
+            for p, g in zip(ctx.params, out):
+                p.grad = g
+            return (None, None) + (None,) * len(out)
+        return (None, None) + tuple(out)   # accumulate into existing .grad the autograd way
 
 
 class _MapeFunction(torch.autograd.Function):
@@ -437,14 +461,20 @@ class PNApcsaftL(nn.Module):
 
     def configure_optimizers(self):
         """models.py:162-188."""
+        from .optim import FusedAdamW, FusedSGD
         opt_name = _cfg(self.config, "optimizer")
+        params, offsets, total = self.model.flat_layout()
+        params = [p for p in params]
+        if any(not p.requires_grad for p in params):      # frozen tensors: let the optimizer lay out what is left
+            params, layout = [p for p in params if p.requires_grad], None
+        else:
+            layout = (offsets, total)
         if opt_name == "adam":
-            opt = torch.optim.AdamW(self.parameters(), lr=_cfg(self.config, "learning_rate"),
-                                    weight_decay=_cfg(self.config, "weight_decay"), amsgrad=True, eps=1e-5)
+            opt = FusedAdamW(params, lr=_cfg(self.config, "learning_rate"),
+                             weight_decay=_cfg(self.config, "weight_decay"), amsgrad=True, eps=1e-5, layout=layout)
         elif opt_name == "sgd":
-            opt = torch.optim.SGD(self.parameters(), lr=_cfg(self.config, "learning_rate"),
-                                  momentum=_cfg(self.config, "momentum"),
-                                  weight_decay=_cfg(self.config, "weight_decay"), nesterov=True)
+            opt = FusedSGD(params, lr=_cfg(self.config, "learning_rate"), momentum=_cfg(self.config, "momentum"),
+                           weight_decay=_cfg(self.config, "weight_decay"), nesterov=True, layout=layout)
         else:
             raise ValueError(f"Unsupported optimizer: {opt_name}.")
         sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, _cfg(self.config, "warmup_steps"))

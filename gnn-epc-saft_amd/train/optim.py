@@ -1,0 +1,201 @@
+"""Fused optimizers over one flat parameter buffer -- the optimizer half of the training-step host loop
+(SURVEY.md section 8(f) rank 2).  Drop-ins for what ``configure_optimizers`` builds at
+``/root/reference/gnnepcsaft/train/models.py:162-178``: ``torch.optim.AdamW(amsgrad=True, eps=1e-5)`` and
+``torch.optim.SGD(nesterov=True)``.  Both are ``torch.optim.Optimizer`` subclasses, so ``param_groups[0]["lr"]``
+schedulers (``CosineAnnealingWarmRestarts``), ``zero_grad`` and ``state_dict`` / ``load_state_dict`` in torch's
+per-parameter format keep working; one step is ONE HIP launch (``gnnsaft_adamw_step`` / ``gnnsaft_sgd_step``).
+
+Layout: every parameter's ``.data`` is re-pointed at a slice of one flat f32 buffer (offsets padded to 64
+floats).  With ``layout=model.flat_layout()`` the slices coincide with the flat gradient buffer
+``gnnsaft_backward`` writes, so the step consumes that buffer as it is -- no gather, no per-tensor launches;
+any other gradient source is gathered into a flat buffer first (slower, still correct).
+"""
+
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from .._native import check, lib
+
+_PAD = 64  # floats; matches PNAPCSAFT._backward
+
+
+def default_layout(params: Sequence[torch.nn.Parameter]) -> Tuple[List[int], int]:
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + _PAD - 1) // _PAD * _PAD
+    return offs, off
+
+
+class _FlatOptimizer(torch.optim.Optimizer):
+    _STATE_KEYS: Tuple[str, ...] = ()
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], defaults: dict,
+                 layout: Optional[Tuple[Sequence[int], int]] = None):
+        params = list(params)
+        if any(isinstance(p, dict) for p in params):
+            raise NotImplementedError("one parameter group only (the reference builds one: models.py:163-178)")
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError("optimizer got an empty parameter list")
+        super().__init__(params, defaults)
+        self._params: List[torch.nn.Parameter] = params
+        dev = params[0].device
+        for p in params:
+            if p.device != dev or p.dtype != torch.float32 or not p.is_cuda:
+                raise RuntimeError("fused optimizers need float32 parameters on one HIP device: move the module "
+                                   "to the GPU before configure_optimizers()")
+        self._offsets, self._total = (list(layout[0]), int(layout[1])) if layout is not None else default_layout(params)
+        if len(self._offsets) != len(params):
+            raise ValueError("layout does not match the parameter list")
+        self._flat: Optional[torch.Tensor] = None
+        self._flat_state = {}
+        self._gather: Optional[torch.Tensor] = None
+        self._steps = 0
+        self.grad_scale = 1.0          # set to 1 / world_size by the data-parallel loop (SUM all-reduce)
+        self._adopt()
+
+    # ---- flat parameter buffer
+    def _adopt(self) -> None:
+        """(Re-)point every parameter at its slice of the flat buffer; needed again after module.to() / load."""
+        dev = self._params[0].device
+        flat = torch.zeros(self._total, dtype=torch.float32, device=dev)
+        for p, off in zip(self._params, self._offsets):
+            view = flat[off:off + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+        self._flat = flat
+
+    def _adopted(self) -> bool:
+        base = self._flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * off and p.is_contiguous() for p, off in zip(self._params, self._offsets))
+
+    def _state_buffer(self, key: str) -> torch.Tensor:
+        buf = self._flat_state.get(key)
+        if buf is None:
+            buf = self._flat_state[key] = torch.zeros_like(self._flat)
+            for p, off in zip(self._params, self._offsets):   # torch-format views, so state_dict() just works
+                self.state[p][key] = buf[off:off + p.numel()].view(p.shape)
+        return buf
+
+    def _flat_grad(self) -> torch.Tensor:
+        """The gradients as one flat tensor in this optimizer's layout: zero-copy when they already are one."""
+        first = self._params[0].grad
+        if first is None:
+            raise RuntimeError("step() without gradients")
+        base = first.data_ptr() - 4 * self._offsets[0]
+        zero_copy = all(p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
+                        and p.grad.data_ptr() == base + 4 * off for p, off in zip(self._params, self._offsets))
+        owner = getattr(first, "_base", None)
+        if zero_copy and owner is not None and owner.dim() == 1 and owner.data_ptr() == base \
+                and owner.numel() >= self._total:
+            return owner
+        if self._gather is None:
+            self._gather = torch.zeros_like(self._flat)
+        for p, off in zip(self._params, self._offsets):
+            dst = self._gather[off:off + p.numel()].view(p.shape)
+            if p.grad is None:
+                dst.zero_()
+            else:
+                dst.copy_(p.grad)
+        return self._gather
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)          # torch's loader leaves freshly cloned per-parameter tensors
+        loaded = {id(p): dict(self.state[p]) for p in self._params if p in self.state}
+        self._flat_state = {}
+        steps = 0
+        for key in self._STATE_KEYS:
+            if any(key in st for st in loaded.values()):
+                buf = self._state_buffer(key)
+                for p, off in zip(self._params, self._offsets):
+                    src = loaded.get(id(p), {}).get(key)
+                    if src is not None:
+                        buf[off:off + p.numel()].view(p.shape).copy_(src)
+        for p in self._params:
+            st = loaded.get(id(p), {})
+            if "step" in st:
+                steps = max(steps, int(float(st["step"])))
+                self.state[p]["step"] = torch.tensor(float(steps))
+        self._steps = steps
+
+    def _tick(self) -> int:
+        self._steps += 1
+        for p in self._params:
+            self.state[p]["step"] = torch.tensor(float(self._steps))   # host scalar, as torch keeps it
+        return self._steps
+
+
+class FusedAdamW(_FlatOptimizer):
+    """``torch.optim.AdamW`` semantics (decoupled weight decay, optional AMSGrad), one launch per step."""
+
+    _STATE_KEYS = ("exp_avg", "exp_avg_sq", "max_exp_avg_sq")
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 amsgrad: bool = False, layout=None):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad),
+                         layout=layout)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if not self._adopted():
+            self._adopt()
+        g = self.param_groups[0]
+        grad = self._flat_grad()
+        m, v = self._state_buffer("exp_avg"), self._state_buffer("exp_avg_sq")
+        vmax = self._state_buffer("max_exp_avg_sq") if g["amsgrad"] else None
+        step = self._tick()
+        stream = torch.cuda.current_stream(self._flat.device).cuda_stream
+        with torch.cuda.device(self._flat.device):
+            check(lib.gnnsaft_adamw_step(self._flat.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                         None if vmax is None else vmax.data_ptr(), self._total, float(g["lr"]),
+                                         float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                         float(g["weight_decay"]), step, float(self.grad_scale), stream),
+                  "gnnsaft_adamw_step")
+        return loss
+
+
+class FusedSGD(_FlatOptimizer):
+    """``torch.optim.SGD(momentum, nesterov=True, dampening=0)`` semantics, one launch per step."""
+
+    _STATE_KEYS = ("momentum_buffer",)
+
+    def __init__(self, params, lr: float = 1e-3, momentum: float = 0.0, weight_decay: float = 0.0,
+                 nesterov: bool = True, layout=None):
+        if lr < 0 or momentum < 0 or weight_decay < 0:
+            raise ValueError("invalid SGD hyper-parameter")
+        if not nesterov:
+            raise NotImplementedError("only the Nesterov form the reference uses (models.py:171-177)")
+        if momentum <= 0:
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")   # torch's own check
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=True,
+                                      dampening=0), layout=layout)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if not self._adopted():
+            self._adopt()
+        g = self.param_groups[0]
+        grad = self._flat_grad()
+        first = "momentum_buffer" not in self._flat_state
+        buf = self._state_buffer("momentum_buffer")
+        self._tick()
+        stream = torch.cuda.current_stream(self._flat.device).cuda_stream
+        with torch.cuda.device(self._flat.device):
+            check(lib.gnnsaft_sgd_step(self._flat.data_ptr(), grad.data_ptr(), buf.data_ptr(), self._total,
+                                       float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), int(first),
+                                       float(self.grad_scale), stream), "gnnsaft_sgd_step")
+        return loss

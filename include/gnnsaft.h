@@ -386,6 +386,22 @@ int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int64_t num_no
                                   int64_t num_edges, int64_t num_graphs,
                                   gnnsaft_workspace_map *map);
 
+/* ------------------------------------------------------------------------ */
+/* Fused optimizer steps over one flat f32 parameter buffer (training-step    */
+/* host loop).  Replace torch.optim.AdamW(amsgrad=True, */
+/* eps=1e-5) / torch.optim.SGD(nesterov=True) of models.py:162-178; same        */
+/* update rule, one launch.  `grad_scale` multiplies the gradient first (1 /    */
+/* world size after a SUM all-reduce).  max_exp_avg_sq == NULL: amsgrad off.   */
+/* All pointers 16-byte aligned, `count` floats each.  `step` counts from 1.   */
+/* ------------------------------------------------------------------------ */
+int gnnsaft_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                       float *max_exp_avg_sq, int64_t count, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int64_t step, float grad_scale,
+                       gnnsaft_stream_t stream);
+int gnnsaft_sgd_step(float *param, const float *grad, float *momentum_buf, int64_t count, float lr,
+                     float momentum, float weight_decay, int32_t first_step, float grad_scale,
+                     gnnsaft_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,28 @@ def main():
         gathered.append(sum(both) / world)
     for p, w in zip([p for p in model.parameters() if p.requires_grad], gathered):
         assert torch.allclose(p.grad, w, rtol=1e-12, atol=1e-15)
+    # the layout gnnsaft_backward leaves behind: every .grad a view of ONE flat buffer -> reduced in place, and
+    # allreduce_flat_sum hands back the 1/world factor the fused optimizer folds into its kernel
+    params = [p for p in model.parameters() if p.requires_grad]
+    flat = torch.zeros(sum((p.numel() + 63) // 64 * 64 for p in params), dtype=torch.float64)
+    off = 0
+    for p, g in zip(params, local):
+        view = flat[off:off + p.numel()].view(p.shape)
+        view.copy_(g)
+        p.grad = view
+        off += (p.numel() + 63) // 64 * 64
+    assert parallel.common_gradient_buffer(params) is flat
+    before = flat.clone()
+    scale = parallel.allreduce_flat_sum(flat)
+    assert scale == 1.0 / world
+    for p, w in zip(params, gathered):
+        assert torch.allclose(p.grad * scale, w, rtol=1e-12, atol=1e-15)      # views see the reduced buffer
+    for p, g in zip(params, local):
+        p.grad.copy_(g)
+    parallel.FlatGradientAllReduce(params)()                                   # zero-copy path of the class
+    for p, w in zip(params, gathered):
+        assert torch.allclose(p.grad, w, rtol=1e-12, atol=1e-15)
+    assert not torch.equal(before, flat) or world == 1
     dist.barrier()
     dist.destroy_process_group()
     print("GLOO_OK")

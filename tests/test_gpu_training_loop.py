@@ -1,0 +1,88 @@
+"""Training-step host loop (train/loop.py): gnnsaft_forward -> MAPE -> gnnsaft_backward -> fused AdamW, scheduler
+per step, logging, Lightning-dialect checkpoints and resume (reference: Trainer.fit over PNApcsaftL,
+/root/reference/gnnepcsaft/train/train.py:142-185 with models.py:162-202)."""
+
+import copy
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_stages import DEV  # noqa: E402
+
+
+def _setup(seed=0):
+    import gnn_epc_saft_amd as G
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    batches = [make_synthetic_batch(64, 500 + i).to(DEV) for i in range(3)]
+    cfg = dict(propagation_depth=2, hidden_dim=64, pre_layers=1, post_layers=1, num_mlp_layers=1, num_para=3,
+               skip_connections=True, add_self_loops=True, dropout_rate=0.0, model="PNAL", optimizer="adam",
+               learning_rate=2e-3, weight_decay=1e-2, warmup_steps=8, momentum=0.9, num_train_steps=12,
+               log_every_steps=3, checkpoint_every_steps=6)
+    torch.manual_seed(seed)
+    lit = G.create_model(cfg, degree_histogram(batches)).to(DEV)
+    return lit, batches, cfg
+
+
+def test_loop_trains_logs_checkpoints_and_resumes(tmp_path):
+    from gnn_epc_saft_amd.train import checkpoint as C
+    from gnn_epc_saft_amd.train.loop import training_loop
+    lit, batches, cfg = _setup()
+    start = copy.deepcopy(lit.state_dict())
+    seen = []
+    hist = training_loop(lit, batches, workdir=str(tmp_path), on_log=lambda s, v, lr: seen.append((s, v, lr)))
+    assert [s for s, _ in hist] == [3, 6, 9, 12] and [s for s, _, _ in seen] == [3, 6, 9, 12]
+    assert hist[-1][1] < hist[0][1]                                  # it learns
+    lrs = [lr for _, _, lr in seen]
+    assert lrs[0] < 2e-3 and lrs[2] > lrs[1]                         # cosine decay, restart after warmup_steps = 8
+    ck6 = os.path.join(str(tmp_path), "train", "checkpoints", "step=6.ckpt")
+    ck12 = os.path.join(str(tmp_path), "train", "checkpoints", "step=12.ckpt")
+    assert os.path.exists(ck6) and os.path.exists(ck12)
+    final = {k: v.detach().cpu() for k, v in lit.state_dict().items()}
+    # run-to-run noise of an uninterrupted run (float atomics in the backward's edge-class reduction, amplified by
+    # Adam's m / sqrt(v) where gradients are tiny): the yardstick for the resumed trajectory
+    lit_b, _, _ = _setup()
+    training_loop(lit_b, batches, checkpoint_every_steps=0)
+    noise = {k: float((v.cpu() - final[k]).abs().max()) for k, v in lit_b.state_dict().items()
+             if v.is_floating_point()}
+    # resume from step 6 in a fresh module
+    lit2, _, _ = _setup(seed=1)
+    ck = C.load_checkpoint(lit2, ck6)
+    assert ck["global_step"] == 6 and "optimizer_states" in ck and "lr_schedulers" in ck
+    conf = lit2.configure_optimizers()                               # restored state is exact
+    assert C.resume(ck, conf["optimizer"], conf["lr_scheduler"]["scheduler"]) == 6
+    st = conf["optimizer"].state_dict()["state"]
+    for i, want in ck["optimizer_states"][0]["state"].items():
+        assert float(st[i]["step"]) == 6.0
+        for key in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+            assert torch.equal(st[i][key].cpu(), want[key]), (i, key)
+    assert conf["lr_scheduler"]["scheduler"].last_epoch == 6
+    hist2 = training_loop(lit2, batches, resume_from=ck)
+    assert [s for s, _ in hist2] == [9, 12]
+    for (s1, v1), (s2, v2) in zip(hist[2:], hist2):
+        assert s1 == s2 and abs(v1 - v2) < 1e-3 * abs(v1)
+    for k, v in lit2.state_dict().items():
+        if v.is_floating_point():
+            scale = float(final[k].abs().max()) + 1e-12
+            assert float((v.cpu() - final[k]).abs().max()) <= max(4 * noise[k], 1e-4 * scale), (k, noise[k])
+        else:
+            assert torch.equal(v.cpu(), final[k]), k                 # num_batches_tracked: 12 on both
+    # the checkpoint loads into the bare module through the other dialect's entry point too
+    import gnn_epc_saft_amd as G
+    bare = G.PNAPCSAFT(64, lit.model.pna_params, lit.model.mlp_params)
+    C.load_checkpoint(bare, ck12)
+    for k, v in bare.state_dict().items():
+        assert torch.equal(v, final["model." + k])
+    assert any(not torch.equal(start[k].cpu(), final[k]) for k in final)
+
+
+def test_sgd_configuration_steps_too():
+    from gnn_epc_saft_amd.train.loop import training_loop
+    from gnn_epc_saft_amd.train.optim import FusedSGD
+    lit, batches, cfg = _setup()
+    lit.config = dict(cfg, optimizer="sgd", learning_rate=1e-3)
+    assert isinstance(lit.configure_optimizers()["optimizer"], FusedSGD)
+    hist = training_loop(lit, batches, max_steps=8, log_every_steps=4, checkpoint_every_steps=0)
+    assert len(hist) == 2 and all(v == v for _, v in hist)

@@ -124,8 +124,11 @@ def test_create_model_and_calc_deg_contract():
         G.create_model(cfg, deg)
     lit = G.create_model(dict(cfg, model="PNAL", optimizer="adam", learning_rate=1e-3, weight_decay=1e-2,
                               warmup_steps=100, momentum=0.9), deg)
-    opt = lit.configure_optimizers()
-    assert isinstance(opt["optimizer"], torch.optim.AdamW) and opt["lr_scheduler"]["interval"] == "step"
+    with pytest.raises(RuntimeError, match="HIP device"):   # fused optimizers live on the GPU: no CPU fallback
+        lit.configure_optimizers()
+    with pytest.raises(ValueError, match="Unsupported optimizer"):
+        G.create_model(dict(cfg, model="PNAL", optimizer="lion", learning_rate=1e-3, weight_decay=1e-2,
+                            warmup_steps=100, momentum=0.9), deg).configure_optimizers()
     b = make_synthetic_batch(50, 3)
     assert b.x.shape[1] == 9 and b.edge_attr.shape[1] == 3 and b.edge_index.shape[1] % 2 == 0
     assert bool((b.edge_index[0, 0::2] == b.edge_index[1, 1::2]).all())       # (i,j),(j,i) per bond
@@ -176,3 +179,41 @@ def test_two_rank_gloo_rehearsal():
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert "GLOO_OK" in outs[0] and "GLOO_OK" in outs[1]
+
+
+def test_checkpoint_dialects_round_trip(tmp_path):
+    """Both checkpoint dialects of the reference (legacy ``model_state_dict`` of train/utils.py:109-119 and the
+    Lightning ``state_dict`` with ``model.`` keys, demo/utils.py:42-50) load into either module type."""
+    import gnn_epc_saft_amd as G
+    from gnn_epc_saft_amd.train import checkpoint as C
+    deg = torch.tensor([0, 5, 3, 2, 1])
+    cfg = dict(hidden_dim=64, num_para=3)
+    mk = lambda: G.PNAPCSAFT(64, G.PnaconvsParams(2, 1, 2, deg), G.ReadoutMLPParams(1, 3))
+    torch.manual_seed(3)
+    src = mk()
+    for b in src.buffers():
+        if b.dtype == torch.float32:
+            b.add_(torch.rand_like(b))
+    lit = G.PNApcsaftL(src.pna_params, src.mlp_params, cfg)
+    lit.model.load_state_dict(src.state_dict())
+    legacy, light = str(tmp_path / "legacy.pt"), str(tmp_path / "epoch=0-step=10.ckpt")
+    C.save_checkpoint(C.legacy_checkpoint(src, None, step=10), legacy)
+    C.save_checkpoint(C.lightning_checkpoint(lit, None, None, global_step=10), light)
+    raw = torch.load(light, weights_only=True)
+    assert all(k.startswith("model.") for k in raw["state_dict"]) and raw["global_step"] == 10
+    assert set(torch.load(legacy, weights_only=True)) == {"model_state_dict", "optimizer_state_dict",
+                                                           "scaler_state_dict", "step"}
+    for path in (legacy, light):
+        for target in (mk(), G.PNApcsaftL(src.pna_params, src.mlp_params, cfg)):
+            ck = C.load_checkpoint(target, path)
+            got = (target.model if isinstance(target, G.PNApcsaftL) else target).state_dict()
+            for k, v in src.state_dict().items():
+                assert torch.equal(got[k], v), k
+            assert C.resume(ck) == 10
+    # a float64 checkpoint (evaluate_ensemble.py:68 casts the model to double) loads into the float32 module
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in src.state_dict().items()}
+    t = mk()
+    C.load_checkpoint(t, {"model_state_dict": sd64})
+    assert all(torch.equal(t.state_dict()[k], v) for k, v in src.state_dict().items())
+    with pytest.raises(ValueError):
+        C.load_checkpoint(mk(), {"model_state_dict": {"x": 3}})
