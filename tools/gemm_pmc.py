@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gnn_epc_saft_amd.kernels as K
 from gnn_epc_saft_amd.data.synthetic import make_synthetic_batch
 DEV = "cuda:0"
-for graphs, h in ((1024, 128), (8192, 256)):
+SEL = {"C2": (1024, 128), "C3": (8192, 256)}
+for graphs, h in ([SEL[a] for a in sys.argv[1:]] or list(SEL.values())):
     d = make_synthetic_batch(graphs, 1)
     n = d.x.shape[0]
     x = torch.randn(n, h, device=DEV)
