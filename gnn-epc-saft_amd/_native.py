@@ -11,6 +11,13 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
 
+# torch FIRST: its wheel bundles its own libamdhip64 / libhsa-runtime64.  Loaded after torch, libgnnsaft.so binds
+# to that already-resident HIP runtime (same soname) and shares torch's streams, events and allocations.  Loaded
+# before torch, the dynamic linker would pull /opt/rocm's runtime in for this library and torch would then add its
+# own: two HIP runtimes in one process (measured on the GPU box: hipStreamCreate in the second one fails with
+# "no ROCm-capable device is detected", and stream handles would cross runtimes).
+import torch  # noqa: F401  (import order matters, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgnnsaft.so")
 

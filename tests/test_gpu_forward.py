@@ -4,7 +4,7 @@ vectors, plus size-independent properties at the BASELINE.json sizes.
 Tolerance.  north_star asks for 1e-5 relative f32.  The reference arithmetic has a
 discontinuity (PyG StdAggregation zeroes std where var <= 1e-5) that makes ANY two f32
 evaluations of it -- including the oracle run in f32 vs f64 -- disagree by ~1e-4 on the few
-graphs whose segment variance lands on the threshold (measured: tests/README).  Therefore:
+graphs whose segment variance lands on the threshold (measured: DESIGN.md section 2).  Therefore:
   * golden fixtures are generated threshold-free, and there the bar is the plain one:
         max|hip - f64 oracle| <= 1e-5 * max|oracle|          (TOL)
     relaxed only to 3x the f32 oracle's own distance from the f64 oracle when that is
