@@ -269,7 +269,9 @@ __global__ __launch_bounds__(256) void k_gather_rows_sum(const int32_t *__restri
   gs_st4(dpq + node * (int64_t)(4 * f) + 2 * f + c, acc);
 }
 
-// dr[class, :] = sum of dm[row, :] over the rows of that edge class.  `rows_c` lists the CSR rows grouped by
+constexpr int64_t kClassGemmMax = 256;  // up to this many edge classes the class sums run as a one-hot TN GEMM
+
+// Fallback for many classes: dr[class, :] = sum of dm[row, :] over the rows of that edge class.  `rows_c` lists the CSR rows grouped by
 // class (built once per backward); a thread owns a float4 column slice of a 32-row chunk of that list, keeps a
 // running sum while the class stays the same and flushes with one atomic add per class change (chunks hold
 // one or two classes), so the 60-row table is not hammered.
@@ -395,8 +397,10 @@ static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
   size_t slab = tn_slab_bytes(p.n, (int)(h / 2), (int)(13 * h));       // dW_post
   const size_t s2 = tn_slab_bytes(p.n, (int)h, 176 + 16);                 // one-hot (atom vocabulary rows)
   const size_t s3 = tn_slab_bytes(rows > ee ? rows : ee, (int)h, (int)h);
+  const size_t s4 = (size_t)p.combos <= (size_t)kClassGemmMax ? tn_slab_bytes(p.ep, (int)p.combos, (int)(2 * h)) : 0;
   slab = slab > s2 ? slab : s2;
   slab = slab > s3 ? slab : s3;
+  slab = slab > s4 ? slab : s4;
   size_t tot = 0;
   auto add = [&](size_t b) { tot += gs_align_up(b, 256); };
   add(slab);
@@ -559,8 +563,11 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   // =========================== transposed CSR (rows grouped by source) ===========================
   GS_TRY(launch_group_by_key(I(p.src), p.ep, n, rowptr_s, rows_s, grp_ws, group_by_key_workspace_bytes(n), 1, st));
   // ... and grouped by edge class (for the edge-table gradient)
-  GS_TRY(launch_group_by_key(I(p.combo), p.ep, C, rowptr_c, rows_c, grp_ws, group_by_key_workspace_bytes(n > C ? n : C),
-                             0, st));
+  // Few classes (the reference has 5*6*2 = 60): the per-class sums of dm are a one-hot TN GEMM, no grouping needed.
+  const bool class_gemm = C <= kClassGemmMax;
+  if (!class_gemm)
+    GS_TRY(launch_group_by_key(I(p.combo), p.ep, C, rowptr_c, rows_c, grp_ws,
+                               group_by_key_workspace_bytes(n > C ? n : C), 0, st));
 
   hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * h, 256)), dim3(256), 0, st, dcemb, C * h);
 
@@ -678,9 +685,14 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     }
     hipLaunchKernelGGL(k_gather_rows_sum, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, rowptr_s,
                        rows_s, dm, dpq, n, h, gs_row_split(h / 2));
-    hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * 2 * h, 256)), dim3(256), 0, st, dr, C * 2 * h);
-    hipLaunchKernelGGL(k_class_reduce, dim3((unsigned)gs_ceil_div(gs_ceil_div(p.ep, 32) * (h / 2), 256)), dim3(256),
-                       0, st, rows_c, I(p.combo), dm, p.ep, (int)C, h, dr, gs_row_split(h / 2));
+    if (class_gemm) {
+      GS_TRY(launch_sum_rows_by_class(I(p.combo), (int)C, dm, 2 * (int64_t)h, p.ep, 2 * h, dr, 2 * (int64_t)h, slabs,
+                                      slab_bytes, st));
+    } else {
+      hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * 2 * h, 256)), dim3(256), 0, st, dr, C * 2 * h);
+      hipLaunchKernelGGL(k_class_reduce, dim3((unsigned)gs_ceil_div(gs_ceil_div(p.ep, 32) * (h / 2), 256)),
+                         dim3(256), 0, st, rows_c, I(p.combo), dm, p.ep, (int)C, h, dr, gs_row_split(h / 2));
+    }
     // message GEMMs: dx_in += [dP | dQ] W_pq ; dW_dst,t / dW_src,t = dP_t^T x / dQ_t^T x
     {
       const float *ins[4] = {w.wpre[0][0], w.wpre[1][0], w.wpre[0][0] + h, w.wpre[1][0] + h};

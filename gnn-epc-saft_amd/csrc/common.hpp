@@ -145,6 +145,9 @@ int launch_wgrad_post(const float *du_t, int64_t ldu, const float *x, const floa
 int launch_wgrad_onehot(const float *dx, int64_t ldx, const int64_t *idx, int ncol, const int32_t *dims_host, int64_t n,
                         int hidden, float *dtab_t, int total_rows_padded, float *slabs, size_t slab_bytes,
                         hipStream_t st);
+// out[c, :] = sum of the rows of `a` whose class id is c (one-hot TN GEMM: deterministic, no atomics)
+int launch_sum_rows_by_class(const int32_t *cls, int num_classes, const float *a, int64_t lda, int64_t m, int k,
+                             float *out, int64_t ld_out, float *slabs, size_t slab_bytes, hipStream_t st);
 int launch_transpose(int count, const float *const *in, float *const *out, const int64_t *ld_in, const int64_t *ld_out,
                      int rows, int cols, hipStream_t st);
 int launch_colsum(const float *a, int64_t lda, int64_t m, int cols, float *out, int accumulate, float *partial,

@@ -78,7 +78,10 @@ struct TnOneHot {
   }
 };
 
-template <class AProv>
+// Y_CLASS: the left operand is not a matrix but the one-hot encoding of an int32 class id per row
+// (`dy` reinterpreted): out[c][:] = sum of the A rows of class c, i.e. a segmented reduction by an arbitrary key on
+// the matrix cores, in the fixed summation order of the slab scheme (no atomics).
+template <class AProv, bool Y_CLASS>
 __global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dy, int64_t ldy, AProv ap, int64_t m,
                                                  int n_out, int k, float *__restrict__ slabs, int64_t rows_per_z) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kTnBK * kTnLd];  // [buf][dy | a][32][68]
@@ -101,7 +104,13 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dy, i
       const bool ok = mm < m_end;
       mm = ok ? mm : m_end - 1;
       const int nn = n0 + sc;
-      f32x4 vy = gs_ld4(dy + mm * ldy + (nn < n_out ? nn : 0));
+      f32x4 vy;
+      if (Y_CLASS) {
+        const int c = reinterpret_cast<const int32_t *>(dy)[mm] - nn;
+        vy = f32x4{c == 0 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, c == 2 ? 1.f : 0.f, c == 3 ? 1.f : 0.f};
+      } else {
+        vy = gs_ld4(dy + mm * ldy + (nn < n_out ? nn : 0));
+      }
       f32x4 va = ap.load(mm, k0 + sc);
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
       ry[j] = (ok && nn < n_out) ? vy : zero;  // rows past the chunk contribute nothing
@@ -196,41 +205,88 @@ __global__ __launch_bounds__(256) void k_transpose(TransposeBatch tb, int rows, 
   }
 }
 
-// column sums (bias gradients): partial[chunk][col] then fixed-order sum.  32 columns x 8 row lanes per
-// workgroup, kColChunk rows per chunk.
-constexpr int kColChunk = 1024;
+// column sums (bias gradients): partial[chunk][col] then fixed-order sum.  A workgroup owns 32 columns x
+// kColChunk rows: 8 float4 column groups x 32 row lanes, every thread's 8 rows loaded back to back (independent
+// loads in flight; the first version walked 128 rows per thread one dependent load at a time: 20 us per call).
+constexpr int kColChunk = 256;
 __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ a, int64_t lda, int64_t m, int cols,
                                                         float *__restrict__ partial) {
-  __shared__ double red[8][32];
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  const int cc = c < cols ? c : cols - 1;
+  __shared__ double red[32][33];
+  const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;  // float4 column group, row lane
+  const int c0 = blockIdx.x * 32 + cg * 4;
   const int64_t m_beg = (int64_t)blockIdx.y * kColChunk;
-  int64_t m_end = m_beg + kColChunk;
-  if (m_end > m) m_end = m;
-  double s = 0.0;  // bias gradients in front of a train-mode BatchNorm are exactly zero: keep the sum exact
-  for (int64_t r = m_beg + rl; r < m_end; r += 8) s += (double)a[r * lda + cc];
-  red[rl][cl] = s;
+  const bool vec = c0 + 3 < cols;
+  const int cc = c0 < cols ? c0 : 0;
+  f32x4 v[kColChunk / 32];
+#pragma unroll
+  for (int j = 0; j < kColChunk / 32; ++j) {
+    int64_t r = m_beg + rl + 32 * j;
+    const bool ok = r < m;
+    r = ok ? r : m - 1;
+    const float *src = a + r * lda;
+    if (vec) {
+      v[j] = gs_ld4(src + cc);
+    } else {  // ragged last column group (cols % 4 != 0: the [G, num_para] head)
+      v[j].x = c0 + 0 < cols ? src[c0 + 0] : 0.f;
+      v[j].y = c0 + 1 < cols ? src[c0 + 1] : 0.f;
+      v[j].z = c0 + 2 < cols ? src[c0 + 2] : 0.f;
+      v[j].w = 0.f;
+    }
+    if (!ok) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // bias gradients in front of a train-mode BatchNorm are exactly zero: keep the sums exact (f64)
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int j = 0; j < kColChunk / 32; ++j) {
+    s0 += (double)v[j].x;
+    s1 += (double)v[j].y;
+    s2 += (double)v[j].z;
+    s3 += (double)v[j].w;
+  }
+  red[rl][cg * 4 + 0] = s0;
+  red[rl][cg * 4 + 1] = s1;
+  red[rl][cg * 4 + 2] = s2;
+  red[rl][cg * 4 + 3] = s3;
   __syncthreads();
-  if (rl == 0 && c < cols) {
-    for (int o = 1; o < 8; ++o) s += red[o][cl];
-    partial[(int64_t)blockIdx.y * cols + c] = (float)s;
+  if (threadIdx.x < 32) {
+    const int c = blockIdx.x * 32 + threadIdx.x;
+    double s = 0.0;
+#pragma unroll
+    for (int o = 0; o < 32; ++o) s += red[o][threadIdx.x];
+    if (c < cols) partial[(int64_t)blockIdx.y * cols + c] = (float)s;
   }
 }
+// 32 columns x 8 chunk lanes per workgroup
 __global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ partial, int64_t chunks, int cols,
                                                       float *__restrict__ out, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ double red[8][33];
+  const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int cc = c < cols ? c : cols - 1;
   double s = 0.0;
-  for (int64_t j = 0; j < chunks; ++j) s += (double)partial[j * cols + c];
-  out[c] = accumulate ? out[c] + (float)s : (float)s;
+  for (int64_t j0 = lane; j0 < chunks; j0 += 64) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t j = j0 + 8 * u;
+      t[u] = j < chunks ? partial[j * cols + cc] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (double)t[u];
+  }
+  red[lane][cl] = s;
+  __syncthreads();
+  if (lane == 0 && c < cols) {
+    for (int o = 1; o < 8; ++o) s += red[o][cl];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+  }
 }
 
-template <class AProv>
+template <class AProv, bool Y_CLASS = false>
 static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, int n_out, int k, float *out,
                      int64_t ld_out, int accumulate, float *slabs, size_t slab_bytes, hipStream_t st) {
   GS_REQUIRE(dy && out && slabs, GNNSAFT_ERR_NULL);
-  GS_REQUIRE(m >= 1 && n_out >= 1 && k >= 4 && (k % 4) == 0 && (ldy % 4) == 0 && (ld_out % 4) == 0,
+  GS_REQUIRE(m >= 1 && n_out >= 1 && k >= 4 && (k % 4) == 0 && (Y_CLASS || (ldy % 4) == 0) && (ld_out % 4) == 0,
              GNNSAFT_ERR_SHAPE);
   // number of row slabs: enough workgroups to fill the chip (~1024), never finer than kTnChunk rows
   const int64_t tiles = gs_ceil_div(k, kTnTile) * gs_ceil_div(n_out, kTnTile);
@@ -242,7 +298,7 @@ static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, i
   chunks = gs_ceil_div(m, rows_per_z);
   GS_REQUIRE(slab_bytes >= (size_t)chunks * n_out * k * 4, GNNSAFT_ERR_WORKSPACE);
   const dim3 grid((unsigned)gs_ceil_div(k, kTnTile), (unsigned)gs_ceil_div(n_out, kTnTile), (unsigned)chunks);
-  hipLaunchKernelGGL((k_gemm_tn<AProv>), grid, dim3(256), 0, st, dy, ldy, ap, m, n_out, k, slabs, rows_per_z);
+  hipLaunchKernelGGL((k_gemm_tn<AProv, Y_CLASS>), grid, dim3(256), 0, st, dy, ldy, ap, m, n_out, k, slabs, rows_per_z);
   const int64_t per_slab = (int64_t)n_out * k;
   hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)gs_ceil_div(per_slab / 4, 32)), dim3(256), 0, st, slabs, per_slab,
                      chunks, out, ld_out, k, accumulate);
@@ -288,6 +344,15 @@ int launch_wgrad_onehot(const float *dx, int64_t ldx, const int64_t *idx, int nc
   return launch_tn(dx, ldx, ap, n, hidden, total_rows_padded, dtab_t, total_rows_padded, 0, slabs, slab_bytes, st);
 }
 
+int launch_sum_rows_by_class(const int32_t *cls, int num_classes, const float *a, int64_t lda, int64_t m, int k,
+                             float *out /* [num_classes, k] */, int64_t ld_out, float *slabs, size_t slab_bytes,
+                             hipStream_t st) {
+  GS_REQUIRE(cls != nullptr && a != nullptr && (lda % 4) == 0 && num_classes >= 1, GNNSAFT_ERR_SHAPE);
+  TnPlain ap{a, lda, 0, k};
+  return launch_tn<TnPlain, true>(reinterpret_cast<const float *>(cls), 0, ap, m, num_classes, k, out, ld_out, 0, slabs,
+                                  slab_bytes, st);
+}
+
 int launch_transpose(int count, const float *const *in, float *const *out, const int64_t *ld_in, const int64_t *ld_out,
                      int rows, int cols, hipStream_t st) {
   GS_REQUIRE(count >= 1 && count <= kMaxGemmBatch, GNNSAFT_ERR_SHAPE);
@@ -313,7 +378,7 @@ int launch_colsum(const float *a, int64_t lda, int64_t m, int cols, float *out, 
   GS_REQUIRE(partial_bytes >= (size_t)chunks * cols * 4, GNNSAFT_ERR_WORKSPACE);
   hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)gs_ceil_div(cols, 32), (unsigned)chunks), dim3(256), 0, st, a,
                      lda, m, cols, partial);
-  hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)gs_ceil_div(cols, 256)), dim3(256), 0, st, partial, chunks, cols,
+  hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)gs_ceil_div(cols, 32)), dim3(256), 0, st, partial, chunks, cols,
                      out, accumulate);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
