@@ -394,9 +394,11 @@ struct BwdSizes {
 static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
   const size_t h = d->hidden, nn = p.n > 0 ? p.n : 1, ee = p.ep > 0 ? p.ep : 1, gg = p.g > 0 ? p.g : 1;
   const size_t rows = nn > gg ? nn : gg;
-  size_t slab = tn_slab_bytes(p.n, (int)(h / 2), (int)(13 * h));       // dW_post
+  size_t slab = wgrad_post_folded_slab_bytes(p.tile_cap, pna_fold_tile_rows((int)h), (int)h);  // dW_post, both towers
   const size_t s2 = tn_slab_bytes(p.n, (int)h, 176 + 16);                 // one-hot (atom vocabulary rows)
-  const size_t s3 = tn_slab_bytes(rows > ee ? rows : ee, (int)h, (int)h);
+  size_t s3 = tn_slab_bytes(rows, (int)(4 * h), (int)h);                 // message weights: four [F,F] blocks at once
+  const size_t s3e = d->pre_layers > 1 ? tn_slab_bytes(ee, (int)h, (int)h) : 0;  // edge-row wgrads of extra pre layers
+  s3 = s3 > s3e ? s3 : s3e;
   const size_t s4 = (size_t)p.combos <= (size_t)kClassGemmMax ? tn_slab_bytes(p.ep, (int)p.combos, (int)(2 * h)) : 0;
   slab = slab > s2 ? slab : s2;
   slab = slab > s3 ? slab : s3;
@@ -619,12 +621,11 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       dy = tsw;
     }
     // update wgrad / bias
-    for (int t = 0; t < 2; ++t) {
-      GS_TRY(launch_wgrad_post(du + t * (h / 2), h, x_l, agg_l + t * 4 * h, F(p.log_amp), F(p.log_att), w.avg, n, h,
-                               G(t == 0 ? i_post0 : i_post1), slabs, slab_bytes, st));
+    GS_TRY(launch_wgrad_post_folded(du, x_l, agg_l, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap,
+                                    pna_fold_tile_rows(h), w.avg, h, G(i_post0), G(i_post1), slabs, slab_bytes, st));
+    for (int t = 0; t < 2; ++t)
       GS_TRY(launch_colsum(du + t * (h / 2), h, n, h / 2, G((t == 0 ? i_post0 : i_post1) + 1), 0, slabs, slab_bytes,
                            st));
-    }
     // update dgrad, x part: dx_in = (skip ? dx : 0) + du [N,F] x [W_x,0 ; W_x,1]
     {
       const float *ins[2] = {w.wpost[0][0], w.wpost[1][0]};
@@ -701,12 +702,10 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       const int64_t ldo[4] = {4 * (int64_t)h, 4 * (int64_t)h, 4 * (int64_t)h, 4 * (int64_t)h};
       GS_TRY(launch_transpose(4, ins, outs, ldi, ldo, h, h, st));  // wpqT[j][blk*F + f] = pre_t[f][part*F + j]
       GS_TRY(dgrad(dpq, 4 * (int64_t)h, wpqT, 4 * (int64_t)h, dx, h, n, h, 4 * h, dx_other));
-      for (int t = 0; t < 2; ++t) {
-        float *gw = G(t == 0 ? i_pre0 : i_pre1);
-        GS_TRY(launch_wgrad_plain(dpq + t * h, 4 * (int64_t)h, x_l, h, 0, n, h, h, gw, 3 * (int64_t)h, 0, slabs,
-                                  slab_bytes, st));
-        GS_TRY(launch_wgrad_plain(dpq + 2 * h + t * h, 4 * (int64_t)h, x_l, h, 0, n, h, h, gw + h, 3 * (int64_t)h, 0,
-                                  slabs, slab_bytes, st));
+      {  // dW_dst,t0 | dW_dst,t1 | dW_src,t0 | dW_src,t1 = dPQ^T x: one TN GEMM, four [F,F] blocks of two matrices
+        float *blocks[4] = {G(i_pre0), G(i_pre1), G(i_pre0) + h, G(i_pre1) + h};
+        GS_TRY(launch_wgrad_plain_blocks(dpq, 4 * (int64_t)h, x_l, h, n, 4, h, h, blocks, 3 * (int64_t)h, slabs,
+                                         slab_bytes, st));
       }
     }
     // edge-class table: rtab[c, tF:(t+1)F] = W_t[:,2F:3F] cenc[c] + b_t ; cenc = cemb W_e^T + b_e

@@ -139,12 +139,19 @@ size_t tn_slab_bytes(int64_t m, int n_out, int k);
 int launch_wgrad_plain(const float *dy, int64_t ldy, const float *a, int64_t lda, int relu_a, int64_t m, int n_out,
                        int k, float *out, int64_t ld_out, int accumulate, float *slabs, size_t slab_bytes,
                        hipStream_t st);
-int launch_wgrad_post(const float *du_t, int64_t ldu, const float *x, const float *agg_t, const float *log_amp,
-                      const float *log_att, const float *avg, int64_t n, int hidden, float *dw, float *slabs,
-                      size_t slab_bytes, hipStream_t st);
 int launch_wgrad_onehot(const float *dx, int64_t ldx, const int64_t *idx, int ncol, const int32_t *dims_host, int64_t n,
                         int hidden, float *dtab_t, int total_rows_padded, float *slabs, size_t slab_bytes,
                         hipStream_t st);
+// dW blocks [rows_per_block, k] of one TN GEMM dy[:, b*rows_per_block ..]^T a, each written to its own matrix
+int launch_wgrad_plain_blocks(const float *dy, int64_t ldy, const float *a, int64_t lda, int64_t m, int num_blocks,
+                              int rows_per_block, int k, float *const *out_blocks, int64_t ld_out, float *slabs,
+                              size_t slab_bytes, hipStream_t st);
+// post_nns weight gradients of both towers through the degree tiles (K = 5F contraction, scalers folded per tile)
+int launch_wgrad_post_folded(const float *du, const float *x, const float *agg, const int32_t *perm,
+                             const int32_t *tiles, const int32_t *num_tiles, int64_t tile_cap, int tile_rows,
+                             const float *avg, int hidden, float *dw0, float *dw1, float *slabs, size_t slab_bytes,
+                             hipStream_t st);
+size_t wgrad_post_folded_slab_bytes(int64_t tile_cap, int tile_rows, int hidden);
 // out[c, :] = sum of the rows of `a` whose class id is c (one-hot TN GEMM: deterministic, no atomics)
 int launch_sum_rows_by_class(const int32_t *cls, int num_classes, const float *a, int64_t lda, int64_t m, int k,
                              float *out, int64_t ld_out, float *slabs, size_t slab_bytes, hipStream_t st);

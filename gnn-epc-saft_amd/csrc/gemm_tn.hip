@@ -11,7 +11,7 @@
 //
 // The A operand is virtual, as in gemm.hip:
 //   TnPlain  : a row-major matrix (optionally ReLU'd: extra pre/post layers)
-//   TnPost   : cat[x_i, A, A*amp_i, A*att_i]                 (PNAConv update input, never materialised)
+//   (the PNAConv update input cat[x_i, A, A*amp_i, A*att_i] has its own kernel, k_gemm_tn_postfold)
 //   TnOneHot : concatenated one-hot rows of categorical columns (embedding tables: dE = OneHot^T dX)
 #include "common.hpp"
 
@@ -37,24 +37,6 @@ struct TnPlain {
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     return kk < k ? v : zero;
-  }
-};
-
-struct TnPost {
-  const float *x;        // [N,F]
-  const float *agg;      // [N,2,4F] + tower offset applied by the launcher
-  const float *log_amp;  // [N]
-  const float *log_att;  // [N]
-  const float *avg;      // device [1]
-  int f;
-  __device__ __forceinline__ f32x4 load(int64_t m, int kk) const {
-    const int j = kk - f;
-    const int seg = j < 4 * f ? 0 : (j < 8 * f ? 1 : 2);
-    const float *p = j < 0 ? x + m * f + kk : agg + m * (int64_t)(8 * f) + (j - seg * 4 * f);
-    const f32x4 v = gs_ld4(p);
-    const float avgv = avg[0];
-    const float s = (j < 0 || seg == 0) ? 1.f : (seg == 1 ? log_amp[m] / avgv : avgv / log_att[m]);
-    return v * s;
   }
 };
 
@@ -158,22 +140,152 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dy, i
   }
 }
 
+// ---- post_nns weight gradient through the degree tiles (the backward twin of the degree-folded update).
+// dW_t = du_t^T cat[x, A_t, amp A_t, att A_t] has K = 13F, but amp / att are constant over a degree tile, so a
+// workgroup contracts only [x | A_t] (K = 5F) and, after every tile (rows of ONE in-degree), folds the tile's
+// partial product into three accumulators:  id += S,  amp += amp(d) S,  att += att(d) S  (48 VALU fmas per lane
+// per tile against 32+ MFMAs) -- 10 N F^2 FLOP per layer instead of 26 N F^2.  Rows are addressed through the
+// degree permutation; grid.z walks groups of `tiles_per_z` tiles, grid.y = (n tile, tower).
+struct TnFoldArgs {
+  const float *du;        // [N, F]  (tower t uses columns t F/2 ..)
+  const float *x;         // [N, F]
+  const float *agg;       // [N, 2, 4F]
+  const int32_t *perm;    // slot -> node
+  const int32_t *tiles;   // [num_tiles][4] = degree, first slot, rows, -
+  const int32_t *num_tiles;
+  const float *avg;       // device [1]
+  int f;
+  int tile_rows;
+  int tiles_per_z;
+};
+
+__global__ __launch_bounds__(256) void k_gemm_tn_postfold(TnFoldArgs a, float *__restrict__ slabs) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kTnBK * kTnLd];  // [buf][du | operand][32][68]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;  // 2 x 2 waves, 32 x 32 each
+  const int f = a.f, n_out = f / 2, kfold = 5 * f, kfull = 13 * f;
+  const int n_tiles_n = (n_out + kTnTile - 1) / kTnTile;
+  const int tower = blockIdx.y / n_tiles_n;
+  const int n0 = (blockIdx.y - tower * n_tiles_n) * kTnTile, k0 = blockIdx.x * kTnTile;
+  const bool agg_part = k0 >= f;  // a 64-wide k tile lies wholly in the x block or in the aggregate block (F % 64 == 0)
+  const int nt = a.num_tiles[0];
+  const int t_beg = blockIdx.z * a.tiles_per_z;
+  int t_end = t_beg + a.tiles_per_z;
+  if (t_end > nt) t_end = nt;
+
+  const int sc = (tid & 15) * 4;
+  const int sr = tid >> 4;
+  const int nn = n0 + sc;
+  const float *dy_col = a.du + tower * n_out + (nn < n_out ? nn : 0);
+  const float *op_col = agg_part ? a.agg + tower * 4 * f + (k0 - f) + sc : a.x + k0 + sc;
+  const int64_t op_ld = agg_part ? 8 * (int64_t)f : f;
+  const float avgv = a.avg[0];
+
+  f32x16 acc, acc_id, acc_amp, acc_att;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = acc_id[r] = acc_amp[r] = acc_att[r] = 0.f;
+
+  f32x4 ry[2], ra[2];
+  for (int t = t_beg; t < t_end; ++t) {
+    const int deg = a.tiles[4 * t + 0], slot0 = a.tiles[4 * t + 1], count = a.tiles[4 * t + 2];
+    auto fetch = [&](int row0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int r = row0 + sr + 16 * j;
+        const bool ok = r < count;
+        r = ok ? r : count - 1;
+        const int64_t node = a.perm[slot0 + r];
+        const f32x4 vy = gs_ld4(dy_col + node * f);
+        const f32x4 va = gs_ld4(op_col + node * op_ld);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        ry[j] = (ok && nn < n_out) ? vy : zero;
+        ra[j] = ok ? va : zero;
+      }
+    };
+    auto stash = [&](int buf) {
+      float *ys = lds + buf * 2 * kTnBK * kTnLd;
+      float *as = ys + kTnBK * kTnLd;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        gs_st4(ys + (sr + 16 * j) * kTnLd + sc, ry[j]);
+        gs_st4(as + (sr + 16 * j) * kTnLd + sc, ra[j]);
+      }
+    };
+    const int steps = (count + kTnBK - 1) / kTnBK;
+    __syncthreads();  // the previous tile's last stage has been consumed by every wave
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+      const bool more = s + 1 < steps;
+      if (more) fetch((s + 1) * kTnBK);
+      const float *ys = lds + (s & 1) * 2 * kTnBK * kTnLd + wn * 32 + (lane & 31);
+      const float *as = ys + kTnBK * kTnLd - wn * 32 + wk * 32;
+#pragma unroll
+      for (int q = 0; q < kTnBK / 2; ++q) {
+        const int row = 2 * q + (lane >> 5);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ys[row * kTnLd], as[row * kTnLd], acc, 0, 0, 0);
+      }
+      if (more) stash((s + 1) & 1);
+      __syncthreads();
+    }
+    if (agg_part) {  // fold this degree's partial product
+      const float amp = logf((float)deg + 1.f) / avgv;
+      const float att = avgv / logf(fmaxf((float)deg, 1.f) + 1.f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc_id[r] += acc[r];
+        acc_amp[r] += amp * acc[r];
+        acc_att[r] += att * acc[r];
+        acc[r] = 0.f;
+      }
+    }
+  }
+  // slab layout = the unfolded gradient [2 towers][F/2][13F], so the ordinary slab sum finishes the job.
+  // C/D: col = lane & 31 (k), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (n)
+  float *slab = slabs + ((int64_t)blockIdx.z * 2 + tower) * n_out * (int64_t)kfull;
+  const int kc = k0 + wk * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int nr = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (nr < n_out && kc < kfold) {
+      float *o = slab + (int64_t)nr * kfull;
+      if (!agg_part) {
+        o[kc] = acc[r];
+      } else {
+        o[kc] = acc_id[r];
+        o[kc + 4 * f] = acc_amp[r];
+        o[kc + 8 * f] = acc_att[r];
+      }
+    }
+  }
+}
+
 // out[i] (+)= sum over the slabs; 8 slab lanes per output float4, combined in a fixed order
+// The dense result [rows, cols] may be scattered by row blocks: block b = row / rows_per_block goes to base[b]
+// (several weight gradients that share one TN GEMM, e.g. the four [F,F] blocks of the message weights).
+struct SlabOut {
+  float *base[4];
+  int64_t rows_per_block;
+};
 __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ slabs, int64_t per_slab, int64_t chunks,
-                                                   float *__restrict__ out, int64_t ld_out, int cols, int accumulate) {
+                                                   SlabOut so, int64_t ld_out, int cols, int accumulate,
+                                                   int64_t slab_stride) {
   __shared__ f32x4 red[8][32];
   const int il = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int64_t i4 = ((int64_t)blockIdx.x * 32 + il) * 4;
   const bool ok = i4 < per_slab;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (ok)
-    for (int64_t c = sl; c < chunks; c += 8) s += gs_ld4(slabs + c * per_slab + i4);
+    for (int64_t c = sl; c < chunks; c += 8) s += gs_ld4(slabs + c * slab_stride + i4);
   red[sl][il] = s;
   __syncthreads();
   if (sl != 0 || !ok) return;
   for (int o = 1; o < 8; ++o) s += red[o][il];
   const int64_t r = i4 / cols, cc = i4 - r * cols;  // slab is dense [rows, cols]; out may be a column block
-  float *o = out + r * ld_out + cc;
+  const int64_t blk = r / so.rows_per_block;
+  float *o = so.base[blk] + (r - blk * so.rows_per_block) * ld_out + cc;
   if (accumulate) s += gs_ld4(o);
   gs_st4(o, s);
 }
@@ -284,8 +396,9 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ 
 
 template <class AProv, bool Y_CLASS = false>
 static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, int n_out, int k, float *out,
-                     int64_t ld_out, int accumulate, float *slabs, size_t slab_bytes, hipStream_t st) {
-  GS_REQUIRE(dy && out && slabs, GNNSAFT_ERR_NULL);
+                     int64_t ld_out, int accumulate, float *slabs, size_t slab_bytes, hipStream_t st,
+                     const SlabOut *scatter = nullptr) {
+  GS_REQUIRE(dy && (out || scatter) && slabs, GNNSAFT_ERR_NULL);
   GS_REQUIRE(m >= 1 && n_out >= 1 && k >= 4 && (k % 4) == 0 && (Y_CLASS || (ldy % 4) == 0) && (ld_out % 4) == 0,
              GNNSAFT_ERR_SHAPE);
   // number of row slabs: enough workgroups to fill the chip (~1024), never finer than kTnChunk rows
@@ -300,8 +413,10 @@ static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, i
   const dim3 grid((unsigned)gs_ceil_div(k, kTnTile), (unsigned)gs_ceil_div(n_out, kTnTile), (unsigned)chunks);
   hipLaunchKernelGGL((k_gemm_tn<AProv, Y_CLASS>), grid, dim3(256), 0, st, dy, ldy, ap, m, n_out, k, slabs, rows_per_z);
   const int64_t per_slab = (int64_t)n_out * k;
+  SlabOut so{{out, out, out, out}, (int64_t)1 << 40};
+  if (scatter != nullptr) so = *scatter;
   hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)gs_ceil_div(per_slab / 4, 32)), dim3(256), 0, st, slabs, per_slab,
-                     chunks, out, ld_out, k, accumulate);
+                     chunks, so, ld_out, k, accumulate, per_slab);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }
@@ -318,13 +433,45 @@ int launch_wgrad_plain(const float *dy, int64_t ldy, const float *a, int64_t lda
   return launch_tn(dy, ldy, ap, m, n_out, k, out, ld_out, accumulate, slabs, slab_bytes, st);
 }
 
-int launch_wgrad_post(const float *du_t, int64_t ldu, const float *x, const float *agg_t, const float *log_amp,
-                      const float *log_att, const float *avg, int64_t n, int hidden, float *dw /* [F/2,13F] */,
-                      float *slabs, size_t slab_bytes, hipStream_t st) {
-  GS_REQUIRE(x && agg_t && log_amp && log_att && avg, GNNSAFT_ERR_NULL);
-  GS_REQUIRE((hidden % 64) == 0, GNNSAFT_ERR_UNSUPPORTED);  // a 64-wide k tile must not straddle segments
-  TnPost ap{x, agg_t, log_amp, log_att, avg, hidden};
-  return launch_tn(du_t, ldu, ap, n, hidden / 2, 13 * hidden, dw, 13 * (int64_t)hidden, 0, slabs, slab_bytes, st);
+int launch_wgrad_plain_blocks(const float *dy, int64_t ldy, const float *a, int64_t lda, int64_t m, int num_blocks,
+                              int rows_per_block, int k, float *const *out_blocks, int64_t ld_out, float *slabs,
+                              size_t slab_bytes, hipStream_t st) {
+  GS_REQUIRE(a != nullptr && (lda % 4) == 0 && out_blocks != nullptr && num_blocks >= 1 && num_blocks <= 4,
+             GNNSAFT_ERR_SHAPE);
+  SlabOut so;
+  for (int i = 0; i < 4; ++i) so.base[i] = out_blocks[i < num_blocks ? i : 0];
+  so.rows_per_block = rows_per_block;
+  TnPlain ap{a, lda, 0, k};
+  return launch_tn(dy, ldy, ap, m, num_blocks * rows_per_block, k, nullptr, ld_out, 0, slabs, slab_bytes, st, &so);
+}
+
+int launch_wgrad_post_folded(const float *du, const float *x, const float *agg, const int32_t *perm,
+                             const int32_t *tiles, const int32_t *num_tiles, int64_t tile_cap, int tile_rows,
+                             const float *avg, int hidden, float *dw0, float *dw1 /* [F/2,13F] each */, float *slabs,
+                             size_t slab_bytes, hipStream_t st) {
+  GS_REQUIRE(du && x && agg && perm && tiles && num_tiles && avg && dw0 && dw1 && slabs, GNNSAFT_ERR_NULL);
+  GS_REQUIRE((hidden % 64) == 0 && tile_rows >= kTnBK && (tile_rows % kTnBK) == 0 && tile_cap >= 1,
+             GNNSAFT_ERR_UNSUPPORTED);
+  // ~256 rows per workgroup along the contraction, as launch_tn does
+  const int tiles_per_z = tile_rows >= 2 * kTnChunk ? 1 : 2 * kTnChunk / tile_rows;
+  const int64_t chunks = gs_ceil_div(tile_cap, (int64_t)tiles_per_z);
+  const int n_out = hidden / 2;
+  const int64_t per_slab = (int64_t)n_out * 13 * hidden;
+  GS_REQUIRE(slab_bytes >= (size_t)chunks * 2 * per_slab * 4, GNNSAFT_ERR_WORKSPACE);
+  TnFoldArgs a{du, x, agg, perm, tiles, num_tiles, avg, hidden, tile_rows, tiles_per_z};
+  const dim3 grid((unsigned)(5 * hidden / kTnTile), (unsigned)(2 * gs_ceil_div(n_out, kTnTile)), (unsigned)chunks);
+  hipLaunchKernelGGL(k_gemm_tn_postfold, grid, dim3(256), 0, st, a, slabs);
+  // both towers in one pass: the slab pair is a dense [2 * F/2, 13F] matrix whose row blocks go to dw0 / dw1
+  SlabOut so{{dw0, dw1, dw1, dw1}, (int64_t)n_out};
+  hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)gs_ceil_div(2 * per_slab / 4, 32)), dim3(256), 0, st, slabs,
+                     2 * per_slab, chunks, so, 13 * (int64_t)hidden, 13 * hidden, 0, 2 * per_slab);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+size_t wgrad_post_folded_slab_bytes(int64_t tile_cap, int tile_rows, int hidden) {
+  const int tiles_per_z = tile_rows >= 2 * kTnChunk ? 1 : 2 * kTnChunk / tile_rows;
+  return (size_t)gs_ceil_div(tile_cap, (int64_t)tiles_per_z) * 2 * (size_t)(hidden / 2) * 13 * hidden * 4;
 }
 
 int launch_wgrad_onehot(const float *dx, int64_t ldx, const int64_t *idx, int ncol, const int32_t *dims_host, int64_t n,
