@@ -367,13 +367,17 @@ __global__ __launch_bounds__(256) void k_combo_embed_bwd(const float *__restrict
 }
 
 // atom tables: dtab_k[v, hh] = det[hh][off_k + v]   (det = one-hot^T dx0, stored transposed)
+// all tables in one launch: thread i owns element (vocabulary row i / h of the concatenated tables, channel i % h)
 __global__ __launch_bounds__(256) void k_unpack_embed_grad(const float *__restrict__ det, int ld, int h, TableGrads tg,
-                                                           int table, int off) {
+                                                           int total_rows) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)tg.dims[table] * h) return;
-  const int64_t v = i / h;
-  const int hh = (int)(i - v * h);
-  tg.grad[table][i] = det[(int64_t)hh * ld + off + v];
+  if (i >= (int64_t)total_rows * h) return;
+  int v = (int)(i / h);
+  const int hh = (int)(i - (int64_t)v * h);
+  const int row = v;
+  int table = 0;
+  while (table + 1 < tg.n && v >= tg.dims[table]) v -= tg.dims[table++];
+  tg.grad[table][(int64_t)v * h + hh] = det[(int64_t)hh * ld + row];
 }
 
 struct Scratch {
@@ -623,9 +627,10 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     // update wgrad / bias
     GS_TRY(launch_wgrad_post_folded(du, x_l, agg_l, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap,
                                     pna_fold_tile_rows(h), w.avg, h, G(i_post0), G(i_post1), slabs, slab_bytes, st));
-    for (int t = 0; t < 2; ++t)
-      GS_TRY(launch_colsum(du + t * (h / 2), h, n, h / 2, G((t == 0 ? i_post0 : i_post1) + 1), 0, slabs, slab_bytes,
-                           st));
+    {  // both towers' bias gradients: column sums of du, halves to two tensors
+      float *outs[2] = {G(i_post0 + 1), G(i_post1 + 1)};
+      GS_TRY(launch_colsum_blocks(du, h, n, 2, h / 2, outs, slabs, slab_bytes, st));
+    }
     // update dgrad, x part: dx_in = (skip ? dx : 0) + du [N,F] x [W_x,0 ; W_x,1]
     {
       const float *ins[2] = {w.wpost[0][0], w.wpost[1][0]};
@@ -709,11 +714,14 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       }
     }
     // edge-class table: rtab[c, tF:(t+1)F] = W_t[:,2F:3F] cenc[c] + b_t ; cenc = cemb W_e^T + b_e
-    for (int t = 0; t < 2; ++t) {
-      float *gw = G(t == 0 ? i_pre0 : i_pre1);
-      GS_TRY(launch_wgrad_plain(dr + t * h, 2 * (int64_t)h, cenc, h, 0, C, h, h, gw + 2 * h, 3 * (int64_t)h, 0, slabs,
-                                slab_bytes, st));
-      GS_TRY(launch_colsum(dr + t * h, 2 * (int64_t)h, C, h, G((t == 0 ? i_pre0 : i_pre1) + 1), 0, slabs, slab_bytes, st));
+    {
+      float *blocks[2] = {G(i_pre0) + 2 * h, G(i_pre1) + 2 * h};
+      GS_TRY(launch_wgrad_plain_blocks(dr, 2 * (int64_t)h, cenc, h, C, 2, h, h, blocks, 3 * (int64_t)h, slabs, slab_bytes,
+                                       st));
+    }
+    {
+      float *outs[2] = {G(i_pre0 + 1), G(i_pre1 + 1)};
+      GS_TRY(launch_colsum_blocks(dr, 2 * (int64_t)h, C, 2, h, outs, slabs, slab_bytes, st));
     }
     {
       const float *ins[2] = {w.wpre[0][0] + 2 * h, w.wpre[1][0] + 2 * h};
@@ -751,16 +759,12 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
                                st));
     TableGrads tg;
     tg.n = d->num_atom_cols;
-    int off = 0;
     for (int k = 0; k < GNNSAFT_MAX_TABLES; ++k) {
       tg.dims[k] = k < d->num_atom_cols ? d->atom_dims[k] : 1;
       tg.grad[k] = k < d->num_atom_cols ? G(pw.atom0 + k) : nullptr;
     }
-    for (int k = 0; k < d->num_atom_cols; ++k) {
-      hipLaunchKernelGGL(k_unpack_embed_grad, dim3((unsigned)gs_ceil_div((int64_t)d->atom_dims[k] * h, 256)),
-                         dim3(256), 0, st, det, vocab_pad, h, tg, k, off);
-      off += d->atom_dims[k];
-    }
+    hipLaunchKernelGGL(k_unpack_embed_grad, dim3((unsigned)gs_ceil_div((int64_t)total * h, 256)), dim3(256), 0, st, det,
+                       vocab_pad, h, tg, total);
   }
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;

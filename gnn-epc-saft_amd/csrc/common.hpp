@@ -159,6 +159,8 @@ int launch_transpose(int count, const float *const *in, float *const *out, const
                      int rows, int cols, hipStream_t st);
 int launch_colsum(const float *a, int64_t lda, int64_t m, int cols, float *out, int accumulate, float *partial,
                   size_t partial_bytes, hipStream_t st);
+int launch_colsum_blocks(const float *a, int64_t lda, int64_t m, int num_blocks, int cols_per_block, float *const *outs,
+                         float *partial, size_t partial_bytes, hipStream_t st);
 size_t group_by_key_workspace_bytes(int64_t num_keys);
 int launch_group_by_key(const int32_t *keys, int64_t count, int64_t num_keys, int32_t *rowptr, int32_t *rows,
                         void *workspace, size_t workspace_bytes, int sort_segments, hipStream_t st);

@@ -321,8 +321,14 @@ __global__ __launch_bounds__(256) void k_transpose(TransposeBatch tb, int rows, 
 // kColChunk rows: 8 float4 column groups x 32 row lanes, every thread's 8 rows loaded back to back (independent
 // loads in flight; the first version walked 128 rows per thread one dependent load at a time: 20 us per call).
 constexpr int kColChunk = 256;
+// `direct` (single chunk): write the sums to their destinations at once, no second launch
+struct ColsumOut {
+  float *base[4];
+  int cols_per_block;
+};
 __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict__ a, int64_t lda, int64_t m, int cols,
-                                                        float *__restrict__ partial) {
+                                                        float *__restrict__ partial, ColsumOut co, int direct,
+                                                        int accumulate) {
   __shared__ double red[32][33];
   const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;  // float4 column group, row lane
   const int c0 = blockIdx.x * 32 + cg * 4;
@@ -365,12 +371,20 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float *__restrict_
     double s = 0.0;
 #pragma unroll
     for (int o = 0; o < 32; ++o) s += red[o][threadIdx.x];
-    if (c < cols) partial[(int64_t)blockIdx.y * cols + c] = (float)s;
+    if (c < cols) {
+      if (direct) {
+        const int blk = c / co.cols_per_block;
+        float *o = co.base[blk] + (c - blk * co.cols_per_block);
+        *o = accumulate ? *o + (float)s : (float)s;
+      } else {
+        partial[(int64_t)blockIdx.y * cols + c] = (float)s;
+      }
+    }
   }
 }
 // 32 columns x 8 chunk lanes per workgroup
 __global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ partial, int64_t chunks, int cols,
-                                                      float *__restrict__ out, int accumulate) {
+                                                      ColsumOut co, int accumulate) {
   __shared__ double red[8][33];
   const int cl = threadIdx.x & 31, lane = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -390,7 +404,9 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ 
   __syncthreads();
   if (lane == 0 && c < cols) {
     for (int o = 1; o < 8; ++o) s += red[o][cl];
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
+    const int blk = c / co.cols_per_block;
+    float *o = co.base[blk] + (c - blk * co.cols_per_block);
+    *o = accumulate ? *o + (float)s : (float)s;
   }
 }
 
@@ -518,17 +534,36 @@ int launch_transpose(int count, const float *const *in, float *const *out, const
   return GNNSAFT_OK;
 }
 
-int launch_colsum(const float *a, int64_t lda, int64_t m, int cols, float *out, int accumulate, float *partial,
-                  size_t partial_bytes, hipStream_t st) {
-  GS_REQUIRE(a && out && partial, GNNSAFT_ERR_NULL);
+static int colsum_impl(const float *a, int64_t lda, int64_t m, int cols, const ColsumOut &co, int accumulate,
+                       float *partial, size_t partial_bytes, hipStream_t st) {
+  GS_REQUIRE(a && partial, GNNSAFT_ERR_NULL);
   const int64_t chunks = gs_ceil_div(m > 0 ? m : 1, kColChunk);
   GS_REQUIRE(partial_bytes >= (size_t)chunks * cols * 4, GNNSAFT_ERR_WORKSPACE);
+  const int direct = chunks == 1;
   hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)gs_ceil_div(cols, 32), (unsigned)chunks), dim3(256), 0, st, a,
-                     lda, m, cols, partial);
-  hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)gs_ceil_div(cols, 32)), dim3(256), 0, st, partial, chunks, cols,
-                     out, accumulate);
+                     lda, m, cols, partial, co, direct, accumulate);
+  if (!direct)
+    hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)gs_ceil_div(cols, 32)), dim3(256), 0, st, partial, chunks, cols,
+                       co, accumulate);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
+}
+
+int launch_colsum(const float *a, int64_t lda, int64_t m, int cols, float *out, int accumulate, float *partial,
+                  size_t partial_bytes, hipStream_t st) {
+  GS_REQUIRE(out != nullptr, GNNSAFT_ERR_NULL);
+  ColsumOut co{{out, out, out, out}, 1 << 30};
+  return colsum_impl(a, lda, m, cols, co, accumulate, partial, partial_bytes, st);
+}
+
+// column sums of [m, num_blocks * cols_per_block], block b written to outs[b] (several bias gradients in one pass)
+int launch_colsum_blocks(const float *a, int64_t lda, int64_t m, int num_blocks, int cols_per_block, float *const *outs,
+                         float *partial, size_t partial_bytes, hipStream_t st) {
+  GS_REQUIRE(outs != nullptr && num_blocks >= 1 && num_blocks <= 4 && cols_per_block >= 1, GNNSAFT_ERR_SHAPE);
+  ColsumOut co;
+  for (int i = 0; i < 4; ++i) co.base[i] = outs[i < num_blocks ? i : 0];
+  co.cols_per_block = cols_per_block;
+  return colsum_impl(a, lda, m, num_blocks * cols_per_block, co, 0, partial, partial_bytes, st);
 }
 
 }  // namespace gs
