@@ -594,12 +594,30 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     const float *rtab = F(p.rtab) + l * C * (int64_t)(2 * h);
     const float *cenc = F(p.cenc) + l * C * (int64_t)h;
 
+    // every weight transpose this layer's dgrads need, in one launch:
+    //   wlinT | wxT[j][t F/2 + o] = W_post,t[o][j] | wpqT[j][blk F + f] = W_pre,t[f][part F + j] |
+    //   wcT[j][t F + f] = W_pre,t[f][2F + j] | weT
+    {
+      const int64_t h3 = 3 * (int64_t)h, h13 = 13 * (int64_t)h, h4 = 4 * (int64_t)h, h2 = 2 * (int64_t)h;
+      const TransposeItem items[10] = {
+          {w.wlin, wlinT, h, h, h, h},
+          {w.wpost[0][0], wxT, h13, h, h / 2, h},
+          {w.wpost[1][0], wxT + h / 2, h13, h, h / 2, h},
+          {w.wpre[0][0], wpqT, h3, h4, h, h},
+          {w.wpre[1][0], wpqT + h, h3, h4, h, h},
+          {w.wpre[0][0] + h, wpqT + 2 * h, h3, h4, h, h},
+          {w.wpre[1][0] + h, wpqT + 3 * h, h3, h4, h, h},
+          {w.wpre[0][0] + 2 * h, wcT, h3, h2, h, h},
+          {w.wpre[1][0] + 2 * h, wcT + h, h3, h2, h, h},
+          {w.we, weT, h, h, h, h},
+      };
+      GS_TRY(launch_transpose_list(10, items, st));
+    }
     // x_{l+1} = relu(bn(y)) + x_l : dy through BN+ReLU; the skip gradient stays in dx
     GS_TRY(bn_relu_backward(y_l, dx, stat, w.bn.gamma, w.bn.beta, n, h, G(i_bn), G(i_bn + 1), dy, bnpart, st));
     // lin
     GS_TRY(launch_wgrad_plain(dy, h, u_l, h, 0, n, h, h, G(i_lin), h, 0, slabs, slab_bytes, st));
     GS_TRY(launch_colsum(dy, h, n, h, G(i_lin + 1), 0, slabs, slab_bytes, st));
-    GS_TRY(transpose1(w.wlin, h, wlinT, h, h, h));
     GS_TRY(dgrad(dy, h, wlinT, h, du, h, n, h, h, nullptr));
     // extra post layers (Linear(F/2,F/2) after a ReLU, per tower), last to first: du_j -> du_{j-1}
     for (int j = q - 1; j >= 1; --j) {
@@ -633,10 +651,6 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     }
     // update dgrad, x part: dx_in = (skip ? dx : 0) + du [N,F] x [W_x,0 ; W_x,1]
     {
-      const float *ins[2] = {w.wpost[0][0], w.wpost[1][0]};
-      float *outs[2] = {wxT, wxT + h / 2};
-      const int64_t ldi[2] = {13 * (int64_t)h, 13 * (int64_t)h}, ldo[2] = {h, h};
-      GS_TRY(launch_transpose(2, ins, outs, ldi, ldo, h / 2, h, st));  // wxT[j][t*F/2 + o] = W_t[o][j]
       GS_TRY(dgrad(du, h, wxT, h, dx_other, h, n, h, h, d->skip_connections ? dx : nullptr));
     }
     // update dgrad, aggregate part (degree-tiled, scalers folded): dagg[i,t,:] = du_t[i] W_A,eff(d_i, t)
@@ -701,11 +715,6 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     }
     // message GEMMs: dx_in += [dP | dQ] W_pq ; dW_dst,t / dW_src,t = dP_t^T x / dQ_t^T x
     {
-      const float *ins[4] = {w.wpre[0][0], w.wpre[1][0], w.wpre[0][0] + h, w.wpre[1][0] + h};
-      float *outs[4] = {wpqT, wpqT + h, wpqT + 2 * h, wpqT + 3 * h};
-      const int64_t ldi[4] = {3 * (int64_t)h, 3 * (int64_t)h, 3 * (int64_t)h, 3 * (int64_t)h};
-      const int64_t ldo[4] = {4 * (int64_t)h, 4 * (int64_t)h, 4 * (int64_t)h, 4 * (int64_t)h};
-      GS_TRY(launch_transpose(4, ins, outs, ldi, ldo, h, h, st));  // wpqT[j][blk*F + f] = pre_t[f][part*F + j]
       GS_TRY(dgrad(dpq, 4 * (int64_t)h, wpqT, 4 * (int64_t)h, dx, h, n, h, 4 * h, dx_other));
       {  // dW_dst,t0 | dW_dst,t1 | dW_src,t0 | dW_src,t1 = dPQ^T x: one TN GEMM, four [F,F] blocks of two matrices
         float *blocks[4] = {G(i_pre0), G(i_pre1), G(i_pre0) + h, G(i_pre1) + h};
@@ -724,14 +733,9 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       GS_TRY(launch_colsum_blocks(dr, 2 * (int64_t)h, C, 2, h, outs, slabs, slab_bytes, st));
     }
     {
-      const float *ins[2] = {w.wpre[0][0] + 2 * h, w.wpre[1][0] + 2 * h};
-      float *outs[2] = {wcT, wcT + h};
-      const int64_t ldi[2] = {3 * (int64_t)h, 3 * (int64_t)h}, ldo[2] = {2 * (int64_t)h, 2 * (int64_t)h};
-      GS_TRY(launch_transpose(2, ins, outs, ldi, ldo, h, h, st));  // wcT[j][t*F + f] = pre_t[f][2F + j]
       GS_TRY(dgrad(dr, 2 * (int64_t)h, wcT, 2 * (int64_t)h, dcenc, h, C, h, 2 * h, nullptr));
       GS_TRY(launch_wgrad_plain(dcenc, h, F(p.cemb), h, 0, C, h, h, G(base + 1), h, 0, slabs, slab_bytes, st));
       GS_TRY(launch_colsum(dcenc, h, C, h, G(base + 2), 0, slabs, slab_bytes, st));
-      GS_TRY(transpose1(w.we, h, weT, h, h, h));
       GS_TRY(dgrad(dcenc, h, weT, h, dcemb, h, C, h, h, dcemb));  // accumulate over layers (in place)
     }
     // dx now holds dL/dx_l; dx_other is free again

@@ -155,6 +155,15 @@ size_t wgrad_post_folded_slab_bytes(int64_t tile_cap, int tile_rows, int hidden)
 // out[c, :] = sum of the rows of `a` whose class id is c (one-hot TN GEMM: deterministic, no atomics)
 int launch_sum_rows_by_class(const int32_t *cls, int num_classes, const float *a, int64_t lda, int64_t m, int k,
                              float *out, int64_t ld_out, float *slabs, size_t slab_bytes, hipStream_t st);
+constexpr int kMaxTransposeBatch = 12;
+struct TransposeItem {
+  const float *in;
+  float *out;
+  int64_t ld_in, ld_out;
+  int rows, cols;  // of `in`
+};
+// out[c][r] = in[r][c] for up to kMaxTransposeBatch small matrices of different shapes in one launch
+int launch_transpose_list(int count, const TransposeItem *items, hipStream_t st);
 int launch_transpose(int count, const float *const *in, float *const *out, const int64_t *ld_in, const int64_t *ld_out,
                      int rows, int cols, hipStream_t st);
 int launch_colsum(const float *a, int64_t lda, int64_t m, int cols, float *out, int accumulate, float *partial,

@@ -292,16 +292,20 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ sla
 
 // out[c][r] = in[r][c] for a batch of small matrices (weights): LDS-tiled 32x32
 struct TransposeBatch {
-  const float *in[kMaxGemmBatch];
-  float *out[kMaxGemmBatch];
-  int64_t ld_in[kMaxGemmBatch];
-  int64_t ld_out[kMaxGemmBatch];
+  const float *in[kMaxTransposeBatch];
+  float *out[kMaxTransposeBatch];
+  int64_t ld_in[kMaxTransposeBatch];
+  int64_t ld_out[kMaxTransposeBatch];
+  int rows[kMaxTransposeBatch];
+  int cols[kMaxTransposeBatch];
 };
-__global__ __launch_bounds__(256) void k_transpose(TransposeBatch tb, int rows, int cols) {
+__global__ __launch_bounds__(256) void k_transpose(TransposeBatch tb) {
   __shared__ float t[32][33];
   const float *in = tb.in[blockIdx.z];
   float *out = tb.out[blockIdx.z];
   const int64_t ldi = tb.ld_in[blockIdx.z], ldo = tb.ld_out[blockIdx.z];
+  const int rows = tb.rows[blockIdx.z], cols = tb.cols[blockIdx.z];
+  if ((int)blockIdx.y * 32 >= rows || (int)blockIdx.x * 32 >= cols) return;  // grid is sized for the largest entry
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
 #pragma unroll
@@ -516,22 +520,35 @@ int launch_sum_rows_by_class(const int32_t *cls, int num_classes, const float *a
                                   slab_bytes, st);
 }
 
-int launch_transpose(int count, const float *const *in, float *const *out, const int64_t *ld_in, const int64_t *ld_out,
-                     int rows, int cols, hipStream_t st) {
-  GS_REQUIRE(count >= 1 && count <= kMaxGemmBatch, GNNSAFT_ERR_SHAPE);
+int launch_transpose_list(int count, const TransposeItem *items, hipStream_t st) {
+  GS_REQUIRE(count >= 1 && count <= kMaxTransposeBatch && items != nullptr, GNNSAFT_ERR_SHAPE);
   TransposeBatch tb;
-  for (int i = 0; i < kMaxGemmBatch; ++i) {
-    const int j = i < count ? i : 0;
-    tb.in[i] = in[j];
-    tb.out[i] = out[j];
-    tb.ld_in[i] = ld_in[j];
-    tb.ld_out[i] = ld_out[j];
-    GS_REQUIRE(tb.in[i] && tb.out[i], GNNSAFT_ERR_NULL);
+  int max_rows = 1, max_cols = 1;
+  for (int i = 0; i < kMaxTransposeBatch; ++i) {
+    const TransposeItem &it = items[i < count ? i : 0];
+    tb.in[i] = it.in;
+    tb.out[i] = it.out;
+    tb.ld_in[i] = it.ld_in;
+    tb.ld_out[i] = it.ld_out;
+    tb.rows[i] = it.rows;
+    tb.cols[i] = it.cols;
+    GS_REQUIRE(it.in && it.out && it.rows >= 1 && it.cols >= 1, GNNSAFT_ERR_NULL);
+    max_rows = it.rows > max_rows ? it.rows : max_rows;
+    max_cols = it.cols > max_cols ? it.cols : max_cols;
   }
-  hipLaunchKernelGGL(k_transpose, dim3((unsigned)gs_ceil_div(cols, 32), (unsigned)gs_ceil_div(rows, 32), (unsigned)count),
-                     dim3(256), 0, st, tb, rows, cols);
+  hipLaunchKernelGGL(k_transpose, dim3((unsigned)gs_ceil_div(max_cols, 32), (unsigned)gs_ceil_div(max_rows, 32),
+                                        (unsigned)count),
+                     dim3(256), 0, st, tb);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
+}
+
+int launch_transpose(int count, const float *const *in, float *const *out, const int64_t *ld_in, const int64_t *ld_out,
+                     int rows, int cols, hipStream_t st) {
+  GS_REQUIRE(count >= 1 && count <= kMaxTransposeBatch, GNNSAFT_ERR_SHAPE);
+  TransposeItem items[kMaxTransposeBatch];
+  for (int i = 0; i < count; ++i) items[i] = TransposeItem{in[i], out[i], ld_in[i], ld_out[i], rows, cols};
+  return launch_transpose_list(count, items, st);
 }
 
 static int colsum_impl(const float *a, int64_t lda, int64_t m, int cols, const ColsumOut &co, int accumulate,
