@@ -144,16 +144,34 @@ def main() -> None:
     # The captured graph holds the forward + loss kernels only; for N > 1 the (tiny) loss exchange is issued
     # right behind every replay, outside the graph (RCCL inside a captured graph is not exercised here).
     use_graph = bool(args.graph)
-    with torch.no_grad(), torch.cuda.stream(stream):
-        for _ in range(max(args.warmup, 1) if use_graph else args.warmup):
-            loss = step()
-        barrier()
-        graph = None
+    graph, parts_static, graph_note = None, None, None
+    with torch.no_grad():
+        with torch.cuda.stream(stream):
+            for _ in range(max(args.warmup, 1) if use_graph else args.warmup):
+                loss = step()
+            barrier()
         if use_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                parts_static = model.training_step_parts(ddev)
-            graph.replay()
+            # captured on its own stream, thread-local error mode: a HIP call of another thread (e.g. the process
+            # group's watchdog) must not invalidate it; if the capture is refused anyway, the timed steps fall back
+            # to eager launches on the untouched `stream` and the JSON line says so
+            try:
+                cap_stream = torch.cuda.Stream(dev)
+                cap_stream.wait_stream(stream)
+                g_obj = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_obj, stream=cap_stream, capture_error_mode="thread_local"):
+                    parts_static = model.training_step_parts(ddev)
+                stream.wait_stream(cap_stream)
+                with torch.cuda.stream(stream):
+                    g_obj.replay()
+                torch.cuda.synchronize(dev)
+                graph = g_obj
+            except Exception as exc:  # noqa: BLE001
+                graph, graph_note = None, f"capture failed: {type(exc).__name__}: {exc}"[:200]
+                try:
+                    torch.cuda.synchronize(dev)
+                except Exception:  # noqa: BLE001
+                    pass
+    with torch.no_grad(), torch.cuda.stream(stream):
 
         def replay_step():
             graph.replay()
@@ -276,7 +294,8 @@ def main() -> None:
                             f"L={cfg['depth']} pre=post=1 mlp=1 P=3 skip+self-loops, train-mode BatchNorm forward + "
                             f"MAPE loss, no backward",
                 "graphs_per_gpu": cfg["graphs"], "nodes": n, "edges": e, "edges_with_self_loops": e_prime,
-                "launch": "hipGraph replay" if graph is not None else "eager (one C call per step)",
+                "launch": "hipGraph replay" if graph is not None else "eager (one C call per step)" +
+                          (f" [{graph_note}]" if graph_note else ""),
                 "loss_exchange": "RCCL all-reduce of [sum(ape), count]" if world > 1 else "none (1 GPU)",
             },
             "roofline": {
