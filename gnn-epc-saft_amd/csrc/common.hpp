@@ -219,11 +219,20 @@ __device__ __forceinline__ void block_degree_hist(int d, bool live, int32_t *__r
 }
 
 // internal fused launchers used by gnnsaft_forward (the C entry points keep the one-job-per-call form)
+int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_atom_cols,
+                            const float *const *atom_tables_host, const int32_t *atom_dims_host,
+                            int32_t num_bond_cols, const float *const *bond_tables_host,
+                            const int32_t *bond_dims_host, int32_t hidden, float *x_out, float *cemb,
+                            int32_t *zero_ptr, int64_t zero_count, int32_t fold_layers,
+                            const float *const *w_post0_host, const float *const *w_post1_host,
+                            const float *const *w_pre0_host, const float *const *w_pre1_host, float *g_all,
+                            int32_t *err_flag, hipStream_t st);
+void csr_zero_region(void *workspace, int64_t num_nodes, int32_t **ptr, int64_t *count);
 int launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_t num_nodes, int64_t num_edges,
                      int32_t num_bond_cols, const int32_t *bond_dims_host, int32_t self_loops, int32_t *rowptr,
                      int32_t *src, int32_t *dst, int32_t *combo, float *log_amp, float *log_att, int32_t *err_flag,
                      void *workspace, size_t workspace_bytes, const int64_t *batch, int64_t num_graphs,
-                     int32_t *graph_ptr, int32_t *degree_block_hist, hipStream_t st);
+                     int32_t *graph_ptr, int32_t *degree_block_hist, bool counts_zeroed, hipStream_t st);
 int launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm, int32_t *tiles,
                         int32_t *num_tiles, int32_t *scratch, int32_t *err_flag, bool have_block_hist, hipStream_t st);
 int launch_fold_post_weights(int32_t num_layers, const float *const *w_post0_host, const float *const *w_post1_host,

@@ -370,11 +370,18 @@ extern "C" size_t gnnsaft_csr_workspace_bytes(int64_t num_nodes, int64_t num_edg
          gs_align_up((size_t)(num_edges + num_nodes + 1) * 4, 256);  // eid lives in the loop-padded row space
 }
 
+// the int32 region launch_csr_build expects zeroed (in-degree counts + fill cursors) when told `counts_zeroed`
+void gs::csr_zero_region(void *workspace, int64_t num_nodes, int32_t **ptr, int64_t *count) {
+  *ptr = static_cast<int32_t *>(workspace);
+  *count = 2 * (int64_t)gs_align_up((size_t)num_nodes * 4, 256) / 4;
+}
+
 int gs::launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_t num_nodes, int64_t num_edges,
                          int32_t num_bond_cols, const int32_t *bond_dims_host, int32_t self_loops, int32_t *rowptr,
                          int32_t *src, int32_t *dst, int32_t *combo, float *log_amp, float *log_att,
                          int32_t *err_flag, void *workspace, size_t workspace_bytes, const int64_t *batch,
-                         int64_t num_graphs, int32_t *graph_ptr, int32_t *degree_block_hist, hipStream_t st) {
+                         int64_t num_graphs, int32_t *graph_ptr, int32_t *degree_block_hist, bool counts_zeroed,
+                         hipStream_t st) {
   GS_REQUIRE(rowptr && src && dst && combo && log_amp && log_att && workspace, GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_edges == 0 || (edge_index != nullptr && edge_attr != nullptr), GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_nodes >= 0 && num_edges >= 0, GNNSAFT_ERR_SHAPE);
@@ -404,7 +411,7 @@ int gs::launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, in
   }
 
   const int tb = 256;
-  if (n > 0) {
+  if (n > 0 && !counts_zeroed) {
     // counts and cursor are adjacent up to alignment: zero both
     hipLaunchKernelGGL(gs::k_zero_i32, dim3((unsigned)gs_ceil_div(2 * (int64_t)gs_align_up((size_t)n * 4, 256) / 4, tb)),
                        dim3(tb), 0, st, counts, 2 * (int64_t)gs_align_up((size_t)n * 4, 256) / 4, nullptr);
@@ -435,7 +442,7 @@ extern "C" int gnnsaft_csr_build(const int64_t *edge_index, const int64_t *edge_
                                  size_t workspace_bytes, gnnsaft_stream_t stream) {
   return gs::launch_csr_build(edge_index, edge_attr, num_nodes, num_edges, num_bond_cols, bond_dims_host, self_loops,
                               rowptr, src, dst, combo, log_amp, log_att, err_flag, workspace, workspace_bytes, nullptr,
-                              0, nullptr, nullptr, static_cast<hipStream_t>(stream));
+                              0, nullptr, nullptr, false, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gnnsaft_batch_to_ptr(const int64_t *batch, int64_t num_nodes, int64_t num_graphs, int32_t *graph_ptr,

@@ -11,6 +11,7 @@
 // which cuts the dominant GEMM's K from 13F to 5F.  Degrees >= kDegreeBuckets are flagged
 // (GNNSAFT_FLAG_BAD_DEGREE) and clamped; callers with such graphs disable folding.
 #include "common.hpp"
+#include "fold.hpp"
 
 namespace gs {
 
@@ -114,48 +115,8 @@ __global__ __launch_bounds__(kDegBlock) void k_degree_fill(const int32_t *__rest
   perm[start[d] + block_base[(int64_t)blockIdx.x * kDegreeBuckets + d] + before + rank] = (int32_t)i;
 }
 
-// w_eff[d][t][o][0:F] = W_t[o][0:F];  w_eff[d][t][o][F+j] = W_t[o][F+j] + amp(d) W_t[o][5F+j] + att(d) W_t[o][9F+j]
-struct FoldLayers {
-  const float *w0[GNNSAFT_MAX_FOLD_LAYERS];
-  const float *w1[GNNSAFT_MAX_FOLD_LAYERS];
-  const float *avg[GNNSAFT_MAX_FOLD_LAYERS];
-  const float *pre0[GNNSAFT_MAX_FOLD_LAYERS];  // pre_nns[t][0].weight [F,3F] or null: fold the destination term
-  const float *pre1[GNNSAFT_MAX_FOLD_LAYERS];
-};
-
-// Destination-term fold.  msg = P_i + m~ with P_i = W_dst x_i constant over a node's in-edges, so
-// mean/min/max(msg) = P_i + mean/min/max(m~) and std(msg) = std(m~).  The update's aggregate block
-// then contributes  sum_s scale_s(d) (W_s,mean + W_s,min + W_s,max) P_i, i.e. an extra x-block
-//   G_s = (W_s,mean + W_s,min + W_s,max) W_dst      ([F/2, F] per layer, tower, scaler s)
-// so the W_dst GEMM over all nodes disappears.  Tiled f32 matmul, 32x32 outputs per workgroup.
 __global__ __launch_bounds__(256) void k_dst_fold(FoldLayers fl, int f, float *__restrict__ g_all) {
-  __shared__ float as[32][33], bs[32][33];
-  const int layer = blockIdx.z / 6, rem = blockIdx.z % 6, t = rem / 3, sc = rem % 3;
-  const float *wpost = t == 0 ? fl.w0[layer] : fl.w1[layer];
-  const float *wpre = t == 0 ? fl.pre0[layer] : fl.pre1[layer];
-  const int o0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < f; k0 += 32) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int o = o0 + ty + 8 * r;  // A[o][k] = sum over the mean, min, max column blocks of scaler sc
-      const float *w = wpost + (int64_t)o * (13 * f) + f + sc * 4 * f + k0 + tx;
-      as[ty + 8 * r][tx] = (w[0] + w[f]) + w[2 * f];
-      bs[ty + 8 * r][tx] = wpre[(int64_t)(k0 + ty + 8 * r) * (3 * f) + j0 + tx];  // W_dst[k][j]
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-      const float b = bs[k][tx];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] += as[ty + 8 * r][k] * b;
-    }
-    __syncthreads();
-  }
-  float *g = g_all + ((((int64_t)layer * 2 + t) * 3 + sc) * (f / 2)) * f;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) g[(int64_t)(o0 + ty + 8 * r) * f + j0 + tx] = acc[r];
+  dst_fold_body(fl, f, g_all, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 __global__ __launch_bounds__(256) void k_fold_post_weights(FoldLayers fl, const int32_t *__restrict__ hist, int f,

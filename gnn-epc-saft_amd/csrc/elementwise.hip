@@ -3,6 +3,7 @@
 // 122-123), BatchNorm finalize / apply (models.py:82,128-131), global_add_pool
 // (models.py:133) and the MAPE loss (models.py:194).  All float4 per lane.
 #include "common.hpp"
+#include "fold.hpp"
 
 namespace gs {
 
@@ -14,9 +15,9 @@ struct TableSet {
 
 // out[i, :] = sum_k tab_k[idx[i,k], :]   (left-to-right, as ogb's encoder loop)
 template <int MAXT>
-__global__ __launch_bounds__(256) void k_embed_sum(const int64_t *__restrict__ idx, int64_t rows, TableSet ts, int h,
-                                                   float *__restrict__ out, int32_t *err, RowSplit rs) {
-  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void embed_sum_body(int64_t slot, const int64_t *__restrict__ idx, int64_t rows,
+                                               const TableSet &ts, int h, float *__restrict__ out, int32_t *err,
+                                               const RowSplit &rs) {
   int64_t i;
   int lane_in_row;
   gs_split(rs, slot, i, lane_in_row);
@@ -44,10 +45,16 @@ __global__ __launch_bounds__(256) void k_embed_sum(const int64_t *__restrict__ i
   gs_st4(out + i * h + c, acc);
 }
 
+template <int MAXT>
+__global__ __launch_bounds__(256) void k_embed_sum(const int64_t *__restrict__ idx, int64_t rows, TableSet ts, int h,
+                                                   float *__restrict__ out, int32_t *err, RowSplit rs) {
+  embed_sum_body<MAXT>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, idx, rows, ts, h, out, err, rs);
+}
+
 // out[c, :] = sum_k tab_k[digit_k(c), :] for every attribute combination c
-__global__ __launch_bounds__(256) void k_combo_embed(TableSet ts, int64_t combos, int h, float *__restrict__ out) {
+__device__ __forceinline__ void combo_embed_body(int64_t slot, const TableSet &ts, int64_t combos, int h,
+                                                 float *__restrict__ out) {
   const int per_row = h / 4;
-  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t cid = slot / per_row;
   if (cid >= combos) return;
   const int c = (int)(slot - cid * per_row) * 4;
@@ -60,6 +67,55 @@ __global__ __launch_bounds__(256) void k_combo_embed(TableSet ts, int64_t combos
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < ts.n; ++k) acc += gs_ld4(ts.tab[k] + (int64_t)digit[k] * h + c);
   gs_st4(out + cid * h + c, acc);
+}
+
+__global__ __launch_bounds__(256) void k_combo_embed(TableSet ts, int64_t combos, int h, float *__restrict__ out) {
+  combo_embed_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, ts, combos, h, out);
+}
+
+// The four independent first kernels of a forward in ONE launch (workgroup ranges dispatch to the job bodies):
+// atom embedding sum | bond-class embedding table | zeroing of the CSR histogram / cursor | destination-term
+// weight fold.  None reads what another writes, and each is otherwise a 3-10 us launch at the head of a
+// dependent chain.
+struct PrologueArgs {
+  // embedding sum
+  const int64_t *x_idx;
+  int64_t rows;
+  TableSet atoms;
+  float *x_out;
+  int32_t *err;
+  RowSplit rs;
+  // bond-class table
+  TableSet bonds;
+  int64_t combos;
+  float *cemb;
+  // zero fill
+  int32_t *zero_ptr;
+  int64_t zero_count;
+  // destination-term fold (dst_blocks == 0: off)
+  FoldLayers fl;
+  float *g_all;
+  int dst_gx, dst_gy;
+  int h;
+  unsigned end_embed, end_combo, end_zero;  // exclusive workgroup bounds of the first three jobs
+};
+
+template <int MAXT>
+__global__ __launch_bounds__(256) void k_forward_prologue(PrologueArgs a) {
+  const unsigned b = blockIdx.x;
+  if (b < a.end_embed) {
+    embed_sum_body<MAXT>((int64_t)b * 256 + threadIdx.x, a.x_idx, a.rows, a.atoms, a.h, a.x_out, a.err, a.rs);
+  } else if (b < a.end_combo) {
+    combo_embed_body((int64_t)(b - a.end_embed) * 256 + threadIdx.x, a.bonds, a.combos, a.h, a.cemb);
+  } else if (b < a.end_zero) {
+    const int64_t i = (int64_t)(b - a.end_combo) * 256 + threadIdx.x;
+    if (i < a.zero_count) a.zero_ptr[i] = 0;
+  } else {
+    const unsigned d = b - a.end_zero;
+    const int per_z = a.dst_gx * a.dst_gy;
+    const int bz = d / per_z, r = d - bz * per_z;
+    dst_fold_body(a.fl, a.h, a.g_all, r % a.dst_gx, r / a.dst_gx, bz);
+  }
 }
 
 // ---- BatchNorm: one workgroup per channel, Chan combine of (mean, M2) partials in f64
@@ -200,6 +256,61 @@ static int make_tables(int32_t num_cols, const float *const *tables_host, const 
     ts.tab[k] = k < num_cols ? tables_host[k] : nullptr;
     if (k < num_cols) GS_REQUIRE(ts.tab[k] != nullptr && ts.dims[k] >= 1, GNNSAFT_ERR_NULL);
   }
+  return GNNSAFT_OK;
+}
+
+int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_atom_cols,
+                            const float *const *atom_tables_host, const int32_t *atom_dims_host,
+                            int32_t num_bond_cols, const float *const *bond_tables_host,
+                            const int32_t *bond_dims_host, int32_t hidden, float *x_out, float *cemb,
+                            int32_t *zero_ptr, int64_t zero_count, int32_t fold_layers,
+                            const float *const *w_post0_host, const float *const *w_post1_host,
+                            const float *const *w_pre0_host, const float *const *w_pre1_host, float *g_all,
+                            int32_t *err_flag, hipStream_t st) {
+  GS_REQUIRE(x_idx && x_out && cemb && num_rows >= 1, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 4 && (hidden % 4) == 0, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(fold_layers >= 0 && fold_layers <= GNNSAFT_MAX_FOLD_LAYERS, GNNSAFT_ERR_SHAPE);
+  PrologueArgs a;
+  int rc = make_tables(num_atom_cols, atom_tables_host, atom_dims_host, a.atoms);
+  if (rc != GNNSAFT_OK) return rc;
+  rc = make_tables(num_bond_cols, bond_tables_host, bond_dims_host, a.bonds);
+  if (rc != GNNSAFT_OK) return rc;
+  a.x_idx = x_idx;
+  a.rows = num_rows;
+  a.x_out = x_out;
+  a.err = err_flag;
+  a.rs = gs_row_split(hidden / 4);
+  a.combos = 1;
+  for (int k = 0; k < num_bond_cols; ++k) a.combos *= a.bonds.dims[k];
+  GS_REQUIRE(a.combos <= (1 << 20), GNNSAFT_ERR_UNSUPPORTED);
+  a.cemb = cemb;
+  a.zero_ptr = zero_ptr;
+  a.zero_count = zero_ptr != nullptr ? zero_count : 0;
+  a.g_all = g_all;
+  a.h = hidden;
+  for (int i = 0; i < GNNSAFT_MAX_FOLD_LAYERS; ++i) {
+    const int j = i < fold_layers ? i : 0;
+    a.fl.w0[i] = fold_layers ? w_post0_host[j] : nullptr;
+    a.fl.w1[i] = fold_layers ? w_post1_host[j] : nullptr;
+    a.fl.avg[i] = nullptr;
+    a.fl.pre0[i] = fold_layers ? w_pre0_host[j] : nullptr;
+    a.fl.pre1[i] = fold_layers ? w_pre1_host[j] : nullptr;
+  }
+  GS_REQUIRE(fold_layers == 0 || ((hidden % 64) == 0 && g_all != nullptr), GNNSAFT_ERR_SHAPE);
+  a.dst_gx = hidden / 32;
+  a.dst_gy = hidden / 64;
+  const int64_t be = gs_ceil_div(num_rows * (hidden / 4), 256), bc = gs_ceil_div(a.combos * (hidden / 4), 256);
+  const int64_t bz = gs_ceil_div(a.zero_count, 256), bd = (int64_t)a.dst_gx * a.dst_gy * 6 * fold_layers;
+  GS_REQUIRE(be + bc + bz + bd < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);
+  a.end_embed = (unsigned)be;
+  a.end_combo = (unsigned)(be + bc);
+  a.end_zero = (unsigned)(be + bc + bz);
+  const dim3 grid((unsigned)(be + bc + bz + bd));
+  if (num_atom_cols <= 9)
+    hipLaunchKernelGGL(k_forward_prologue<9>, grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_forward_prologue<GNNSAFT_MAX_TABLES>, grid, dim3(256), 0, st, a);
+  GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }
 

@@ -372,6 +372,25 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
   const int64_t wstride = (int64_t)kDegreeBuckets * 5 * h * h;  // floats per layer in weff
   // ---- K0 structure chain, on the side stream when the caller lends one: destination-term fold (weights only),
   //      CSR, graph offsets, degree tiles, degree-folded update weights
+  // The four independent first jobs (atom embedding sum, bond-class embedding table, zeroing of the CSR
+  // histogram, destination-term weight fold) share ONE launch on the caller's stream; then the chains fork.
+  const bool dst_in_prologue = fold_dst && d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS;
+  {
+    const float *w0[GNNSAFT_MAX_FOLD_LAYERS], *w1[GNNSAFT_MAX_FOLD_LAYERS];
+    const float *p0[GNNSAFT_MAX_FOLD_LAYERS], *p1[GNNSAFT_MAX_FOLD_LAYERS];
+    for (int i = 0; i < GNNSAFT_MAX_FOLD_LAYERS && i < d->num_layers; ++i) {
+      w0[i] = lw[i].wpost[0][0];
+      w1[i] = lw[i].wpost[1][0];
+      p0[i] = lw[i].wpre[0][0];
+      p1[i] = lw[i].wpre[1][0];
+    }
+    int32_t *zero_ptr = nullptr;
+    int64_t zero_count = 0;
+    csr_zero_region(ws + p.csr_ws, n, &zero_ptr, &zero_count);
+    GS_TRY(launch_forward_prologue(x_idx, n, d->num_atom_cols, atom_tab, d->atom_dims, d->num_bond_cols, bond_tab,
+                                   d->bond_dims, h, F(p.x0), F(p.cemb), zero_ptr, zero_count,
+                                   dst_in_prologue ? d->num_layers : 0, w0, w1, p0, p1, F(p.gfold), err_flag, st));
+  }
   hipStream_t sa = st;
   if (aux != nullptr) {
     sa = aux->stream;
@@ -396,21 +415,19 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     }
     return GNNSAFT_OK;
   };
-  if (d->fold_degree_scalers && fold_dst) GS_TRY(fold_weights(1));
+  if (d->fold_degree_scalers && fold_dst && !dst_in_prologue) GS_TRY(fold_weights(1));
   // CSR + graph offsets (batch == NULL: un-batched Data, models.py:116, one graph spanning all nodes) + the first
-  // pass of the degree bucketing, in 6 launches
+  // pass of the degree bucketing, in 5 launches (the histogram was zeroed by the prologue)
   GS_REQUIRE(batch != nullptr || g == 1, GNNSAFT_ERR_SHAPE);
   GS_TRY(launch_csr_build(edge_index, edge_attr, n, num_edges, d->num_bond_cols, d->bond_dims, d->self_loops,
                           I(p.rowptr), I(p.src), I(p.dst), I(p.combo), F(p.log_amp), F(p.log_att), err_flag,
                           ws + p.csr_ws, gnnsaft_csr_workspace_bytes(n, num_edges), batch, g, I(p.graph_ptr),
-                          d->fold_degree_scalers ? I(p.hist3) + 2 * kDegreeBuckets : nullptr, sa));
+                          d->fold_degree_scalers ? I(p.hist3) + 2 * kDegreeBuckets : nullptr, true, sa));
   if (d->fold_degree_scalers)
     GS_TRY(launch_degree_tiles(I(p.rowptr), n, h, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3), err_flag, true,
                                sa));
   if (d->fold_degree_scalers) GS_TRY(fold_weights(2));
-  // ---- K1 embeddings and the edge-class tables of all layers, on the caller's stream
-  GS_TRY(gnnsaft_embed_sum(x_idx, n, d->num_atom_cols, atom_tab, d->atom_dims, h, F(p.x0), err_flag, st));
-  GS_TRY(gnnsaft_bond_combo_embed(d->num_bond_cols, bond_tab, d->bond_dims, h, F(p.cemb), st));
+  // ---- the edge-class tables of all layers, on the caller's stream
 
   for (int l0 = 0; l0 < d->num_layers; l0 += kMaxGemmBatch) {
     const int nl = d->num_layers - l0 < kMaxGemmBatch ? d->num_layers - l0 : kMaxGemmBatch;

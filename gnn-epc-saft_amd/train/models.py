@@ -160,7 +160,10 @@ class PNAPCSAFT(nn.Module):
         # to std) into those weights: removes half of the message GEMM and a quarter of K4's reads.  Used when
         # fold_degree_scalers is on, pre_layers == 1 and hidden_dim % 64 == 0; otherwise ignored.
         self.fold_dst_term = True
-        self.use_side_stream = os.environ.get("GNNSAFT_SINGLE_STREAM", "0") != "1"
+        # Optional side stream for the structure chain (gnnsaft_aux).  Off by default: measured on MI355X the
+        # hipGraph replay of the step is 0.490 ms with it and 0.491 ms without (C2), and the graph executor does
+        # not reliably run the two branches concurrently (profiles/r01_c2_graph_replay_timeline.txt).
+        self.use_side_stream = os.environ.get("GNNSAFT_SIDE_STREAM", "0") == "1"
         # backward fast path: set .grad to views of the one flat gradient buffer when every .grad is None
         self.direct_grads = True
         self._profile = None  # gnnsaft_profile* (bench.py attaches one to time kernels with HIP events)
@@ -281,8 +284,7 @@ class PNAPCSAFT(nn.Module):
                 self._workspace = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=dev)
             ws = self._workspace
         if self._err_flag is None or self._err_flag.device != dev:
-            self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._err_flag.zero_()
+            self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)   # sticky: cleared when read
         out = torch.empty((g, desc.num_para), dtype=torch.float32, device=dev)
         tgt_ptr, loss_ptr, loss = None, None, None
         if target is not None:
@@ -366,9 +368,15 @@ class PNAPCSAFT(nn.Module):
         return self._launch(data, None, tape=False)[0]
 
     def input_error_flags(self) -> int:
-        """Synchronises and returns the OR of GNNSAFT_FLAG_* bits raised by the last forward
-        (out-of-range indices are clamped, never dereferenced)."""
-        return 0 if self._err_flag is None else int(self._err_flag.item())
+        """Synchronises, returns and clears the OR of the GNNSAFT_FLAG_* bits raised by the forwards since the
+        last call (out-of-range indices are clamped, never dereferenced).  The flag word is not reset per forward:
+        that would cost a launch at the head of every step for a word that is all but always zero."""
+        if self._err_flag is None:
+            return 0
+        flags = int(self._err_flag.item())
+        if flags:
+            self._err_flag.zero_()
+        return flags
 
     def _apply(self, fn, *args, **kwargs):
         self._workspace = None
