@@ -272,3 +272,41 @@ def test_full_size_properties(config_id):
                 _, loss3 = hip_twin(copy.deepcopy(o)).run(dd, target=tgt.to(DEV))
             want = float(mape(want64, tgt.double()))
             assert abs(float(loss3[0]) - want) < 1e-4 * want
+
+
+def test_side_stream_and_graph_replay_give_the_same_bits():
+    """The optional gnnsaft_aux side stream (structure chain beside the embedding / edge-table chain) and a hipGraph
+    replay of the step only change the schedule: outputs and the loss are bit-identical to the eager single-stream
+    run, also when the same module runs many steps back to back."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    data = make_synthetic_batch(96, 321)
+    oracle = oracle_model(128, 3, 1, 1, 1, 3, True, True, degree_histogram(data), seed=2).train()
+    dd = data.to(DEV)
+    tgt = dd.para.view(-1, 3)
+
+    def run(side, steps):
+        m = hip_twin(copy.deepcopy(oracle))
+        m.use_side_stream = side
+        outs = []
+        with torch.no_grad():
+            for _ in range(steps):
+                pred, loss3 = m.run(dd, target=tgt)
+                outs.append((pred.clone(), loss3.clone()))
+        torch.cuda.synchronize()
+        return m, outs
+
+    _, base = run(False, 4)
+    _, side = run(True, 4)
+    for (p0, l0), (p1, l1) in zip(base, side):
+        assert torch.equal(p0, p1) and torch.equal(l0, l1)
+    # graph capture with the side stream: fork / join become parallel branches of the graph
+    m, _ = run(True, 1)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g, stream=s):
+        pred, loss3 = m.run(dd, target=tgt)
+    for k in range(1, 4):            # the module has seen one step already: replays are steps 2..4
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(pred, base[k][0]) and torch.equal(loss3, base[k][1])
