@@ -1,0 +1,134 @@
+"""PyG-free batch loader for the training loop: what ``torch_geometric.loader.
+DataLoader(train_dataset, batch_size, shuffle=True)`` gives the reference (``/root/reference/gnnepcsaft/train/
+train.py:74-79``) for the fields the hot path reads -- ``x, edge_index, edge_attr, batch, ptr, para,
+num_graphs`` -- delivered device-resident.
+
+The dataset (a list of small per-molecule graphs) is flattened ONCE into packed int64 / float32 arrays with
+per-graph offsets; a batch is then three gathers of contiguous row ranges (no Python loop over tensors, no
+per-graph ``torch.cat``), staged through pinned host buffers and copied on a side HIP stream so that the copy of
+batch k+1 overlaps the training step of batch k.  DataLoader worker processes (``train.py:77``) are not needed:
+collation is a few vectorised index operations per batch.
+"""
+
+from __future__ import annotations
+
+from typing import Iterator, List, Optional, Sequence
+
+import torch
+
+from .synthetic import GraphData
+
+
+class PackedGraphs:
+    """All graphs of a dataset in five flat tensors + offsets (the on-host analogue of PyG's ``(data, slices)``
+    ``InMemoryDataset`` storage, ``graphdataset.py:48``)."""
+
+    def __init__(self, graphs: Sequence):
+        if len(graphs) == 0:
+            raise ValueError("empty dataset")
+        self.num_graphs = len(graphs)
+        n = torch.tensor([int(g.x.shape[0]) for g in graphs], dtype=torch.int64)
+        e = torch.tensor([int(g.edge_index.shape[1]) for g in graphs], dtype=torch.int64)
+        self.node_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), n.cumsum(0)])
+        self.edge_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), e.cumsum(0)])
+        self.x = torch.cat([g.x.to(torch.int64) for g in graphs])
+        self.edge_index = torch.cat([g.edge_index.to(torch.int64) for g in graphs], dim=1)     # graph-local node ids
+        self.edge_attr = torch.cat([g.edge_attr.to(torch.int64) for g in graphs])
+        paras = [g.para for g in graphs]
+        if any(p is None for p in paras):
+            self.para, self.para_width = None, 0
+        else:
+            self.para_width = int(paras[0].numel())
+            self.para = torch.stack([p.reshape(-1).to(torch.float32) for p in paras])
+
+    @staticmethod
+    def _ranges(ptr: torch.Tensor, ids: torch.Tensor):
+        """Indices of the concatenated ranges [ptr[i], ptr[i+1]) for i in ids, and the start of each in the output."""
+        lens = ptr[ids + 1] - ptr[ids]
+        out_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)])
+        total = int(out_ptr[-1])
+        owner = torch.repeat_interleave(torch.arange(ids.numel()), lens)               # batch-local graph of each row
+        idx = torch.arange(total) - out_ptr[owner] + ptr[ids][owner]
+        return idx, owner, out_ptr
+
+    def collate(self, ids: torch.Tensor) -> GraphData:
+        """Batch of the graphs ``ids`` (in that order), identical to ``synthetic.collate([graphs[i] for i in ids])``."""
+        ids = ids.to(torch.int64)
+        nidx, nowner, nptr = self._ranges(self.node_ptr, ids)
+        eidx, eowner, _ = self._ranges(self.edge_ptr, ids)
+        edge_index = self.edge_index[:, eidx] + nptr[eowner]        # re-base graph-local node ids
+        para = None if self.para is None else self.para[ids].reshape(-1)
+        return GraphData(self.x[nidx], edge_index, self.edge_attr[eidx], nowner, nptr, para, int(ids.numel()))
+
+
+class GraphLoader:
+    """Iterable of device-resident batches.  ``for batch in loader`` yields ``GraphData`` on ``device``; every epoch
+    reshuffles with ``seed + epoch`` (``shuffle=True``) like PyG's loader does through its sampler."""
+
+    def __init__(self, graphs, batch_size: int, shuffle: bool = False, drop_last: bool = False,
+                 device: Optional[torch.device] = None, seed: int = 0, rank: int = 0, world_size: int = 1):
+        self.packed = graphs if isinstance(graphs, PackedGraphs) else PackedGraphs(graphs)
+        if batch_size < 1:
+            raise ValueError("batch_size must be positive")
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), bool(shuffle), bool(drop_last)
+        self.device = None if device is None else torch.device(device)
+        self.seed, self.epoch = int(seed), 0
+        self.rank, self.world_size = int(rank), int(world_size)     # DistributedSampler semantics: strided shards
+        self._copy_stream = None
+
+    def __len__(self) -> int:
+        per_rank = (self.packed.num_graphs + self.world_size - 1) // self.world_size
+        return per_rank // self.batch_size if self.drop_last else (per_rank + self.batch_size - 1) // self.batch_size
+
+    def _order(self) -> torch.Tensor:
+        n = self.packed.num_graphs
+        if self.shuffle:
+            order = torch.randperm(n, generator=torch.Generator().manual_seed(self.seed + self.epoch))
+        else:
+            order = torch.arange(n)
+        if self.world_size > 1:      # pad to a multiple of the world size by wrapping around, then stride
+            pad = (-n) % self.world_size
+            if pad:
+                order = torch.cat([order, order[:pad]])
+            order = order[self.rank::self.world_size]
+        return order
+
+    def _batches(self) -> List[torch.Tensor]:
+        order = self._order()
+        chunks = list(order.split(self.batch_size))
+        if self.drop_last and chunks and chunks[-1].numel() < self.batch_size:
+            chunks.pop()
+        return chunks
+
+    def _stage(self, host: GraphData):
+        """Pinned staging + asynchronous copy on the side stream; returns (device batch, ready event)."""
+        dev = self.device
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(dev)
+        pin = lambda t: None if t is None else t.pin_memory()
+        pinned = GraphData(pin(host.x), pin(host.edge_index), pin(host.edge_attr), pin(host.batch), pin(host.ptr),
+                           pin(host.para), host.num_graphs)
+        with torch.cuda.stream(self._copy_stream):
+            out = pinned.to(dev, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self._copy_stream)
+        return out, ready, pinned       # `pinned` is kept alive until the copy has been waited for
+
+    def __iter__(self) -> Iterator[GraphData]:
+        chunks = self._batches()
+        self.epoch += 1
+        if self.device is None or self.device.type != "cuda":
+            for ids in chunks:
+                b = self.packed.collate(ids)
+                yield b if self.device is None else b.to(self.device)
+            return
+        nxt = self._stage(self.packed.collate(chunks[0])) if chunks else None
+        for k in range(len(chunks)):
+            cur = nxt
+            nxt = self._stage(self.packed.collate(chunks[k + 1])) if k + 1 < len(chunks) else None   # overlaps step k
+            batch, ready, _keep = cur
+            torch.cuda.current_stream(self.device).wait_event(ready)
+            for t in (batch.x, batch.edge_index, batch.edge_attr, batch.batch, batch.ptr, batch.para):
+                if t is not None:
+                    t.record_stream(torch.cuda.current_stream(self.device))
+            yield batch

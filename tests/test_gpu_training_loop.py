@@ -86,3 +86,29 @@ def test_sgd_configuration_steps_too():
     assert isinstance(lit.configure_optimizers()["optimizer"], FusedSGD)
     hist = training_loop(lit, batches, max_steps=8, log_every_steps=4, checkpoint_every_steps=0)
     assert len(hist) == 2 and all(v == v for _, v in hist)
+
+
+def test_loader_feeds_the_loop_with_overlapped_copies():
+    """GraphLoader (pinned staging, copies on a side stream) delivers the same device batches as a direct
+    ``.to(device)`` of the collated graphs, and the training loop consumes it over several epochs."""
+    import gnn_epc_saft_amd as G
+    from gnn_epc_saft_amd.data.loader import GraphLoader
+    from gnn_epc_saft_amd.data.synthetic import collate, degree_histogram
+    from gnn_epc_saft_amd.train.loop import training_loop
+    from test_host_cpu import _graph_list
+    graphs = _graph_list(150, 9)
+    ld = GraphLoader(graphs, 64, shuffle=False, device=DEV)
+    got = list(ld)
+    assert [b.num_graphs for b in got] == [64, 64, 22]
+    for k, b in enumerate(got):
+        want = collate(graphs[64 * k:64 * (k + 1)])
+        for f in ("x", "edge_index", "edge_attr", "batch", "ptr", "para"):
+            assert getattr(b, f).device.type == "cuda" and torch.equal(getattr(b, f).cpu(), getattr(want, f)), f
+    cfg = dict(propagation_depth=2, hidden_dim=64, pre_layers=1, post_layers=1, num_mlp_layers=1, num_para=3,
+               skip_connections=True, add_self_loops=True, dropout_rate=0.0, model="PNAL", optimizer="adam",
+               learning_rate=2e-3, weight_decay=1e-2, warmup_steps=50, momentum=0.9, num_train_steps=12,
+               log_every_steps=3, checkpoint_every_steps=0)
+    torch.manual_seed(0)
+    lit = G.create_model(cfg, degree_histogram(graphs)).to(DEV)
+    hist = training_loop(lit, GraphLoader(graphs, 64, shuffle=True, device=DEV, seed=1))      # 4 epochs of 3 batches
+    assert [s for s, _ in hist] == [3, 6, 9, 12] and hist[-1][1] < hist[0][1]

@@ -217,3 +217,45 @@ def test_checkpoint_dialects_round_trip(tmp_path):
     assert all(torch.equal(t.state_dict()[k], v) for k, v in src.state_dict().items())
     with pytest.raises(ValueError):
         C.load_checkpoint(mk(), {"model_state_dict": {"x": 3}})
+
+
+def _graph_list(num, seed):
+    from gnn_epc_saft_amd.data.synthetic import GraphData, make_synthetic_batch
+    b = make_synthetic_batch(num, seed, num_para=3)
+    out = []
+    for g in range(b.num_graphs):
+        n0, n1 = int(b.ptr[g]), int(b.ptr[g + 1])
+        em = (b.edge_index[1] >= n0) & (b.edge_index[1] < n1)
+        out.append(GraphData(b.x[n0:n1], b.edge_index[:, em] - n0, b.edge_attr[em], para=b.para.view(-1, 3)[g]))
+    return out
+
+
+def test_packed_loader_collates_like_pyg_and_shards_like_distributed_sampler():
+    """GraphLoader = PyG DataLoader for the fields the path reads (train.py:74-79): vectorised collation equals the
+    per-graph concatenation, epochs reshuffle deterministically, ranks get disjoint strided shards."""
+    from gnn_epc_saft_amd.data.loader import GraphLoader, PackedGraphs
+    from gnn_epc_saft_amd.data.synthetic import GraphData, collate
+    graphs = _graph_list(37, 5)
+    graphs.append(GraphData(graphs[0].x[:1], torch.zeros((2, 0), dtype=torch.int64),
+                            torch.zeros((0, 3), dtype=torch.int64), para=graphs[0].para))   # 1 node, 0 edges
+    pk = PackedGraphs(graphs)
+    ids = torch.tensor([5, 37, 0, 36, 7, 7, 12])
+    got, want = pk.collate(ids), collate([graphs[i] for i in ids.tolist()])
+    for f in ("x", "edge_index", "edge_attr", "batch", "ptr", "para"):
+        assert torch.equal(getattr(got, f), getattr(want, f)), f
+    assert got.num_graphs == 7
+    ld = GraphLoader(pk, 8, shuffle=True, seed=3)
+    assert len(ld) == 5
+    e1 = [b.para.view(-1, 3) for b in ld]
+    e2 = [b.para.view(-1, 3) for b in ld]
+    assert sum(p.shape[0] for p in e1) == 38 and not torch.equal(torch.cat(e1), torch.cat(e2))   # reshuffled
+    again = GraphLoader(pk, 8, shuffle=True, seed=3)
+    assert torch.equal(torch.cat(e1), torch.cat([b.para.view(-1, 3) for b in again]))              # same seed, same epoch
+    assert len(GraphLoader(pk, 8, drop_last=True)) == 4
+    # two ranks: 19 graphs each, together every graph exactly once (38 is even: no wrap-around padding)
+    parts = [torch.cat([b.para.view(-1, 3) for b in GraphLoader(pk, 8, seed=1, rank=r, world_size=2)])
+             for r in range(2)]
+    assert parts[0].shape[0] == parts[1].shape[0] == 19
+    both = torch.cat(parts)
+    ref = torch.stack([g.para for g in graphs])
+    assert torch.equal(both[both[:, 0].argsort()][:, 0], ref[ref[:, 0].argsort()][:, 0])
