@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   //      row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int half = lane >> 5;
   const int wrow0 = wm * WTM;  // block-local
+  const bool full_tile = ti.count >= BM && n0 + BN <= n_out;  // block-uniform
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * WTN + j * 32 + (lane & 31);
@@ -417,14 +418,26 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) res[r] = epi.residual[grow[r] * epi.ldr + colc];
       }
+      float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int lr = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = acc[i][j][r] + bias;
-        if (AFFINE) v = v * sc + sh;
-        v = epi.relu_out ? fmaxf(v, 0.f) : v;
-        if (RESID) v = epi.residual_is_mask ? (res[r] > 0.f ? v : 0.f) : v + res[r];
-        if (lr < ti.count && col_ok) ent.out[grow[r] * ldo + col] = v;
+        v[r] = acc[i][j][r] + bias;
+        if (AFFINE) v[r] = v[r] * sc + sh;
+        v[r] = epi.relu_out ? fmaxf(v[r], 0.f) : v[r];
+        if (RESID) v[r] = epi.residual_is_mask ? (res[r] > 0.f ? v[r] : 0.f) : v[r] + res[r];
+      }
+      // A per-element guard makes hipcc branch around every store and put an s_waitcnt vmcnt(0) in front of it:
+      // 16 serialised store round trips per 32x32 tile, more than the MFMA time of a short-K workgroup.  Full
+      // tiles (all but the last row / column tile) take the unguarded path: 16 stores issued back to back.
+      if (full_tile) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ent.out[grow[r] * ldo + col] = v[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (lr < ti.count && col_ok) ent.out[grow[r] * ldo + col] = v[r];
+        }
       }
     }
   }

@@ -133,10 +133,18 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dy, i
   // C/D: col = lane & 31 (k), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (n)
   float *slab = slabs + (int64_t)blockIdx.z * n_out * (int64_t)k;
   const int kc = k0 + wk * 32 + (lane & 31);
+  if (n0 + kTnTile <= n_out && k0 + kTnTile <= k) {  // full tile: unguarded stores, issued back to back (gemm.hip)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int nr = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (nr < n_out && kc < k) slab[(int64_t)nr * k + kc] = acc[r];
+    for (int r = 0; r < 16; ++r) {
+      const int nr = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      slab[(int64_t)nr * k + kc] = acc[r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int nr = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (nr < n_out && kc < k) slab[(int64_t)nr * k + kc] = acc[r];
+    }
   }
 }
 
@@ -246,11 +254,20 @@ __global__ __launch_bounds__(256) void k_gemm_tn_postfold(TnFoldArgs a, float *_
   // C/D: col = lane & 31 (k), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (n)
   float *slab = slabs + ((int64_t)blockIdx.z * 2 + tower) * n_out * (int64_t)kfull;
   const int kc = k0 + wk * 32 + (lane & 31);
+  const bool full = n0 + kTnTile <= n_out;  // kfold = 5F is a multiple of the 64-wide k tile
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int nr = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (nr < n_out && kc < kfold) {
-      float *o = slab + (int64_t)nr * kfull;
+    float *o = slab + (int64_t)(full || nr < n_out ? nr : 0) * kfull;
+    if (full) {  // block-uniform: unguarded stores, issued back to back (gemm.hip)
+      if (!agg_part) {
+        o[kc] = acc[r];
+      } else {
+        o[kc] = acc_id[r];
+        o[kc + 4 * f] = acc_amp[r];
+        o[kc + 8 * f] = acc_att[r];
+      }
+    } else if (nr < n_out && kc < kfold) {
       if (!agg_part) {
         o[kc] = acc[r];
       } else {
