@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dy, i
   stash(0);
   __syncthreads();
   for (int64_t s = 0; s < steps; ++s) {
-    const bool more = s + 1 < steps;
-    if (more) fetch(m_beg + (s + 1) * kTnBK);
+    // unconditional: rows past the slab come back as zeros (see gemm.hip on branches in the staging path)
+    fetch(m_beg + (s + 1) * kTnBK);
     const float *ys = lds + (s & 1) * 2 * kTnBK * kTnLd + wn * 32 + (lane & 31);
     const float *as = ys + kTnBK * kTnLd - wn * 32 + wk * 32;
 #pragma unroll
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dy, i
       const int row = 2 * q + (lane >> 5);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ys[row * kTnLd], as[row * kTnLd], acc, 0, 0, 0);
     }
-    if (more) stash((s + 1) & 1);
+    stash((s + 1) & 1);
     __syncthreads();
   }
   // C/D: col = lane & 31 (k), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (n)
@@ -226,8 +226,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_postfold(TnFoldArgs a, float *_
     stash(0);
     __syncthreads();
     for (int s = 0; s < steps; ++s) {
-      const bool more = s + 1 < steps;
-      if (more) fetch((s + 1) * kTnBK);
+      fetch((s + 1) * kTnBK);  // unconditional: rows past the tile come back as zeros
       const float *ys = lds + (s & 1) * 2 * kTnBK * kTnLd + wn * 32 + (lane & 31);
       const float *as = ys + kTnBK * kTnLd - wn * 32 + wk * 32;
 #pragma unroll
@@ -235,7 +234,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_postfold(TnFoldArgs a, float *_
         const int row = 2 * q + (lane >> 5);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ys[row * kTnLd], as[row * kTnLd], acc, 0, 0, 0);
       }
-      if (more) stash((s + 1) & 1);
+      stash((s + 1) & 1);
       __syncthreads();
     }
     if (agg_part) {  // fold this degree's partial product
