@@ -275,6 +275,14 @@ def main() -> None:
         if os.path.exists(tpath):  # PMC-measured HBM bytes per K4 launch (rocprofv3 --pmc passes, profiles/)
             with open(tpath) as fh:
                 traffic = json.load(fh).get("hbm_bytes_per_launch")
+        rocprof_k4_ms = None
+        spath = os.path.join(ROOT, "profiles", f"r01_{cfg['name'].lower()}_kernel_stats_final.csv")
+        if os.path.exists(spath):  # rocprofv3 --kernel-trace --stats of this command, committed under profiles/
+            import csv
+            with open(spath) as fh:
+                for row in csv.DictReader(fh):
+                    if "k_pna_aggregate<2>" in row["Name"]:
+                        rocprof_k4_ms = float(row["AverageNs"]) * 1e-6
         out = {
             "metric": "molecular graphs/sec (forward+loss)",
             "value": total_graphs / elapsed,
@@ -303,6 +311,7 @@ def main() -> None:
                 "bound": "hbm", "achieved": k4_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": k4_gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": k4_bytes, "avg_launch_ms": k4_ms, "launches_timed": k4_n,
+                "rocprofv3_avg_launch_ms": rocprof_k4_ms,   # from profiles/ (kernel time without the event overhead)
                 "how": "HIP events on the launch stream around every K4 launch of an instrumented repeat of the "
                        "timed steps",
             },
