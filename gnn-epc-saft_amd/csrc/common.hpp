@@ -233,8 +233,18 @@ int launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_
                      int32_t *src, int32_t *dst, int32_t *combo, float *log_amp, float *log_att, int32_t *err_flag,
                      void *workspace, size_t workspace_bytes, const int64_t *batch, int64_t num_graphs,
                      int32_t *graph_ptr, int32_t *degree_block_hist, bool counts_zeroed, hipStream_t st);
+// optional rider of launch_degree_tiles: fold the update weights of all layers in the launch that fills the
+// permutation (both need only the degree plan)
+struct DegreeFoldRequest {
+  int num_layers;
+  const float *const *w_post0, *const *w_post1, *const *avg;
+  const float *g_all;   // destination-term products (k_dst_fold) or null
+  float *w_eff;
+  int64_t layer_stride;
+};
 int launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm, int32_t *tiles,
-                        int32_t *num_tiles, int32_t *scratch, int32_t *err_flag, bool have_block_hist, hipStream_t st);
+                        int32_t *num_tiles, int32_t *scratch, int32_t *err_flag, bool have_block_hist, hipStream_t st,
+                        const DegreeFoldRequest *fold = nullptr);
 int launch_fold_post_weights(int32_t num_layers, const float *const *w_post0_host, const float *const *w_post1_host,
                              const float *const *avg_deg_log_host, const float *const *w_pre0_host,
                              const float *const *w_pre1_host, float *g_scratch, const int32_t *hist, int32_t hidden,

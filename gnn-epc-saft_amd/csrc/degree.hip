@@ -95,10 +95,9 @@ __global__ __launch_bounds__(256) void k_degree_plan(int32_t *__restrict__ block
 }
 
 // pass 3: perm[start[d] + (nodes of degree d in earlier blocks / waves / lanes)] = node
-__global__ __launch_bounds__(kDegBlock) void k_degree_fill(const int32_t *__restrict__ rowptr, int64_t n,
-                                                           const int32_t *__restrict__ block_base,
-                                                           const int32_t *__restrict__ start,
-                                                           int32_t *__restrict__ perm) {
+__device__ __forceinline__ void degree_fill_body(const int32_t *__restrict__ rowptr, int64_t n,
+                                                 const int32_t *__restrict__ block_base,
+                                                 const int32_t *__restrict__ start, int32_t *__restrict__ perm) {
   __shared__ int32_t wcount[kDegBlock / 64][kDegreeBuckets];
   for (int t = threadIdx.x; t < (kDegBlock / 64) * kDegreeBuckets; t += kDegBlock) (&wcount[0][0])[t] = 0;
   __syncthreads();
@@ -115,21 +114,27 @@ __global__ __launch_bounds__(kDegBlock) void k_degree_fill(const int32_t *__rest
   perm[start[d] + block_base[(int64_t)blockIdx.x * kDegreeBuckets + d] + before + rank] = (int32_t)i;
 }
 
+__global__ __launch_bounds__(kDegBlock) void k_degree_fill(const int32_t *__restrict__ rowptr, int64_t n,
+                                                           const int32_t *__restrict__ block_base,
+                                                           const int32_t *__restrict__ start,
+                                                           int32_t *__restrict__ perm) {
+  degree_fill_body(rowptr, n, block_base, start, perm);
+}
+
 __global__ __launch_bounds__(256) void k_dst_fold(FoldLayers fl, int f, float *__restrict__ g_all) {
   dst_fold_body(fl, f, g_all, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-__global__ __launch_bounds__(256) void k_fold_post_weights(FoldLayers fl, const int32_t *__restrict__ hist, int f,
-                                                           float *__restrict__ w_eff_all, int64_t layer_stride,
-                                                           const float *__restrict__ g_all) {
-  const int d = blockIdx.z % kDegreeBuckets;
-  const int layer = blockIdx.z / kDegreeBuckets;
+// slot: float4 index inside one [F/2, 5F] block; t: tower; dz: degree + kDegreeBuckets * layer
+__device__ __forceinline__ void fold_post_weights_body(const FoldLayers &fl, const int32_t *__restrict__ hist, int f,
+                                                       float *__restrict__ w_eff_all, int64_t layer_stride,
+                                                       const float *__restrict__ g_all, int64_t slot, int t, int dz) {
+  const int d = dz % kDegreeBuckets;
+  const int layer = dz / kDegreeBuckets;
   if (hist[d] == 0) return;  // degree absent from this batch
   const float *w0 = fl.w0[layer], *w1 = fl.w1[layer], *avg = fl.avg[layer];
   float *w_eff = w_eff_all + layer * layer_stride;
-  const int t = blockIdx.y;
   const int per_row4 = 5 * f / 4;
-  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t o = slot / per_row4;
   if (o >= f / 2) return;
   const int c = (int)(slot - o * per_row4) * 4;
@@ -151,6 +156,41 @@ __global__ __launch_bounds__(256) void k_fold_post_weights(FoldLayers fl, const 
   gs_st4(w_eff + (((int64_t)d * 2 + t) * (f / 2) + o) * (int64_t)(5 * f) + c, v);
 }
 
+__global__ __launch_bounds__(256) void k_fold_post_weights(FoldLayers fl, const int32_t *__restrict__ hist, int f,
+                                                           float *__restrict__ w_eff_all, int64_t layer_stride,
+                                                           const float *__restrict__ g_all) {
+  fold_post_weights_body(fl, hist, f, w_eff_all, layer_stride, g_all, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
+                         blockIdx.y, blockIdx.z);
+}
+
+// pass 3 of the degree bucketing and the weight fold both need only the plan (bucket starts / histogram): one
+// launch, workgroups [0, fill_blocks) fill the permutation, the rest fold the weights.
+struct FoldJob {
+  FoldLayers fl;
+  const int32_t *hist;
+  int f;
+  float *w_eff_all;
+  int64_t layer_stride;
+  const float *g_all;
+  int x_blocks;      // kDegBlock-thread workgroups per [F/2, 5F] block
+  int num_layers;
+};
+
+__global__ __launch_bounds__(kDegBlock) void k_degree_fill_and_fold(const int32_t *__restrict__ rowptr, int64_t n,
+                                                                    const int32_t *__restrict__ block_base,
+                                                                    const int32_t *__restrict__ start,
+                                                                    int32_t *__restrict__ perm, unsigned fill_blocks,
+                                                                    FoldJob job) {
+  if (blockIdx.x < fill_blocks) {  // block-uniform
+    degree_fill_body(rowptr, n, block_base, start, perm);
+    return;
+  }
+  const unsigned b = blockIdx.x - fill_blocks;
+  const int xb = b % job.x_blocks, rest = b / job.x_blocks;
+  fold_post_weights_body(job.fl, job.hist, job.f, job.w_eff_all, job.layer_stride, job.g_all,
+                         (int64_t)xb * kDegBlock + threadIdx.x, rest & 1, rest >> 1);
+}
+
 }  // namespace gs
 
 extern "C" int64_t gnnsaft_degree_tiles_capacity(int64_t num_nodes, int32_t hidden) {
@@ -167,7 +207,7 @@ extern "C" size_t gnnsaft_degree_scratch_ints(int64_t num_nodes) {
 
 int gs::launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm, int32_t *tiles,
                             int32_t *num_tiles, int32_t *scratch, int32_t *err_flag, bool have_block_hist,
-                            hipStream_t st) {
+                            hipStream_t st, const DegreeFoldRequest *fold) {
   GS_REQUIRE(rowptr && perm && tiles && num_tiles && scratch, GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_nodes >= 1 && hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
   int32_t *hist = scratch, *start = scratch + gs::kDegreeBuckets, *block_hist = scratch + 2 * gs::kDegreeBuckets;
@@ -177,8 +217,35 @@ int gs::launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hi
                        block_hist, err_flag);
   hipLaunchKernelGGL(gs::k_degree_plan, dim3(1), dim3(256), 0, st, block_hist, nb, gs::pna_fold_tile_rows(hidden),
                      hist, start, tiles, num_tiles);
-  hipLaunchKernelGGL(gs::k_degree_fill, dim3((unsigned)nb), dim3(gs::kDegBlock), 0, st, rowptr, num_nodes,
-                     block_hist, start, perm);
+  if (fold == nullptr) {
+    hipLaunchKernelGGL(gs::k_degree_fill, dim3((unsigned)nb), dim3(gs::kDegBlock), 0, st, rowptr, num_nodes,
+                       block_hist, start, perm);
+  } else {  // the degree-folded update weights of all layers ride along (they need only `hist`)
+    GS_REQUIRE(fold->num_layers >= 1 && fold->num_layers <= GNNSAFT_MAX_FOLD_LAYERS && fold->w_eff != nullptr,
+               GNNSAFT_ERR_SHAPE);
+    gs::FoldJob job;
+    const bool fold_dst = fold->g_all != nullptr;
+    for (int i = 0; i < GNNSAFT_MAX_FOLD_LAYERS; ++i) {
+      const int j = i < fold->num_layers ? i : 0;
+      job.fl.w0[i] = fold->w_post0[j];
+      job.fl.w1[i] = fold->w_post1[j];
+      job.fl.avg[i] = fold->avg[j];
+      job.fl.pre0[i] = nullptr;
+      job.fl.pre1[i] = nullptr;
+      GS_REQUIRE(job.fl.w0[i] && job.fl.w1[i] && job.fl.avg[i], GNNSAFT_ERR_NULL);
+    }
+    job.hist = hist;
+    job.f = hidden;
+    job.w_eff_all = fold->w_eff;
+    job.layer_stride = fold->layer_stride;
+    job.g_all = fold_dst ? fold->g_all : nullptr;
+    const int64_t threads = (int64_t)(hidden / 2) * (5 * hidden / 4);
+    job.x_blocks = (int)gs_ceil_div(threads, (int64_t)gs::kDegBlock);
+    job.num_layers = fold->num_layers;
+    const int64_t fold_blocks = (int64_t)job.x_blocks * 2 * gs::kDegreeBuckets * fold->num_layers;
+    hipLaunchKernelGGL(gs::k_degree_fill_and_fold, dim3((unsigned)(nb + fold_blocks)), dim3(gs::kDegBlock), 0, st, rowptr,
+                       num_nodes, block_hist, start, perm, (unsigned)nb, job);
+  }
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }
@@ -187,7 +254,7 @@ extern "C" int gnnsaft_degree_tiles(const int32_t *rowptr, int64_t num_nodes, in
                                     int32_t *tiles, int32_t *num_tiles, int32_t *scratch, int32_t *err_flag,
                                     gnnsaft_stream_t stream) {
   return gs::launch_degree_tiles(rowptr, num_nodes, hidden, perm, tiles, num_tiles, scratch, err_flag, false,
-                                 static_cast<hipStream_t>(stream));
+                                 static_cast<hipStream_t>(stream), nullptr);
 }
 
 extern "C" int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const float *const *w_post0_host,

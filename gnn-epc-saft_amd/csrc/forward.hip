@@ -423,10 +423,23 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
                           I(p.rowptr), I(p.src), I(p.dst), I(p.combo), F(p.log_amp), F(p.log_att), err_flag,
                           ws + p.csr_ws, gnnsaft_csr_workspace_bytes(n, num_edges), batch, g, I(p.graph_ptr),
                           d->fold_degree_scalers ? I(p.hist3) + 2 * kDegreeBuckets : nullptr, true, sa));
-  if (d->fold_degree_scalers)
-    GS_TRY(launch_degree_tiles(I(p.rowptr), n, h, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3), err_flag, true,
-                               sa));
-  if (d->fold_degree_scalers) GS_TRY(fold_weights(2));
+  if (d->fold_degree_scalers) {
+    if (d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS) {  // weight fold rides along with the permutation fill
+      const float *w0[GNNSAFT_MAX_FOLD_LAYERS], *w1[GNNSAFT_MAX_FOLD_LAYERS], *av[GNNSAFT_MAX_FOLD_LAYERS];
+      for (int i = 0; i < d->num_layers; ++i) {
+        w0[i] = lw[i].wpost[0][0];
+        w1[i] = lw[i].wpost[1][0];
+        av[i] = lw[i].avg;
+      }
+      const DegreeFoldRequest req{d->num_layers, w0, w1, av, fold_dst ? F(p.gfold) : nullptr, F(p.weff), wstride};
+      GS_TRY(launch_degree_tiles(I(p.rowptr), n, h, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3), err_flag,
+                                 true, sa, &req));
+    } else {
+      GS_TRY(launch_degree_tiles(I(p.rowptr), n, h, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3), err_flag,
+                                 true, sa));
+      GS_TRY(fold_weights(2));
+    }
+  }
   // ---- the edge-class tables of all layers, on the caller's stream
 
   for (int l0 = 0; l0 < d->num_layers; l0 += kMaxGemmBatch) {
