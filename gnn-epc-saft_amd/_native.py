@@ -19,7 +19,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_voi
 import torch  # noqa: F401  (import order matters, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgnnsaft.so")
+LIB_PATH = os.environ.get("GNNSAFT_LIB") or os.path.join(_HERE, "lib", "libgnnsaft.so")  # override: A/B runs of two builds
 
 MAX_TABLES = 16
 
