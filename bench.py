@@ -330,7 +330,7 @@ def main() -> None:
             "final_loss": float(final_loss),
             "train_step": train,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(cfg, data, deg, args.cpu_budget)
         print(json.dumps(out))
     if world > 1:
