@@ -479,7 +479,8 @@ static int pick_cfg(int64_t m, int n_out, int k, bool stats) {
   if (n_out <= 32) return stats ? kCfg256x32 : kCfg128x32;
   // stats tiles have 64-row waves; up to ~40k rows the 64-row workgroups of 64x128 spread over more CUs than 128x128
   if (stats) return n_out <= 64 ? kCfg128x64 : (m < 40000 ? kCfg64x128 : kCfg128x128);
-  if (n_out >= 128 && k >= 1024) return kCfg128x128;  // long-K update at H = 256
+  // long-K update at H = 256, or enough rows that the big tile's lower launch count wins (C3: 164 k rows)
+  if (n_out >= 128 && (k >= 1024 || m >= 65536)) return kCfg128x128;
   return kCfg64x64;
 }
 
