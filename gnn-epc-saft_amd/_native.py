@@ -88,7 +88,10 @@ SIGNATURES = {
     "gnnsaft_forward_workspace_bytes": (c_size_t, [POINTER(ModelDesc), c_int64, c_int64, c_int64]),
     "gnnsaft_forward_workspace_map": (c_int32, [POINTER(ModelDesc), c_int64, c_int64, c_int64, POINTER(WorkspaceMap)]),
     "gnnsaft_forward": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), c_int32, P, P, P, P, c_int64, c_int64,
-                                  c_int64, P, P, P, P, P, c_size_t, P, P, P]),
+                                  c_int64, P, P, P, P, P, c_size_t, P, P, P, P]),
+    "gnnsaft_structure_bytes": (c_size_t, [POINTER(ModelDesc), c_int64, c_int64, c_int64]),
+    "gnnsaft_structure_build": (c_int32, [POINTER(ModelDesc), P, P, P, c_int64, c_int64, c_int64, P, P, P, c_size_t,
+                                          P]),
     "gnnsaft_adamw_step": (c_int32, [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
                                      c_float, P]),
     "gnnsaft_sgd_step": (c_int32, [P, P, P, c_int64, c_float, c_float, c_float, c_int32, c_float, P]),

@@ -308,13 +308,71 @@ extern "C" int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int
   return GNNSAFT_OK;
 }
 
+static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weights_host, int32_t num_weights,
+                           const int64_t *x_idx, const int64_t *edge_index, const int64_t *edge_attr,
+                           const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
+                           const float *target, float *out, float *loss3, int32_t *err_flag, void *workspace,
+                           size_t workspace_bytes, const void *structure_in, void *structure_out,
+                           gnnsaft_profile *prof, gnnsaft_aux *aux, gnnsaft_stream_t stream);
+
 extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *weights_host, int32_t num_weights,
                                const int64_t *x_idx, const int64_t *edge_index, const int64_t *edge_attr,
                                const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
                                const float *target, float *out, float *loss3, int32_t *err_flag, void *workspace,
-                               size_t workspace_bytes, gnnsaft_profile *prof, gnnsaft_aux *aux,
-                               gnnsaft_stream_t stream) {
-  GS_REQUIRE(d && weights_host && out && workspace, GNNSAFT_ERR_NULL);
+                               size_t workspace_bytes, const void *structure, gnnsaft_profile *prof,
+                               gnnsaft_aux *aux, gnnsaft_stream_t stream) {
+  return gs_forward_impl(d, weights_host, num_weights, x_idx, edge_index, edge_attr, batch, num_nodes, num_edges,
+                         num_graphs, target, out, loss3, err_flag, workspace, workspace_bytes, structure, nullptr, prof,
+                         aux, stream);
+}
+
+extern "C" size_t gnnsaft_structure_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes, int64_t num_edges,
+                                          int64_t num_graphs) {
+  Plan p;
+  if (make_plan(desc, num_nodes, num_edges, num_graphs, p) != GNNSAFT_OK) return 0;
+  return p.struct_bytes;
+}
+
+extern "C" int gnnsaft_structure_build(const gnnsaft_model_desc *d, const int64_t *edge_index, const int64_t *edge_attr,
+                                       const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
+                                       void *structure_out, int32_t *err_flag, void *workspace, size_t workspace_bytes,
+                                       gnnsaft_stream_t stream) {
+  GS_REQUIRE(d && structure_out && workspace, GNNSAFT_ERR_NULL);
+  return gs_forward_impl(d, nullptr, 0, nullptr, edge_index, edge_attr, batch, num_nodes, num_edges, num_graphs,
+                         nullptr, nullptr, nullptr, err_flag, workspace, workspace_bytes, nullptr, structure_out,
+                         nullptr, nullptr, stream);
+}
+
+// structure_in: skip the K0 chain, copy the cached segment into the workspace instead.
+// structure_out (gnnsaft_structure_build): run ONLY the K0 chain and copy the segment out.
+static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weights_host, int32_t num_weights,
+                           const int64_t *x_idx, const int64_t *edge_index, const int64_t *edge_attr,
+                           const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
+                           const float *target, float *out, float *loss3, int32_t *err_flag, void *workspace,
+                           size_t workspace_bytes, const void *structure_in, void *structure_out,
+                           gnnsaft_profile *prof, gnnsaft_aux *aux, gnnsaft_stream_t stream) {
+  const bool structure_only = structure_out != nullptr;
+  GS_REQUIRE(d && workspace && (structure_only || (weights_host && out)), GNNSAFT_ERR_NULL);
+  if (structure_only) {
+    GS_REQUIRE(num_nodes >= 1 && num_graphs >= 1, GNNSAFT_ERR_SHAPE);
+    GS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, GNNSAFT_ERR_WORKSPACE);
+    Plan p;
+    GS_TRY(make_plan(d, num_nodes, num_edges, num_graphs, p));
+    GS_REQUIRE(workspace_bytes >= p.total, GNNSAFT_ERR_WORKSPACE);
+    GS_REQUIRE(batch != nullptr || num_graphs == 1, GNNSAFT_ERR_SHAPE);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    auto I = [&](size_t off) { return reinterpret_cast<int32_t *>(ws + off); };
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+    GS_TRY(launch_csr_build(edge_index, edge_attr, num_nodes, num_edges, d->num_bond_cols, d->bond_dims, d->self_loops,
+                            I(p.rowptr), I(p.src), I(p.dst), I(p.combo), F(p.log_amp), F(p.log_att), err_flag,
+                            ws + p.csr_ws, gnnsaft_csr_workspace_bytes(num_nodes, num_edges), batch, num_graphs,
+                            I(p.graph_ptr), I(p.hist3) + 2 * kDegreeBuckets, false, st));
+    GS_TRY(launch_degree_tiles(I(p.rowptr), num_nodes, d->hidden, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3),
+                               err_flag, true, st));
+    GS_HIP(hipMemcpyAsync(structure_out, ws + p.struct_begin, p.struct_bytes, hipMemcpyDeviceToDevice, st));
+    return GNNSAFT_OK;
+  }
   GS_REQUIRE(num_weights == gnnsaft_num_weights(d), GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(num_nodes >= 1 && num_graphs >= 1 && x_idx != nullptr, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, GNNSAFT_ERR_WORKSPACE);
@@ -386,7 +444,7 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     }
     int32_t *zero_ptr = nullptr;
     int64_t zero_count = 0;
-    csr_zero_region(ws + p.csr_ws, n, &zero_ptr, &zero_count);
+    if (structure_in == nullptr) csr_zero_region(ws + p.csr_ws, n, &zero_ptr, &zero_count);
     GS_TRY(launch_forward_prologue(x_idx, n, d->num_atom_cols, atom_tab, d->atom_dims, d->num_bond_cols, bond_tab,
                                    d->bond_dims, h, F(p.x0), F(p.cemb), zero_ptr, zero_count,
                                    dst_in_prologue ? d->num_layers : 0, w0, w1, p0, p1, F(p.gfold), err_flag, st));
@@ -416,6 +474,12 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
     return GNNSAFT_OK;
   };
   if (d->fold_degree_scalers && fold_dst && !dst_in_prologue) GS_TRY(fold_weights(1));
+  if (structure_in != nullptr) {
+    // cached batch structure (gnnsaft_structure_build): one device copy instead of the K0 chain; the update-weight
+    // fold (needs the cached degree histogram and the CURRENT weights) runs on its own
+    GS_HIP(hipMemcpyAsync(ws + p.struct_begin, structure_in, p.struct_bytes, hipMemcpyDeviceToDevice, sa));
+    if (d->fold_degree_scalers) GS_TRY(fold_weights(2));
+  } else {
   // CSR + graph offsets (batch == NULL: un-batched Data, models.py:116, one graph spanning all nodes) + the first
   // pass of the degree bucketing, in 5 launches (the histogram was zeroed by the prologue)
   GS_REQUIRE(batch != nullptr || g == 1, GNNSAFT_ERR_SHAPE);
@@ -440,6 +504,7 @@ extern "C" int gnnsaft_forward(const gnnsaft_model_desc *d, const void *const *w
       GS_TRY(fold_weights(2));
     }
   }
+  }  // structure built in place
   // ---- the edge-class tables of all layers, on the caller's stream
 
   for (int l0 = 0; l0 < d->num_layers; l0 += kMaxGemmBatch) {

@@ -14,6 +14,7 @@ struct Plan {
   size_t csr_ws, rowptr, src, dst, combo, log_amp, log_att, graph_ptr;
   size_t x0, x1, pq, agg, u0, u1, y, msg0, msg1, cemb, cenc, rtab, stats, bnseg, bnseg_bytes, scale, shift, pooled, m0, m1, m2;
   size_t perm, tiles, num_tiles, hist3, weff, gfold;
+  size_t struct_begin, struct_bytes;  // [rowptr .. hist3]: everything that depends on edge_index / batch only
   int64_t tile_cap;
   // per-layer strides in floats (0 unless desc->save_tape: then every layer keeps its own tensors for backward)
   int64_t sx, spq, sagg, su, sy, smsg;
@@ -61,6 +62,15 @@ static inline int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, i
   p.log_amp = take(nn * 4);
   p.log_att = take(nn * 4);
   p.graph_ptr = take((gg + 1) * 4);
+  // degree tiles directly behind the CSR: together they are the batch STRUCTURE, one contiguous segment that can be
+  // cached per batch (gnnsaft_structure_build) and handed back to gnnsaft_forward
+  p.tile_cap = gnnsaft_degree_tiles_capacity(n, d->hidden);
+  p.perm = take(nn * 4);
+  p.tiles = take((size_t)p.tile_cap * 16);
+  p.num_tiles = take(4);
+  p.hist3 = take(gnnsaft_degree_scratch_ints(n) * 4);
+  p.struct_begin = p.rowptr;
+  p.struct_bytes = off - p.rowptr;
   const size_t nlay = (size_t)(d->num_layers > 0 ? d->num_layers : 1);
   const bool tape = d->save_tape != 0;
   const size_t rep = tape ? nlay : 1;
@@ -101,11 +111,6 @@ static inline int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, i
   p.m0 = take(gg * h * 4);
   p.m1 = take(gg * h * 4);
   p.m2 = take(gg * h * 4);
-  p.tile_cap = gnnsaft_degree_tiles_capacity(n, d->hidden);
-  p.perm = take(nn * 4);
-  p.tiles = take((size_t)p.tile_cap * 16);
-  p.num_tiles = take(4);
-  p.hist3 = take(gnnsaft_degree_scratch_ints(n) * 4);
   p.weff = d->fold_degree_scalers ? take(nl * (size_t)kDegreeBuckets * 5 * h * h * 4) : 0;
   p.gfold = d->fold_degree_scalers ? take(nl * 2 * 3 * (h / 2) * h * 4) : 0;
   p.total = off;

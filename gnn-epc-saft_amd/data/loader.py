@@ -66,7 +66,8 @@ class GraphLoader:
     reshuffles with ``seed + epoch`` (``shuffle=True``) like PyG's loader does through its sampler."""
 
     def __init__(self, graphs, batch_size: int, shuffle: bool = False, drop_last: bool = False,
-                 device: Optional[torch.device] = None, seed: int = 0, rank: int = 0, world_size: int = 1):
+                 device: Optional[torch.device] = None, seed: int = 0, rank: int = 0, world_size: int = 1,
+                 cache_on_device: bool = False, structure_for=None):
         self.packed = graphs if isinstance(graphs, PackedGraphs) else PackedGraphs(graphs)
         if batch_size < 1:
             raise ValueError("batch_size must be positive")
@@ -75,6 +76,13 @@ class GraphLoader:
         self.seed, self.epoch = int(seed), 0
         self.rank, self.world_size = int(rank), int(world_size)     # DistributedSampler semantics: strided shards
         self._copy_stream = None
+        # cache_on_device (only without shuffling: the batch list is then the same every epoch): keep the collated
+        # batches resident in HBM; with structure_for=<PNAPCSAFT> also their CSR / degree tiles
+        # (model.build_structure), so that from the second epoch on a step starts at the embeddings.
+        if cache_on_device and shuffle:
+            raise ValueError("cache_on_device needs a fixed batch list (shuffle=False)")
+        self.cache_on_device, self.structure_for = bool(cache_on_device), structure_for
+        self._cache: Optional[List[GraphData]] = None
 
     def __len__(self) -> int:
         per_rank = (self.packed.num_graphs + self.world_size - 1) // self.world_size
@@ -115,6 +123,23 @@ class GraphLoader:
         return out, ready, pinned       # `pinned` is kept alive until the copy has been waited for
 
     def __iter__(self) -> Iterator[GraphData]:
+        if self._cache is not None:
+            self.epoch += 1
+            yield from self._cache
+            return
+        if self.cache_on_device:
+            if self.device is None or self.device.type != "cuda":
+                raise ValueError("cache_on_device needs a HIP device")
+            built = []
+            for ids in self._batches():
+                b = self.packed.collate(ids).to(self.device)
+                if self.structure_for is not None:
+                    b.gnnsaft_structure = self.structure_for.build_structure(b)
+                built.append(b)
+            self._cache = built
+            self.epoch += 1
+            yield from built
+            return
         chunks = self._batches()
         self.epoch += 1
         if self.device is None or self.device.type != "cuda":

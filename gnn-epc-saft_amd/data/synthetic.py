@@ -34,6 +34,7 @@ class GraphData:
         if num_graphs is None:
             num_graphs = 1 if batch is None else (int(ptr.numel()) - 1 if ptr is not None else int(batch.max()) + 1)
         self.num_graphs = num_graphs
+        self.gnnsaft_structure = None   # optional cached CSR / degree tiles (PNAPCSAFT.build_structure)
 
     @property
     def num_nodes(self) -> int:
@@ -41,8 +42,10 @@ class GraphData:
 
     def to(self, device, non_blocking: bool = False) -> "GraphData":
         mv = lambda t: None if t is None else t.to(device, non_blocking=non_blocking)
-        return GraphData(mv(self.x), mv(self.edge_index), mv(self.edge_attr), mv(self.batch), mv(self.ptr),
-                         mv(self.para), self.num_graphs)
+        out = GraphData(mv(self.x), mv(self.edge_index), mv(self.edge_attr), mv(self.batch), mv(self.ptr),
+                        mv(self.para), self.num_graphs)
+        out.gnnsaft_structure = mv(self.gnnsaft_structure)
+        return out
 
 
 def collate(graphs: Sequence[GraphData]) -> GraphData:

@@ -296,13 +296,21 @@ class PNAPCSAFT(nn.Module):
         stream = torch.cuda.current_stream(dev).cuda_stream
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
         ws_bytes = ws.numel() - (ws_ptr - ws.data_ptr())
+        structure = getattr(data, "gnnsaft_structure", None)      # cached by build_structure() / GraphLoader
+        struct_ptr = None
+        if structure is not None:
+            if structure.device != dev or structure.dtype != torch.uint8 or not structure.is_contiguous() or \
+                    structure.numel() != lib.gnnsaft_structure_bytes(ctypes.byref(desc), n, e, g):
+                raise ValueError("data.gnnsaft_structure does not belong to this batch / model configuration")
+            struct_ptr = structure.data_ptr()
         with torch.cuda.device(dev):
             aux = aux_for(dev.index if dev.index is not None else torch.cuda.current_device()) \
                 if self.use_side_stream else None
             rc = lib.gnnsaft_forward(ctypes.byref(desc), wtab, nw, x.data_ptr(), edge_index.data_ptr() if e else None,
                                      edge_attr.data_ptr() if e else None,
                                      None if batch is None else batch.data_ptr(), n, e, g, tgt_ptr, out.data_ptr(),
-                                     loss_ptr, self._err_flag.data_ptr(), ws_ptr, ws_bytes, self._profile, aux, stream)
+                                     loss_ptr, self._err_flag.data_ptr(), ws_ptr, ws_bytes, struct_ptr, self._profile,
+                                     aux, stream)
         check(rc, "gnnsaft_forward")
         ctx = None
         if tape:
@@ -349,6 +357,39 @@ class PNAPCSAFT(nn.Module):
                                       scratch.numel() - (sp - scratch.data_ptr()), stream)
         check(rc, "gnnsaft_backward")
         return grads
+
+    @torch.no_grad()
+    def build_structure(self, data) -> torch.Tensor:
+        """The batch STRUCTURE of ``data`` (CSR by destination, graph offsets, degree tiles: what depends on
+        ``edge_index`` / ``edge_attr`` / ``batch`` only) as an opaque device tensor.  Attach it to a batch that will
+        be seen again (``data.gnnsaft_structure = model.build_structure(data)``; ``GraphLoader(cache_structure=
+        True)`` does so): every later forward / training step over that batch skips the CSR build.  Valid for this
+        model's ``hidden_dim`` / ``self_loops`` and this batch only."""
+        x, edge_index, edge_attr = data.x, data.edge_index.contiguous(), data.edge_attr.contiguous()
+        batch = getattr(data, "batch", None)
+        self._check_mode(x)
+        dev = x.device
+        n, e = int(x.shape[0]), int(edge_index.shape[1])
+        g = 1 if batch is None else int(getattr(data, "num_graphs", None) or int(batch[-1]) + 1)
+        desc = self._model_desc()
+        need = lib.gnnsaft_forward_workspace_bytes(ctypes.byref(desc), n, e, g)
+        nbytes = lib.gnnsaft_structure_bytes(ctypes.byref(desc), n, e, g)
+        if need == 0 or nbytes == 0:
+            raise _native.GnnsaftError("configuration outside the supported shape envelope")
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if self._err_flag is None or self._err_flag.device != dev:
+            self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            check(lib.gnnsaft_structure_build(ctypes.byref(desc), edge_index.data_ptr() if e else None,
+                                              edge_attr.data_ptr() if e else None,
+                                              None if batch is None else batch.contiguous().data_ptr(), n, e, g,
+                                              blob.data_ptr(), self._err_flag.data_ptr(), ws_ptr,
+                                              ws.numel() - (ws_ptr - ws.data_ptr()), stream),
+                  "gnnsaft_structure_build")
+        return blob
 
     def run(self, data, target: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """Forward (+ MAPE loss when ``target`` [G,P] is given) WITHOUT autograd.  Returns

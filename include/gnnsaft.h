@@ -340,8 +340,24 @@ int gnnsaft_forward(const gnnsaft_model_desc *desc,
                     const float *target /* [G,P] or NULL */,
                     float *out /* [G,P] */, float *loss3 /* [3] or NULL */,
                     int32_t *err_flag /* device int32, zeroed by the caller, or NULL */,
-                    void *workspace, size_t workspace_bytes, gnnsaft_profile *profile /* or NULL */,
+                    void *workspace, size_t workspace_bytes,
+                    const void *structure /* from gnnsaft_structure_build, or NULL: build it here */,
+                    gnnsaft_profile *profile /* or NULL */,
                     gnnsaft_aux *aux /* or NULL: single stream */, gnnsaft_stream_t stream);
+
+/* The batch STRUCTURE (CSR by destination, graph offsets, degree tiles: everything that depends   */
+/* on edge_index / edge_attr / batch only) as one opaque device blob, for batches that are seen     */
+/* again (epochs over a fixed batch list, repeated inference): build once, pass to every            */
+/* gnnsaft_forward over the same (desc sizes, n, e, g) -- it replaces the K0 chain by one device    */
+/* copy.  `workspace` as for gnnsaft_forward.  The blob must come from the same desc->hidden /      */
+/* self_loops / bond_dims and the same (num_nodes, num_edges, num_graphs).                          */
+size_t gnnsaft_structure_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes, int64_t num_edges,
+                               int64_t num_graphs);
+int gnnsaft_structure_build(const gnnsaft_model_desc *desc, const int64_t *edge_index,
+                            const int64_t *edge_attr, const int64_t *batch, int64_t num_nodes,
+                            int64_t num_edges, int64_t num_graphs, void *structure_out,
+                            int32_t *err_flag, void *workspace, size_t workspace_bytes,
+                            gnnsaft_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* Backward of the path (what autograd does when Lightning calls               */

@@ -112,3 +112,33 @@ def test_loader_feeds_the_loop_with_overlapped_copies():
     lit = G.create_model(cfg, degree_histogram(graphs)).to(DEV)
     hist = training_loop(lit, GraphLoader(graphs, 64, shuffle=True, device=DEV, seed=1))      # 4 epochs of 3 batches
     assert [s for s, _ in hist] == [3, 6, 9, 12] and hist[-1][1] < hist[0][1]
+
+
+def test_loader_with_cached_batches_and_structure():
+    """shuffle=False + cache_on_device: batches (and their CSR / degree tiles) are built once, later epochs reuse
+    them; the training trajectory equals the uncached one bit for bit."""
+    import gnn_epc_saft_amd as G
+    from gnn_epc_saft_amd.data.loader import GraphLoader
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram
+    from gnn_epc_saft_amd.train.loop import training_loop
+    from test_host_cpu import _graph_list
+    graphs = _graph_list(150, 9)
+    cfg = dict(propagation_depth=2, hidden_dim=64, pre_layers=1, post_layers=1, num_mlp_layers=1, num_para=3,
+               skip_connections=True, add_self_loops=True, dropout_rate=0.0, model="PNAL", optimizer="adam",
+               learning_rate=2e-3, weight_decay=1e-2, warmup_steps=50, momentum=0.9, num_train_steps=9,
+               log_every_steps=3, checkpoint_every_steps=0)
+    def run(cached):
+        torch.manual_seed(0)
+        lit = G.create_model(cfg, degree_histogram(graphs)).to(DEV)
+        ld = GraphLoader(graphs, 64, device=DEV, cache_on_device=cached, structure_for=lit.model if cached else None)
+        hist = training_loop(lit, ld)
+        if cached:
+            assert ld._cache is not None and all(b.gnnsaft_structure is not None for b in ld._cache)
+        return hist, [p.detach().clone() for p in lit.parameters()]
+    h0, p0 = run(False)
+    h1, p1 = run(True)
+    assert h0 == h1
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        GraphLoader(graphs, 64, shuffle=True, device=DEV, cache_on_device=True)
