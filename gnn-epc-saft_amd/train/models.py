@@ -113,12 +113,6 @@ class _NodeBatchNormWeights(_ParamsOnly):
         self.module = nn.BatchNorm1d(hidden)
 
 
-def _bn_tensors(bn: nn.BatchNorm1d) -> List[torch.Tensor]:
-    if not (bn.affine and bn.track_running_stats):
-        raise NotImplementedError("BatchNorm1d must be affine with running statistics (reference default)")
-    return [bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked]
-
-
 class PNAPCSAFT(nn.Module):
     """Graph neural network predicting ePC-SAFT parameters (models.py:48-135), MI355X kernels."""
 
@@ -170,26 +164,49 @@ class PNAPCSAFT(nn.Module):
 
     # ------------------------------------------------------------------ host glue
     def _weight_tensors(self) -> List[torch.Tensor]:
-        """Canonical weight table order (csrc/forward.hip header)."""
-        out: List[torch.Tensor] = [t.weight for t in self.node_embed.tables()]
-        out += [t.weight for t in self.edge_embed.tables()]
-        for conv, bn in zip(self.convs, self.batch_norms):
-            out.append(conv.aggr_module.avg_deg_log)
-            out += [conv.edge_encoder.weight, conv.edge_encoder.bias]
-            for stack in list(conv.pre_nns) + list(conv.post_nns):
-                for layer in stack:
-                    if isinstance(layer, nn.Linear):
-                        out += [layer.weight, layer.bias]
-            out += [conv.lin.weight, conv.lin.bias]
-            out += _bn_tensors(bn.module)
+        """Canonical weight table order (csrc/forward.hip header).  Walks the module tree through the
+        ``_modules`` / ``_parameters`` / ``_buffers`` dicts: ``nn.Module.__getattr__`` costs ~1 us per dot, which
+        made this walk (89 tensors at L = 3) the largest single item of the per-call Python time.  Nothing is
+        cached, so replaced parameters / submodules are always seen."""
+        out: List[torch.Tensor] = []
+        mods = self._modules
+
+        def lin(m):       # nn.Linear
+            p = m._parameters
+            out.append(p["weight"])
+            out.append(p["bias"])
+
+        def bn(m):        # nn.BatchNorm1d
+            if not (m.affine and m.track_running_stats):
+                raise NotImplementedError("BatchNorm1d must be affine with running statistics (reference default)")
+            p, b = m._parameters, m._buffers
+            out.extend((p["weight"], p["bias"], b["running_mean"], b["running_var"], b["num_batches_tracked"]))
+
+        for enc in (mods["node_embed"], mods["edge_embed"]):
+            for t in enc._modules[enc._list_name]._modules.values():
+                out.append(t._parameters["weight"])
+        for conv, norm in zip(mods["convs"]._modules.values(), mods["batch_norms"]._modules.values()):
+            cm = conv._modules
+            out.append(cm["aggr_module"]._buffers["avg_deg_log"])
+            lin(cm["edge_encoder"])
+            for stacks in (cm["pre_nns"], cm["post_nns"]):
+                for stack in stacks._modules.values():
+                    for layer in stack._modules.values():
+                        if isinstance(layer, nn.Linear):
+                            lin(layer)
+            lin(cm["lin"])
+            bn(norm._modules["module"])
+        seq = list(mods["mlp"]._modules.values())
         m = self.mlp_params.num_mlp_layers
         for i in range(m):
-            out += [self.mlp[4 * i].weight, self.mlp[4 * i].bias]
-            out += _bn_tensors(self.mlp[4 * i + 1])
-        tail = self.mlp[4 * m]
-        out += [tail[0].weight, tail[0].bias] + _bn_tensors(tail[1])
-        out += [tail[4].weight, tail[4].bias] + _bn_tensors(tail[5])
-        out += [tail[8].weight, tail[8].bias]
+            lin(seq[4 * i])
+            bn(seq[4 * i + 1])
+        tail = list(seq[4 * m]._modules.values())
+        lin(tail[0])
+        bn(tail[1])
+        lin(tail[4])
+        bn(tail[5])
+        lin(tail[8])
         return out
 
     def _model_desc(self) -> ModelDesc:
