@@ -142,3 +142,33 @@ def test_loader_with_cached_batches_and_structure():
         assert torch.equal(a, b)
     with pytest.raises(ValueError):
         GraphLoader(graphs, 64, shuffle=True, device=DEV, cache_on_device=True)
+
+
+def test_full_size_training_steps_are_finite_and_learn():
+    """BASELINE.json config 2 (1024 graphs, H=128, L=3): a few full training steps at the benchmark size -- every
+    gradient finite, the loss goes down, running statistics move (the oracle is too slow to check gradients here;
+    tests/test_gpu_backward.py does that on small batches)."""
+    import gnn_epc_saft_amd as G
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    data = make_synthetic_batch(1024, 1236, num_para=3)
+    cfg = dict(hidden_dim=128, num_para=3, optimizer="adam", learning_rate=1e-3, weight_decay=1e-2, warmup_steps=100,
+               momentum=0.9)
+    torch.manual_seed(0)
+    lit = G.PNApcsaftL(G.PnaconvsParams(3, 1, 1, degree_histogram(data), skip_connections=True, self_loops=True),
+                       G.ReadoutMLPParams(1, 3), cfg).to(DEV).train()
+    conf = lit.configure_optimizers()
+    opt, sched = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    dd = data.to(DEV)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        loss = lit.training_step(dd)
+        loss.backward()
+        for name, p in lit.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        opt.step()
+        sched.step()
+        losses.append(float(loss))
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    assert int(lit.model.batch_norms[0].module.num_batches_tracked) == 8
+    assert lit.model.input_error_flags() == 0
