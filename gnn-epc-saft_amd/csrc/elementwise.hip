@@ -97,24 +97,29 @@ struct PrologueArgs {
   float *g_all;
   int dst_gx, dst_gy;
   int h;
-  unsigned end_embed, end_combo, end_zero;  // exclusive workgroup bounds of the first three jobs
+  unsigned dst_blocks;             // workgroups [0, dst_blocks): destination fold
+  unsigned end_embed, end_combo;   // then embedding sum [0, end_embed), class table [.., end_combo), zero fill
 };
 
 template <int MAXT>
 __global__ __launch_bounds__(256) void k_forward_prologue(PrologueArgs a) {
-  const unsigned b = blockIdx.x;
+  // the destination fold goes FIRST in the grid: its workgroups are the long-latency ones (a k-loop with
+  // barriers), so they should be resident from the start while the streaming jobs fill the remaining CUs
+  if (blockIdx.x < a.dst_blocks) {
+    const unsigned d = blockIdx.x;
+    const int per_z = a.dst_gx * a.dst_gy;
+    const int bz = d / per_z, r = d - bz * per_z;
+    dst_fold_body(a.fl, a.h, a.g_all, r % a.dst_gx, r / a.dst_gx, bz);
+    return;
+  }
+  const unsigned b = blockIdx.x - a.dst_blocks;
   if (b < a.end_embed) {
     embed_sum_body<MAXT>((int64_t)b * 256 + threadIdx.x, a.x_idx, a.rows, a.atoms, a.h, a.x_out, a.err, a.rs);
   } else if (b < a.end_combo) {
     combo_embed_body((int64_t)(b - a.end_embed) * 256 + threadIdx.x, a.bonds, a.combos, a.h, a.cemb);
-  } else if (b < a.end_zero) {
+  } else {
     const int64_t i = (int64_t)(b - a.end_combo) * 256 + threadIdx.x;
     if (i < a.zero_count) a.zero_ptr[i] = 0;
-  } else {
-    const unsigned d = b - a.end_zero;
-    const int per_z = a.dst_gx * a.dst_gy;
-    const int bz = d / per_z, r = d - bz * per_z;
-    dst_fold_body(a.fl, a.h, a.g_all, r % a.dst_gx, r / a.dst_gx, bz);
   }
 }
 
@@ -302,9 +307,9 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
   const int64_t be = gs_ceil_div(num_rows * (hidden / 4), 256), bc = gs_ceil_div(a.combos * (hidden / 4), 256);
   const int64_t bz = gs_ceil_div(a.zero_count, 256), bd = (int64_t)a.dst_gx * a.dst_gy * 6 * fold_layers;
   GS_REQUIRE(be + bc + bz + bd < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);
+  a.dst_blocks = (unsigned)bd;
   a.end_embed = (unsigned)be;
   a.end_combo = (unsigned)(be + bc);
-  a.end_zero = (unsigned)(be + bc + bz);
   const dim3 grid((unsigned)(be + bc + bz + bd));
   if (num_atom_cols <= 9)
     hipLaunchKernelGGL(k_forward_prologue<9>, grid, dim3(256), 0, st, a);
