@@ -259,6 +259,25 @@ def main() -> None:
     lin_n, lin_ms = kernel_ms(_native.PROF_LIN)
     _native.lib.gnnsaft_profile_destroy(handle)
 
+    # What a HIP event pair measures around a launch that does (almost) nothing (~6 us: the launch's fixed cost plus
+    # ~2.4 us of dispatch latency / event handling).  Reported beside the K4 time to explain the gap between the
+    # event-timed and the rocprofv3 kernel duration; the roofline `achieved` keeps the raw event time.
+    event_overhead_ms = None
+    if rank == 0:
+        from gnn_epc_saft_amd import kernels as _k
+        tiny_p, tiny_t = torch.ones(1, 3, device=dev), torch.ones(1, 3, device=dev)
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+        with torch.cuda.stream(stream):
+            for _ in range(8):
+                _k.mape(tiny_p, tiny_t)
+            for a, b in pairs:
+                a.record(stream)
+                _k.mape(tiny_p, tiny_t)
+                b.record(stream)
+        torch.cuda.synchronize(dev)
+        gaps = sorted(a.elapsed_time(b) for a, b in pairs)
+        event_overhead_ms = gaps[len(gaps) // 2]
+
     t = torch.tensor([elapsed, elapsed_instr, elapsed_eager], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -312,6 +331,7 @@ def main() -> None:
                 "frac": k4_gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": k4_bytes, "avg_launch_ms": k4_ms, "launches_timed": k4_n,
                 "rocprofv3_avg_launch_ms": rocprof_k4_ms,   # from profiles/ (kernel time without the event overhead)
+                "event_pair_ms_around_empty_kernel": event_overhead_ms,  # median over 64 launches of a 3-element k_mape
                 "how": "HIP events on the launch stream around every K4 launch of an instrumented repeat of the "
                        "timed steps",
             },
