@@ -213,8 +213,7 @@ def main() -> None:
 
     # ---- secondary measurement: a training step WITH backward (gnnsaft_backward), eager; for N > 1 followed by
     # the single flat RCCL all-reduce of the gradients (what DDP does for the reference, train.py:142-145)
-    train = None
-    if args.train_steps > 0:
+    def measure_train_step():
         from gnn_epc_saft_amd.train.loop import allreduce_gradients
         conf = model.configure_optimizers()        # fused AdamW(amsgrad) + CosineAnnealingWarmRestarts
         opt, sched = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
@@ -241,11 +240,21 @@ def main() -> None:
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt[0])
-        train = {"what": "forward + MAPE + backward (all parameter gradients)" +
+        return {"what": "forward + MAPE + backward (all parameter gradients)" +
                          (" + flat gradient all-reduce (RCCL)" if world > 1 else "") +
                          " + fused AdamW(amsgrad) step + LR schedule step, eager",
                  "steps": args.train_steps, "ms_per_step": el / args.train_steps * 1e3,
                  "graphs_per_s": cfg["graphs"] * world * args.train_steps / el}
+
+    train = None
+    if args.train_steps > 0:
+        if world > 1:
+            train = measure_train_step()      # collectives inside: a failure must stay loud on every rank
+        else:
+            try:                              # secondary measurement: never lose the headline line over it
+                train = measure_train_step()
+            except Exception as exc:  # noqa: BLE001
+                train = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     def kernel_ms(bit):
         cnt, tot = ctypes.c_int32(), ctypes.c_float()
@@ -263,7 +272,7 @@ def main() -> None:
     # ~2.4 us of dispatch latency / event handling).  Reported beside the K4 time to explain the gap between the
     # event-timed and the rocprofv3 kernel duration; the roofline `achieved` keeps the raw event time.
     event_overhead_ms = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         from gnn_epc_saft_amd import kernels as _k
         tiny_p, tiny_t = torch.ones(1, 3, device=dev), torch.ones(1, 3, device=dev)
         pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
@@ -351,7 +360,10 @@ def main() -> None:
             "train_step": train,
         }
         if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(cfg, data, deg, args.cpu_budget)
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, data, deg, args.cpu_budget)
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
