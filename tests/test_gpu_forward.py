@@ -348,3 +348,45 @@ def test_cached_structure_gives_the_same_bits_and_is_validated():
     with pytest.raises(ValueError), torch.no_grad():
         m(od)
     assert m.input_error_flags() == 0
+
+
+def test_hip_path_properties_node_relabelling_explicit_loops_isolated_nodes():
+    """The invariances the oracle is held to (tests/test_oracle_cpu.py), on the HIP path itself: relabelling the
+    nodes of a graph, appending the self-loops explicitly instead of setting the flag, and nodes without in-edges."""
+    from gnn_epc_saft_amd.data.synthetic import GraphData, degree_histogram, make_synthetic_batch
+    data = make_synthetic_batch(40, 77)
+    n = data.x.shape[0]
+    oracle = oracle_model(64, 3, 1, 1, 1, 3, True, True, degree_histogram(data), seed=6).eval()
+    hip = hip_twin(copy.deepcopy(oracle))
+    with torch.no_grad():
+        ref = hip(data.to(DEV))
+        # relabel the nodes inside every graph (reverse their order): rows of x / batch permuted, endpoints mapped
+        p = torch.cat([torch.arange(int(data.ptr[g + 1]) - 1, int(data.ptr[g]) - 1, -1) for g in range(data.num_graphs)])
+        inv = torch.empty_like(p)
+        inv[p] = torch.arange(n)
+        relabelled = GraphData(data.x[p], inv[data.edge_index], data.edge_attr, data.batch[p], data.ptr, data.para,
+                               data.num_graphs)
+        assert rel_err(hip(relabelled.to(DEV)), ref) < TOL
+        # self_loops=True  ==  explicit (i, i) edges with attribute [0, 0, 0] appended last, flag off
+        plain = hip_twin(copy.deepcopy(oracle))
+        plain.pna_params = copy.copy(plain.pna_params)
+        plain.pna_params.self_loops = False
+        loops = torch.arange(n).repeat(2, 1)
+        explicit = GraphData(data.x, torch.cat([data.edge_index, loops], dim=1),
+                             torch.cat([data.edge_attr, torch.zeros((n, 3), dtype=torch.int64)]), data.batch,
+                             data.ptr, data.para, data.num_graphs)
+        assert torch.equal(plain(explicit.to(DEV)), ref)          # same rows in the same order: same bits
+        # nodes without in-edges (no self-loops): aggregates are exactly zero, degree 0 is a legal bucket
+        keep = data.edge_index[1] % 3 != 0                          # drop every edge into nodes 0, 3, 6, ...
+        sparse = GraphData(data.x, data.edge_index[:, keep], data.edge_attr[keep], data.batch, data.ptr, data.para,
+                           data.num_graphs)
+        o2 = copy.deepcopy(oracle)
+        o2.pna_params = copy.copy(o2.pna_params)
+        o2.pna_params.self_loops = False
+        h2 = hip_twin(copy.deepcopy(o2))
+        h2.pna_params = copy.copy(h2.pna_params)
+        h2.pna_params.self_loops = False
+        want = copy.deepcopy(o2).double()(sparse)
+        got = h2(sparse.to(DEV)).cpu()
+        assert h2.input_error_flags() == 0
+        assert rel_err(got, want) < max(TOL, 3 * rel_err(copy.deepcopy(o2)(sparse), want))
