@@ -71,7 +71,8 @@ SIGNATURES = {
     "gnnsaft_degree_tiles": (c_int32, [P, c_int64, c_int32, P, P, P, P, P, P]),
     "gnnsaft_pna_fold_post_weights": (c_int32, [P, P, P, P, c_int32, P, P]),
     "gnnsaft_pna_update_folded": (c_int32, [P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
-    "gnnsaft_debug_set_gemm_config": (None, [c_int32]),
+    "gnnsaft_debug_linear_tile": (c_int32, [P, c_int64, P, c_int64, P, P, c_int64, c_int64, c_int32, c_int32, P,
+                                            c_int32, P]),
     "gnnsaft_bn_finalize": (c_int32, [P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, c_int32, P, P, P]),
     "gnnsaft_bn_train_scratch_bytes": (c_size_t, [c_int64, c_int32]),
     "gnnsaft_bn_train_apply": (c_int32, [P, P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, P, P, P, P, c_size_t,

@@ -56,7 +56,11 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict
   f32x4 p = {0.f, 0.f, 0.f, 0.f};
   if (MODE == kFusedPQ) p = gs_ld4(pq + node * (int64_t)(4 * f) + c);
 
-  f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  // Sums are taken of d = m - m_first (the segment's first row): var = E[d^2] - E[d]^2 then has no cancellation.
+  // The textbook E[m^2] - E[m]^2 in f32 carries an absolute error of ~1e-7 m^2, i.e. ~1 % of PyG's 1e-5 masking
+  // threshold: std within 0.8 % only near the threshold, mask flips, and -- through d std/dm = (m - mean)/(n std) --
+  // gradient errors of 2e-3 on the message weights (profiles/r02_std_variance_gradient_analysis.txt).
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, v0 = {0.f, 0.f, 0.f, 0.f};
   const float inf = __builtin_huge_valf();
   f32x4 mn = {inf, inf, inf, inf}, mx = {-inf, -inf, -inf, -inf};
 
@@ -85,12 +89,14 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict
         mrow[j] = gs_ld4(msgs + (int64_t)r * (2 * f) + c);
       }
     }
+    if (r0 == beg) v0 = mrow[0];
 #pragma unroll
     for (int j = 0; j < kEdgeBatch; ++j) {
       if (r0 + j < end) {
         const f32x4 v = mrow[j];
-        s += v;
-        s2 += v * v;
+        const f32x4 d = v - v0;
+        s += d;
+        s2 += d * d;
         mn.x = fminf(mn.x, v.x);
         mn.y = fminf(mn.y, v.y);
         mn.z = fminf(mn.z, v.z);
@@ -107,8 +113,9 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict
   f32x4 mean = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};
   if (cnt > 0) {
     const float fc = (float)cnt;
-    mean = s / fc;
-    const f32x4 var = s2 / fc - mean * mean;
+    const f32x4 dmean = s / fc;
+    mean = v0 + dmean;
+    const f32x4 var = s2 / fc - dmean * dmean;
     // PyG StdAggregation: var.clamp(min=1e-5).sqrt(), then 0 where <= sqrt(1e-5)
     const float thr = 0.0031622776601683794f;
     float sv[4] = {var.x, var.y, var.z, var.w};

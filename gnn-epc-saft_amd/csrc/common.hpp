@@ -108,7 +108,7 @@ __device__ __forceinline__ f32x4 gs_relu4(f32x4 v) {
 
 int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const GemmBatchEntry *entries,
                   int64_t ldw, int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi,
-                  hipStream_t stream);
+                  hipStream_t stream, int cfg = -1 /* tile configuration, -1 = measured heuristic */);
 
 int launch_pna_update(const float *x, const float *agg, const float *log_amp, const float *log_att,
                       const float *avg_deg_log, int64_t n, int hidden, const GemmBatchEntry *entries /*2*/,
@@ -123,8 +123,6 @@ int pna_fold_tile_rows(int hidden);
 int launch_pna_update_folded(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
                              const int32_t *num_tiles, int64_t max_tiles, int64_t n, int hidden, const float *w_eff,
                              const float *b_post0, const float *b_post1, float *u, hipStream_t stream);
-
-void debug_set_gemm_config(int cfg);
 
 // degree-tiled dgrad of the folded update: out[perm[slot], :] = a[perm[slot], a_off:a_off+k] x W(d)^T for the
 // rows of every degree tile; entries[t].w points at the (transposed, folded) weights of degree 0, the weights

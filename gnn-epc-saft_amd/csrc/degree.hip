@@ -319,5 +319,3 @@ extern "C" int gnnsaft_pna_update_folded(const float *x, const float *agg, const
                                       gnnsaft_degree_tiles_capacity(num_nodes, hidden), num_nodes, hidden, w_eff,
                                       b_post0, b_post1, u, static_cast<hipStream_t>(stream));
 }
-
-extern "C" void gnnsaft_debug_set_gemm_config(int32_t cfg) { gs::debug_set_gemm_config(cfg); }

@@ -171,6 +171,17 @@ extern "C" int gnnsaft_linear(const float *a, int64_t lda, int32_t relu_in, cons
   return launch_linear(a, lda, relu_in, 1, &ent, ldw, ldo, m, n_out, k, epi, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int gnnsaft_debug_linear_tile(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
+                                         float *out, int64_t ldo, int64_t m, int32_t n_out, int32_t k, float *stats,
+                                         int32_t tile_config, gnnsaft_stream_t stream) {
+  GemmBatchEntry ent{w, bias, out, 0};
+  LinearEpilogue epi;
+  epi.stats = stats;
+  GS_REQUIRE(stats == nullptr || ldo == n_out, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(tile_config >= 0, GNNSAFT_ERR_SHAPE);
+  return launch_linear(a, lda, 0, 1, &ent, ldw, ldo, m, n_out, k, epi, static_cast<hipStream_t>(stream), tile_config);
+}
+
 extern "C" int gnnsaft_pna_node_terms(const float *x, int64_t num_nodes, int32_t hidden, const float *w_pre0,
                                       const float *w_pre1, float *pq, gnnsaft_stream_t stream) {
   GS_REQUIRE(x && w_pre0 && w_pre1 && pq, GNNSAFT_ERR_NULL);

@@ -468,13 +468,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
 enum GemmCfg { kCfg256x32 = 0, kCfg128x64 = 1, kCfg128x128 = 2, kCfg64x64 = 3, kCfg64x128 = 4, kCfg128x32 = 5,
                kNumCfg = 6 };
 static const int kCfgBM[kNumCfg] = {256, 128, 128, 64, 64, 128};
-static const int kCfgBN[kNumCfg] = {32, 64, 128, 64, 128, 32};
 static const bool kCfgStatsOk[kNumCfg] = {true, true, true, false, true, false};
-static int g_cfg_override = -1;  // gnnsaft_debug_set_gemm_config (tuning only)
 
 static int pick_cfg(int64_t m, int n_out, int k, bool stats) {
-  if (g_cfg_override >= 0 && g_cfg_override < kNumCfg && (!stats || kCfgStatsOk[g_cfg_override]))
-    return g_cfg_override;
   // measured on MI355X (tools/gemm_tune.py, profiles/r01_gemm_tile_sweep.txt)
   if (n_out <= 32) return stats ? kCfg256x32 : kCfg128x32;
   // stats tiles have 64-row waves; up to ~40k rows the 64-row workgroups of 64x128 spread over more CUs than 128x128
@@ -528,7 +524,7 @@ static int launch_cfg(const AProv &ap, int nbatch, const GemmBatch &b, int64_t l
 
 template <class AProv, bool FULL_EPILOGUES>
 static int dispatch(const AProv &ap, int nbatch, const GemmBatchEntry *entries, int64_t ldw, int64_t ldo, int64_t m,
-                    int n_out, int k, const LinearEpilogue &epi, hipStream_t stream) {
+                    int n_out, int k, const LinearEpilogue &epi, hipStream_t stream, int cfg = -1) {
   GS_REQUIRE(nbatch >= 1 && nbatch <= kMaxGemmBatch, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(m >= 0 && n_out >= 1 && k >= 4 && (k % 4) == 0 && (ldw % 4) == 0, GNNSAFT_ERR_SHAPE);
   if (m == 0) return GNNSAFT_OK;
@@ -544,25 +540,25 @@ static int dispatch(const AProv &ap, int nbatch, const GemmBatchEntry *entries, 
   const bool st = epi.stats != nullptr, af = epi.scale != nullptr, rs = epi.residual != nullptr;
   if constexpr (!FULL_EPILOGUES) {
     GS_REQUIRE(!st && !af && !rs, GNNSAFT_ERR_UNSUPPORTED);
-    return launch_cfg<AProv, false, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
+    return launch_cfg<AProv, false, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream, cfg);
   } else {
     if (st) {
       GS_REQUIRE(!af && !rs, GNNSAFT_ERR_UNSUPPORTED);  // train mode writes the pre-BN tensor
-      return launch_cfg<AProv, true, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
+      return launch_cfg<AProv, true, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream, cfg);
     }
-    if (af && rs) return launch_cfg<AProv, false, true, true>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
-    if (af) return launch_cfg<AProv, false, true, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
-    if (rs) return launch_cfg<AProv, false, false, true>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
-    return launch_cfg<AProv, false, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream);
+    if (af && rs) return launch_cfg<AProv, false, true, true>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream, cfg);
+    if (af) return launch_cfg<AProv, false, true, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream, cfg);
+    if (rs) return launch_cfg<AProv, false, false, true>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream, cfg);
+    return launch_cfg<AProv, false, false, false>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, stream, cfg);
   }
 }
 
 int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const GemmBatchEntry *entries, int64_t ldw,
-                  int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi, hipStream_t stream) {
+                  int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi, hipStream_t stream, int cfg) {
   GS_REQUIRE(a != nullptr, GNNSAFT_ERR_NULL);
   GS_REQUIRE((lda % 4) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0, GNNSAFT_ERR_SHAPE);
   PlainA ap{a, lda, relu_in, m, k};
-  return dispatch<PlainA, true>(ap, nbatch, entries, ldw, ldo, m, n_out, k, epi, stream);
+  return dispatch<PlainA, true>(ap, nbatch, entries, ldw, ldo, m, n_out, k, epi, stream, cfg);
 }
 
 int launch_pna_update(const float *x, const float *agg, const float *log_amp, const float *log_att,
@@ -632,7 +628,5 @@ int launch_linear_degree_tiled(const float *a, int64_t lda, const int32_t *perm,
   return launch_cfg<PermPlainA, false, false, false>(ap, nbatch, b, ldw, ldo, n, n_out, k, ea, stream,
                                                      tiled_cfg_for(hidden), max_tiles);
 }
-
-void debug_set_gemm_config(int cfg) { g_cfg_override = cfg; }
 
 }  // namespace gs

@@ -149,6 +149,21 @@ def make_synthetic_batch(num_graphs: int, seed: int, num_para: int = 3, n_min: i
                      torch.from_numpy(batch), torch.from_numpy(ptr), torch.from_numpy(para), num_graphs)
 
 
+def synthetic_dataset(num_graphs: int, seed: int, num_para: int = 3) -> List[GraphData]:
+    """``num_graphs`` single-molecule ``GraphData`` objects (graph-local node ids, ``para`` [num_para]): the
+    synthetic stand-in for an ``InMemoryDataset`` of the reference."""
+    b = make_synthetic_batch(num_graphs, seed, num_para=num_para)
+    ptr = b.ptr.tolist()
+    counts = torch.bincount(b.batch[b.edge_index[1]], minlength=num_graphs)   # edges per graph
+    eptr = [0] + counts.cumsum(0).tolist()                    # edges are graph-contiguous by construction
+    para = b.para.view(num_graphs, num_para)
+    out = []
+    for g in range(num_graphs):
+        n0, n1, e0, e1 = ptr[g], ptr[g + 1], eptr[g], eptr[g + 1]
+        out.append(GraphData(b.x[n0:n1], b.edge_index[:, e0:e1] - n0, b.edge_attr[e0:e1], para=para[g]))
+    return out
+
+
 def split_graphs(data: GraphData, world_size: int, rank: int) -> GraphData:
     """Contiguous ``ptr`` range of graphs for one rank:
     nodes and edges follow their graph, edge ids are re-based locally."""

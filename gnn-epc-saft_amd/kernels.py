@@ -92,7 +92,7 @@ def bn_rows_per_group() -> int:
 
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu_in: bool = False,
            scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, relu_out: bool = False,
-           residual: Optional[torch.Tensor] = None, want_stats: bool = False):
+           residual: Optional[torch.Tensor] = None, want_stats: bool = False, tile_config: Optional[int] = None):
     m, k = a.shape
     n_out = w.shape[0]
     out = torch.empty((m, n_out), dtype=torch.float32, device=a.device)
@@ -100,6 +100,11 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu_
     if want_stats:
         groups = (m + bn_rows_per_group() - 1) // bn_rows_per_group()
         stats = torch.full((groups, 2, n_out), float("nan"), dtype=torch.float32, device=a.device)
+    if tile_config is not None:     # test / tuning hook: explicit tile configuration, plain epilogue only
+        assert not relu_in and scale is None and shift is None and not relu_out and residual is None
+        check(lib.gnnsaft_debug_linear_tile(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), n_out, m, n_out,
+                                            k, _p(stats), int(tile_config), _stream(a)), "gnnsaft_debug_linear_tile")
+        return (out, stats) if want_stats else out
     check(lib.gnnsaft_linear(_p(a), a.stride(0), int(relu_in), _p(w), w.stride(0), _p(bias), _p(out), n_out, m, n_out,
                              k, _p(scale), _p(shift), int(relu_out), _p(residual),
                              0 if residual is None else residual.stride(0), _p(stats), _stream(a)), "gnnsaft_linear")
@@ -207,10 +212,6 @@ def pna_update_folded(x, agg, perm, tiles, num_tiles, hist3, avg_deg_log, w_post
     check(lib.gnnsaft_pna_update_folded(_p(x), _p(agg), _p(perm), _p(tiles), _p(num_tiles), n, h, _p(w_eff),
                                         _p(b_post0), _p(b_post1), _p(u), _stream(x)), "gnnsaft_pna_update_folded")
     return u
-
-
-def debug_set_gemm_config(cfg: int) -> None:
-    lib.gnnsaft_debug_set_gemm_config(int(cfg))
 
 
 def bn_train_apply(stats, y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum: float, eps: float,

@@ -31,7 +31,44 @@ def _world() -> int:
 def allreduce_gradients(optimizer) -> None:
     """Data-parallel exchange of one step: SUM all-reduce of the flat gradient buffer, averaging deferred to the
     optimizer kernel (``grad_scale``).  One collective of 2-28 MB for the reference's model sizes."""
-    optimizer.grad_scale = allreduce_flat_sum(optimizer._flat_grad())
+    flat = optimizer._flat_grad()      # backward's own buffer (zero copy) or a gathered copy of the p.grad tensors
+    optimizer.use_reduced_gradient(flat, allreduce_flat_sum(flat))   # step() consumes THIS buffer, not p.grad again
+
+
+def broadcast_training_state(lit: PNApcsaftL, optimizer, scheduler, step: int, src: int = 0) -> int:
+    """What DDP does when Lightning wraps the module (train.py:142-145): every replica starts from rank ``src``'s
+    parameters and buffers -- plus, here, its optimizer / scheduler state and step counter, so that a resume on
+    one rank or a per-rank seed cannot leave silently diverging replicas.  One flat parameter buffer, one flat
+    buffer per optimizer state, one packed buffer for the BatchNorm statistics."""
+    if _world() == 1:
+        return step
+    dist.broadcast(optimizer.flat_parameters(), src)
+    bufs = [b for b in lit.buffers()]
+    if bufs:
+        packed = torch.cat([b.detach().reshape(-1).to(torch.float64) for b in bufs])
+        dist.broadcast(packed, src)
+        off = 0
+        with torch.no_grad():
+            for b in bufs:
+                b.copy_(packed[off:off + b.numel()].view(b.shape).to(b.dtype))
+                off += b.numel()
+    meta = [None]
+    if dist.get_rank() == src:
+        meta = [dict(step=int(step), steps=int(optimizer._steps), keys=sorted(optimizer._flat_state),
+                     sched=scheduler.state_dict(), lr=[g["lr"] for g in optimizer.param_groups])]
+    dist.broadcast_object_list(meta, src)
+    m = meta[0]
+    for key in m["keys"]:
+        dist.broadcast(optimizer._state_buffer(key), src)
+    if dist.get_rank() != src:
+        optimizer._steps = m["steps"]
+        for p in optimizer._params:
+            if m["steps"]:
+                optimizer.state[p]["step"] = torch.tensor(float(m["steps"]))
+        scheduler.load_state_dict(m["sched"])
+        for g, lr in zip(optimizer.param_groups, m["lr"]):
+            g["lr"] = lr
+    return int(m["step"])
 
 
 def training_loop(lit: PNApcsaftL, batches: Iterable, max_steps: Optional[int] = None, *,
@@ -57,6 +94,7 @@ def training_loop(lit: PNApcsaftL, batches: Iterable, max_steps: Optional[int] =
     lit.train()
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = _world()
+    step = broadcast_training_state(lit, opt, sched, step)
     history: List[Tuple[int, float]] = []
     epoch = 0
     while step < max_steps:
@@ -78,6 +116,11 @@ def training_loop(lit: PNApcsaftL, batches: Iterable, max_steps: Optional[int] =
                     dist.all_reduce(logged, op=dist.ReduceOp.SUM)
                     logged /= world
                 value = float(logged)   # the only host sync of the loop
+                flags = lit.model.input_error_flags()      # rides on that sync: clamped / dropped indices are not
+                if flags:                                   # silent (the reference's Embedding / scatter would fault)
+                    raise ValueError(f"training batches raised GNNSAFT_FLAG_* bits {flags:#x} by step {step} (1 bad "
+                                     "edge index, 2 categorical index outside its vocabulary, 4 batch vector not "
+                                     "sorted / out of range, 8 in-degree >= 32 with the degree-folded update)")
                 history.append((step, value))
                 if on_log is not None and rank == 0:
                     on_log(step, value, float(opt.param_groups[0]["lr"]))

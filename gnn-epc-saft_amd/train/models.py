@@ -125,10 +125,12 @@ class PNAPCSAFT(nn.Module):
         self.hidden_dim = int(hidden_dim)
         self.pna_params = pna_params
         self.mlp_params = mlp_params
-        self.node_embed = _CategoricalTables("atom_embedding_list", atom_feature_dims, hidden_dim)
-        self.edge_embed = _CategoricalTables("bond_embedding_list", bond_feature_dims, hidden_dim)
+        # registration order as in the reference (models.py:62-66: convs, batch_norms, node_embed, edge_embed, mlp):
+        # it fixes ``parameters()`` order, hence the positional indices of torch optimizer state_dicts
         self.convs = nn.ModuleList()
         self.batch_norms = nn.ModuleList()
+        self.node_embed = _CategoricalTables("atom_embedding_list", atom_feature_dims, hidden_dim)
+        self.edge_embed = _CategoricalTables("bond_embedding_list", bond_feature_dims, hidden_dim)
         for _ in range(pna_params.propagation_depth):
             self.convs.append(_PNAConvWeights(hidden_dim, pna_params.deg, pna_params.pre_layers,
                                               pna_params.post_layers))
@@ -147,9 +149,12 @@ class PNAPCSAFT(nn.Module):
         self._err_flag: Optional[torch.Tensor] = None
         self._loss_buf: Optional[torch.Tensor] = None
         # Degree-folded update GEMM (K = 5F instead of 13F): exact for in-degrees (self-loop included) below
-        # gnnsaft_degree_buckets() = 32, which covers molecular graphs; set False for other graphs
-        # (input_error_flags() reports GNNSAFT_FLAG_BAD_DEGREE = 8 if a larger degree was met).
-        self.fold_degree_scalers = True
+        # gnnsaft_degree_buckets() = 32, which covers molecular graphs.  Decided here, on the host, from the
+        # training-set degree histogram the constructor is given anyway: if that histogram reaches the bucket limit
+        # the forward uses the scalers-on-load kernel (K = 13F) instead.  A batch that exceeds the histogram it was
+        # built for raises GNNSAFT_FLAG_BAD_DEGREE = 8 (input_error_flags(); training_loop checks it).
+        max_deg = int(pna_params.deg.numel()) - 1 + int(bool(pna_params.self_loops))
+        self.fold_degree_scalers = max_deg < int(lib.gnnsaft_degree_buckets())
         # Also fold the message's destination term W_dst x_dst (a per-node constant under mean/min/max, invisible
         # to std) into those weights: removes half of the message GEMM and a quarter of K4's reads.  Used when
         # fold_degree_scalers is on, pre_layers == 1 and hidden_dim % 64 == 0; otherwise ignored.
@@ -274,6 +279,10 @@ class PNAPCSAFT(nn.Module):
             if desc.hidden % 64 != 0 or desc.num_para > 8:
                 raise NotImplementedError("backward needs hidden_dim % 64 == 0 and num_para <= 8 (the reference's "
                                           "envelope: 64 / 128 / 256, 3 or 5); run other shapes under torch.no_grad()")
+            if not self.fold_degree_scalers:
+                raise NotImplementedError("backward is implemented for the degree-folded update only (in-degrees "
+                                          "below gnnsaft_degree_buckets() = 32); fold_degree_scalers is off for "
+                                          "this model, run it under torch.no_grad()")
             desc.save_tape, desc.fold_degree_scalers, desc.fold_dst_term = 1, 1, 0
         if x.shape[1] != desc.num_atom_cols or edge_attr.shape[1] != desc.num_bond_cols:
             raise ValueError("x / edge_attr column counts do not match the embedding tables")
@@ -529,12 +538,15 @@ class PNApcsaftL(nn.Module):
         """models.py:162-188."""
         from .optim import FusedAdamW, FusedSGD
         opt_name = _cfg(self.config, "optimizer")
-        params, offsets, total = self.model.flat_layout()
-        params = [p for p in params]
+        # Parameters in ``self.parameters()`` order -- the order the reference hands to torch.optim, which indexes
+        # its state_dict by position -- each with the flat-buffer offset gnnsaft_backward writes its gradient at.
+        table_params, table_offsets, total = self.model.flat_layout()
+        offset_of = {id(p): off for p, off in zip(table_params, table_offsets)}
+        params = list(self.parameters())
         if any(not p.requires_grad for p in params):      # frozen tensors: let the optimizer lay out what is left
             params, layout = [p for p in params if p.requires_grad], None
         else:
-            layout = (offsets, total)
+            layout = ([offset_of[id(p)] for p in params], total)
         if opt_name == "adam":
             opt = FusedAdamW(params, lr=_cfg(self.config, "learning_rate"),
                              weight_decay=_cfg(self.config, "weight_decay"), amsgrad=True, eps=1e-5, layout=layout)

@@ -54,6 +54,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self._flat: Optional[torch.Tensor] = None
         self._flat_state = {}
         self._gather: Optional[torch.Tensor] = None
+        self._reduced: Optional[torch.Tensor] = None   # flat gradient handed over by the data-parallel exchange
         self._steps = 0
         self.grad_scale = 1.0          # set to 1 / world_size by the data-parallel loop (SUM all-reduce)
         self._adopt()
@@ -103,6 +104,30 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 dst.copy_(p.grad)
         return self._gather
 
+    def use_reduced_gradient(self, flat: torch.Tensor, grad_scale: float) -> None:
+        """The data-parallel exchange hands its all-reduced flat buffer (this optimizer's layout) to the NEXT
+        ``step()``, which consumes it once instead of gathering the -- still local -- ``p.grad`` tensors again."""
+        if flat.numel() < self._total or flat.dtype != torch.float32 or flat.device != self._flat.device:
+            raise ValueError("reduced gradient buffer does not match this optimizer's flat layout")
+        self._reduced = flat
+        self.grad_scale = float(grad_scale)
+
+    def _step_gradient(self) -> torch.Tensor:
+        if self._reduced is not None:
+            grad, self._reduced = self._reduced, None
+            return grad
+        return self._flat_grad()
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        self._reduced = None
+        super().zero_grad(set_to_none=set_to_none)
+
+    def flat_parameters(self) -> torch.Tensor:
+        """The one flat f32 buffer every parameter is a view of (broadcast / checksum it as a whole)."""
+        if not self._adopted():
+            self._adopt()
+        return self._flat
+
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)          # torch's loader leaves freshly cloned per-parameter tensors
         loaded = {id(p): dict(self.state[p]) for p in self._params if p in self.state}
@@ -150,7 +175,7 @@ class FusedAdamW(_FlatOptimizer):
         if not self._adopted():
             self._adopt()
         g = self.param_groups[0]
-        grad = self._flat_grad()
+        grad = self._step_gradient()
         m, v = self._state_buffer("exp_avg"), self._state_buffer("exp_avg_sq")
         vmax = self._state_buffer("max_exp_avg_sq") if g["amsgrad"] else None
         step = self._tick()
@@ -189,7 +214,7 @@ class FusedSGD(_FlatOptimizer):
         if not self._adopted():
             self._adopt()
         g = self.param_groups[0]
-        grad = self._flat_grad()
+        grad = self._step_gradient()
         first = "momentum_buffer" not in self._flat_state
         buf = self._state_buffer("momentum_buffer")
         self._tick()

@@ -19,10 +19,10 @@ def calc_deg(dataset, workdir: str = "") -> torch.Tensor:
     path, so this takes the graphs themselves: any iterable of objects with ``edge_index``
     and ``x`` (or ``num_nodes``).  Raw edges only -- no self-loops, even if the model adds them.
     """
-    if isinstance(dataset, str):
+    if isinstance(dataset, str):     # the reference call shape calc_deg("esper", workdir) (train.py:128)
         raise NotImplementedError(
-            f"calc_deg({dataset!r}): loading the reference datasets is out of scope (DVC/GCS, rdkit, ogb absent); "
-            "pass an iterable of graphs instead")
+            f"calc_deg({dataset!r}, {workdir!r}): loading the reference datasets by name is out of scope (DVC/GCS, "
+            "rdkit, ogb absent); pass the graphs themselves -- calc_deg(graphs, workdir) -- instead")
     per_graph = []
     max_degree = -1
     for data in dataset:

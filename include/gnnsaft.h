@@ -232,8 +232,11 @@ int gnnsaft_pna_update_folded(const float *x, const float *agg, const int32_t *p
                               const int32_t *tiles, const int32_t *num_tiles, int64_t num_nodes,
                               int32_t hidden, const float *w_eff, const float *b_post0,
                               const float *b_post1, float *u, gnnsaft_stream_t stream);
-/* tuning hook: force a GEMM tile configuration (-1 = heuristic) */
-void gnnsaft_debug_set_gemm_config(int32_t cfg);
+/* tuning / test hook: gnnsaft_linear (no epilogue options) with an explicit tile configuration    */
+/* 0..5 = 256x32, 128x64, 128x128, 64x64, 64x128, 128x32; per call, the library keeps no global state */
+int gnnsaft_debug_linear_tile(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
+                              float *out, int64_t ldo, int64_t m, int32_t n_out, int32_t k,
+                              float *stats /* or NULL */, int32_t tile_config, gnnsaft_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* BatchNorm (PyG BatchNorm -> torch BatchNorm1d, models.py:82,87,94,98,128).  */

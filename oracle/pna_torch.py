@@ -224,10 +224,10 @@ class OraclePNAPCSAFT(nn.Module):
         super().__init__()
         self.pna_params = pna_params
         self.mlp_params = mlp_params
+        self.convs = nn.ModuleList()          # registration order of models.py:62-66 (fixes parameters() order)
+        self.batch_norms = nn.ModuleList()
         self.node_embed = _CategoricalSum("atom_embedding_list", atom_dims, hidden_dim)
         self.edge_embed = _CategoricalSum("bond_embedding_list", bond_dims, hidden_dim)
-        self.convs = nn.ModuleList()
-        self.batch_norms = nn.ModuleList()
         for _ in range(pna_params.propagation_depth):
             self.convs.append(OraclePNAConv(hidden_dim, pna_params.deg, pna_params.pre_layers, pna_params.post_layers))
             self.batch_norms.append(_NodeBatchNorm(hidden_dim))

@@ -35,8 +35,11 @@ def fill_deterministic(model: torch.nn.Module, seed: int) -> float:
     """Overwrites every parameter / buffer of ``model`` in place; returns the checksum."""
     checksum = 0.0
     sd = model.state_dict()
+    # the checksum is a float sum, hence order-dependent: walk the tensors in the canonical order the fixtures were
+    # generated with, whatever order the module registers its children in
+    groups = ("node_embed", "edge_embed", "convs", "batch_norms", "mlp")
     with torch.no_grad():
-        for name, t in sd.items():
+        for name, t in sorted(sd.items(), key=lambda kv: groups.index(kv[0].split(".")[0])):
             if name.endswith("num_batches_tracked"):
                 t.fill_(3)
                 continue

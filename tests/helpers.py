@@ -45,6 +45,19 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).abs().max()) / scale
 
 
+def gate_err(a: torch.Tensor, b: torch.Tensor, per_row: bool = False):
+    """The parity gate of SURVEY.md section 8(d), per ELEMENT: |a - b| / max(|b|, 1e-6 * max|b|).  Returns the
+    maximum over all elements (or, with ``per_row``, the per-row maxima as a float64 tensor).  Unlike ``rel_err``
+    it does not let small-magnitude outputs hide behind the largest one."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    floor = 1e-6 * float(b.abs().max()) if b.numel() else 0.0
+    e = (a - b).abs() / b.abs().clamp(min=max(floor, 1e-300))
+    if per_row:
+        return e.reshape(e.shape[0], -1).amax(dim=1)
+    return float(e.max()) if e.numel() else 0.0
+
+
 def mini4() -> GraphData:
     """4 graphs: a ring of 5, a single isolated atom (0 edges), a 2-atom molecule, a branched 6-atom tree."""
     g = torch.Generator().manual_seed(7)

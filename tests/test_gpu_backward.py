@@ -63,6 +63,7 @@ CASES = [
     (64, 2, 1, 3, True, True, 32, 1, 2),       # tuner.py search space: pre_layers in {1, 2}
     (128, 2, 1, 3, False, False, 24, 2, 2),
     (64, 1, 1, 3, True, True, 24, 1, 3),
+    (128, 3, 1, 3, True, True, 64, 1, 1),      # the configuration __graft_entry__.smoke() runs
 ]
 
 

@@ -120,12 +120,7 @@ def test_every_gemm_tile_configuration(cfg, m, n_out, k):
     torch.manual_seed(cfg * 7 + m)
     a, w, b = torch.randn(m, k), torch.randn(n_out, k) / math.sqrt(k), torch.randn(n_out)
     ref = a.double() @ w.double().t() + b.double()
-    kk = K()
-    kk.debug_set_gemm_config(cfg)
-    try:
-        out = kk.linear(a.to(DEV), w.to(DEV), b.to(DEV)).cpu()
-    finally:
-        kk.debug_set_gemm_config(-1)
+    out = K().linear(a.to(DEV), w.to(DEV), b.to(DEV), tile_config=cfg).cpu()   # per call: no global tuning state
     assert rel_err(out, ref) < 2e-6
 
 

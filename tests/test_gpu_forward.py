@@ -22,7 +22,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from golden_util import fill_deterministic, list_cases, load_case  # noqa: E402
-from helpers import mini4, oracle_model, rel_err  # noqa: E402
+from helpers import gate_err, mini4, oracle_model, rel_err  # noqa: E402
 from oracle.pna_torch import OracleMlpParams, OraclePNAPCSAFT, OraclePnaParams, mape  # noqa: E402
 
 DEV = "cuda:0"
@@ -70,6 +70,13 @@ def test_golden_vectors(name):
         want32 = torch.from_numpy(case[f"out_{mode}_f32"])
         bar = max(TOL, 3 * rel_err(want32, want64))
         assert rel_err(out, want64) <= bar, (name, mode, rel_err(out, want64), bar)
+        # the SURVEY 8(d) gate, per element.  Eval mode: 1e-5 outright.  Train mode on these 4-graph fixtures runs
+        # BatchNorm1d over FOUR rows in the readout -- the reference arithmetic in f32 (the f32 oracle) is itself
+        # 1.3e-5 .. 1.5e-4 away from the exact result per element there -- so: 3x the f32 oracle's own gate value.
+        gate, gate32 = gate_err(out, want64), gate_err(want32, want64)
+        print(f"{name} {mode}: per-element gate |a-b|/max(|b|,1e-6 max|b|) = {gate:.2e} (f32 oracle {gate32:.2e}), "
+              f"scale-relative {rel_err(out, want64):.2e}")
+        assert gate <= (TOL if mode == "eval" else max(TOL, 3 * gate32)), (name, mode, gate, gate32)
         if mode == "train":
             bn0 = hip.batch_norms[0].module
             assert rel_err(bn0.running_mean, torch.from_numpy(case["train.bn0_running_mean"])) < TOL
@@ -156,7 +163,7 @@ def test_shape_envelope_vs_oracle(cfg, mode):
                 assert int(sd_h[k]) == int(sd_o[k]) == 1
 
 
-FLIP = 2e-3  # upper bound on what one std-threshold flip moves a graph's output (relative to scale)
+FLIP = 5e-3  # upper bound on what one std-threshold flip moves an element of a graph's output (relative to itself)
 
 
 def check_population(out, want32, want64):
@@ -170,13 +177,12 @@ def check_population(out, want32, want64):
         reference's own f32 evaluation is (factor 3), i.e. within 1e-5;
       * the fraction of graphs beyond 1e-5 must not exceed the f32 oracle's by more than 5 points;
       * no graph may be off by more than one flip (FLIP)."""
-    scale = float(want64.abs().max())
-    err_h = (out.double() - want64).abs().amax(dim=1) / scale   # per graph
-    err_o = (want32.double() - want64).abs().amax(dim=1) / scale
+    err_h = gate_err(out, want64, per_row=True)      # per graph: max over its P outputs of the per-element gate
+    err_o = gate_err(want32, want64, per_row=True)
     qs = torch.tensor([0.5, 0.9, 0.99, 1.0], dtype=torch.float64)
     qh, qo = torch.quantile(err_h, qs), torch.quantile(err_o, qs)
     frac_h, frac_o = float((err_h <= TOL).float().mean()), float((err_o <= TOL).float().mean())
-    msg = (f"per-graph error quantiles (50/90/99/100%) hip {['%.1e' % v for v in qh.tolist()]} "
+    msg = (f"per-element gate |a-b|/max(|b|,1e-6 max|b|), per-graph quantiles (50/90/99/100%) hip {['%.1e' % v for v in qh.tolist()]} "
            f"f32-oracle {['%.1e' % v for v in qo.tolist()]}; within {TOL}: hip {frac_h:.4f} f32-oracle {frac_o:.4f}")
     print(msg)
     assert bool((qh[:2] <= torch.clamp(3 * qo[:2], min=TOL)).all()), msg
@@ -193,7 +199,7 @@ def test_single_graph_unbatched_and_one_node_graphs():
     with torch.no_grad():
         out = hip(d.to(DEV)).cpu()          # batch is None -> [1, P]
         want = oracle.double()(d)
-    assert out.shape == (1, 5) and rel_err(out, want) < TOL
+    assert out.shape == (1, 5) and gate_err(out, want) < TOL
     # batch of one graph == un-batched; one-node / zero-edge graphs are legal, with and without loops
     lone = GraphData(d.x[:1], d.edge_index[:, :0], d.edge_attr[:0])
     both = collate([d, lone, lone])
@@ -203,7 +209,7 @@ def test_single_graph_unbatched_and_one_node_graphs():
         with torch.no_grad():
             out = hip(both.to(DEV)).cpu()
             want = oracle.double()(both)
-        assert rel_err(out, want) < TOL
+        assert gate_err(out, want) < TOL
         assert torch.equal(out[1], out[2])
 
 

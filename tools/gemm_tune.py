@@ -53,36 +53,25 @@ def main():
         avg = torch.tensor([1.1], device=DEV)
         rowptr, src, dst, combo, la, lt, _ = K.csr_build(d.edge_index.to(DEV), d.edge_attr.to(DEV), n, (5, 6, 2), True)
         agg = torch.randn(n, 2, 4 * h, device=DEV)
+        w_src = torch.cat([w_pre[0][:, h:2 * h], w_pre[1][:, h:2 * h]]).contiguous()
         shapes = {
-            "node_terms [N,H]x[4H,H]": lambda: K.pna_node_terms(x, w_pre[0], w_pre[1]),
-            "lin+stats  [N,H]x[H,H]": lambda: K.linear(x, w_lin, b_lin, want_stats=True),
-            "lin plain  [N,H]x[H,H]": lambda: K.linear(x, w_lin, b_lin),
+            "src_terms  [N,H]x[2H,H]": lambda c: K.linear(x, w_src, None, tile_config=c),
+            "lin+stats  [N,H]x[H,H]": lambda c: K.linear(x, w_lin, b_lin, want_stats=True, tile_config=c),
+            "lin plain  [N,H]x[H,H]": lambda c: K.linear(x, w_lin, b_lin, tile_config=c),
         }
         print(f"== {name}: N={n} H={h}")
         for sname, fn in shapes.items():
             row = []
-            for cfg in range(6):
-                K.debug_set_gemm_config(cfg)
+            for cfg in range(6):        # explicit tile configuration per call (gnnsaft_debug_linear_tile)
                 try:
-                    row.append(min(timeit(fn) for _ in range(3)))
+                    row.append(min(timeit(lambda: fn(cfg)) for _ in range(3)))
                 except Exception:
                     row.append(float("nan"))
-            K.debug_set_gemm_config(-1)
-            row.append(min(timeit(fn) for _ in range(3)))
+            row.append(min(timeit(lambda: fn(None)) for _ in range(3)))
             print(f"  {sname:26s} " + " ".join(f"{c}:{t:7.1f}" for c, t in zip(CFG_NAMES + ["auto"], row)))
-        # folded update: tile table depends on the configuration's BM
-        row = []
-        for cfg in list(range(6)) + [-1]:
-            K.debug_set_gemm_config(cfg)
-            try:
-                perm, tiles, nt, hist3, _ = K.degree_tiles(rowptr, h)
-                fn = lambda: K.pna_update_folded(x, agg, perm, tiles, nt, hist3, avg, w_post[0], b_post[0], w_post[1],
-                                                 b_post[1])
-                row.append(min(timeit(fn) for _ in range(3)))
-            except Exception as exc:
-                row.append(float("nan"))
-        K.debug_set_gemm_config(-1)
-        print(f"  {'update folded K=5H (+fold)':26s} " + " ".join(f"{c}:{t:7.1f}" for c, t in zip(CFG_NAMES + ["auto"], row)))
+        perm, tiles, nt, hist3, _ = K.degree_tiles(rowptr, h)
+        fn = lambda: K.pna_update_folded(x, agg, perm, tiles, nt, hist3, avg, w_post[0], b_post[0], w_post[1], b_post[1])
+        print(f"  {'update folded K=5H (+fold)':26s} auto:{min(timeit(fn) for _ in range(3)):7.1f}")
         fn = lambda: K.pna_update(x, agg, la, lt, avg, w_post[0], b_post[0], w_post[1], b_post[1])
         print(f"  {'update unfolded K=13H':26s} auto:{min(timeit(fn) for _ in range(3)):7.1f}")
         fn = lambda: K.pna_aggregate(rowptr, src, combo, h, pq=torch.empty(0, device=DEV) if False else pq, rtab=rtab)
