@@ -58,6 +58,43 @@ def gate_err(a: torch.Tensor, b: torch.Tensor, per_row: bool = False):
     return float(e.max()) if e.numel() else 0.0
 
 
+def tape_std_masks(pred: torch.Tensor):
+    """Per layer, which std entries the TAPED HIP forward behind ``pred`` left unmasked ([L] bool tensors [N,2,F]),
+    read from the tape the autograd node keeps (the workspace of gnnsaft_forward with save_tape = 1)."""
+    import ctypes
+
+    from gnn_epc_saft_amd._native import WorkspaceMap, lib
+    tape = pred.grad_fn.tape
+    desc, n, e, g = tape["desc"], tape["n"], tape["e"], tape["g"]
+    wmap = WorkspaceMap()
+    assert lib.gnnsaft_forward_workspace_map(ctypes.byref(desc), n, e, g, ctypes.byref(wmap)) == 0
+    base = tape["ws_ptr"] - tape["ws"].data_ptr()
+    h, layers = desc.hidden, desc.num_layers
+    agg = tape["ws"][base + wmap.agg: base + wmap.agg + 4 * layers * n * 8 * h].view(torch.float32)
+    return [(a[..., 3 * h:] > 0).cpu() for a in agg.view(layers, n, 2, 4 * h)]
+
+
+def std_masks_agree(stages_or_masks, stages64: Dict[str, torch.Tensor]) -> bool:
+    """PyG's StdAggregation zeroes std where var <= 1e-5: a discrete decision per (node, tower, feature).  True when
+    an evaluation (oracle ``stages`` dict, or the list ``tape_std_masks`` returns) took every one of them like the
+    float64 oracle did.  A gradient comparison is only well defined between evaluations that agree here: one
+    differently masked entry moves a whole row of that layer's message weights by ~1e-3 through the 1/std factor of
+    d std / d m (profiles/r02_std_variance_gradient_analysis.txt)."""
+    layer = 0
+    while f"l{layer}.agg" in stages64:
+        a64 = stages64[f"l{layer}.agg"]
+        f = a64.shape[-1] // 4
+        m64 = a64[..., 3 * f:] > 0
+        if isinstance(stages_or_masks, dict):
+            m = stages_or_masks[f"l{layer}.agg"][..., 3 * f:] > 0
+        else:
+            m = stages_or_masks[layer]
+        if not torch.equal(m.cpu(), m64.cpu()):
+            return False
+        layer += 1
+    return True
+
+
 def mini4() -> GraphData:
     """4 graphs: a ring of 5, a single isolated atom (0 edges), a 2-atom molecule, a branched 6-atom tree."""
     g = torch.Generator().manual_seed(7)

@@ -14,7 +14,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import oracle_model, rel_err  # noqa: E402
+from helpers import oracle_model, rel_err, std_masks_agree, tape_std_masks  # noqa: E402
 from oracle.pna_torch import mape, pna_aggregate  # noqa: E402
 from test_gpu_forward import hip_twin  # noqa: E402
 from test_gpu_stages import DEV, K, synth  # noqa: E402
@@ -72,30 +72,30 @@ def test_parameter_gradients_match_oracle_autograd(cfg):
     from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
     from gnn_epc_saft_amd.train.models import mape_loss
     hidden, depth, mlp, num_para, skip, loops, graphs, post, pre = cfg
-    # A std-threshold flip in the forward (tests/test_gpu_forward.py) also moves the gradients discontinuously
-    # (~1e-2 on the flipped tower's message weights).  Take the first batch on which neither the f32 oracle nor
-    # the HIP forward flips w.r.t. the f64 oracle, so that the gradient comparison is well defined.
+    # PyG zeroes std where var <= 1e-5.  An evaluation that takes ONE of those decisions differently from the f64
+    # oracle is off by ~1e-3 on a whole row of that layer's message weights (tests/analysis_gradient_flips_gpu.py:
+    # one entry with var within 1e-9 of the threshold, gradient error confined to that feature's row).  The
+    # comparison is therefore made on the first batch where the f32 oracle and the taped HIP forward took every
+    # masking decision like the f64 oracle -- checked entry by entry on the tape, not guessed from the output.
     for attempt in range(32):
         data = make_synthetic_batch(graphs, 900 + hidden + depth + 1000 * attempt, num_para=num_para)
         oracle = oracle_model(hidden, depth, pre, post, mlp, num_para, skip, loops, degree_histogram(data),
                               seed=depth).train()
+        st64, st32 = {}, {}
         with torch.no_grad():
-            want64 = copy.deepcopy(oracle).double()(data)
-            want32 = copy.deepcopy(oracle)(data)
-            probe = hip_twin(copy.deepcopy(oracle))
-            probe.fold_dst_term = False          # the formulation the grad-mode (tape) forward uses
-            got = probe(data.to(DEV)).cpu()
-        scale = float(want64.abs().max())
-        if max(float((want32.double() - want64).abs().max()), float((got.double() - want64).abs().max())) <= 1e-5 * scale:
+            copy.deepcopy(oracle).double()(data, st64)
+            copy.deepcopy(oracle)(data, st32)
+        hip = hip_twin(copy.deepcopy(oracle))
+        dd = data.to(DEV)
+        pred = hip(dd)                                      # grad mode: builds the autograd node, keeps the tape
+        assert pred.requires_grad
+        if std_masks_agree(st32, st64) and std_masks_agree(tape_std_masks(pred), st64):
             break
     else:
-        pytest.skip("no flip-free batch found")
+        pytest.skip("no batch without a std-mask difference found")
+    print(f"batch {attempt}: std masks of the f32 oracle and of the HIP tape equal the f64 oracle's in all {depth} layers")
     loss64, g64 = grads_of(oracle, data, num_para, torch.float64)
     loss32, g32 = grads_of(oracle, data, num_para, torch.float32)
-    hip = hip_twin(copy.deepcopy(oracle))
-    dd = data.to(DEV)
-    pred = hip(dd)                                      # grad mode: builds the autograd node
-    assert pred.requires_grad
     loss = mape_loss(pred, dd.para.view(-1, num_para))
     loss.backward()
     assert abs(float(loss) - loss64) < 2e-5 * abs(loss64)
@@ -189,19 +189,18 @@ def test_min_max_ties_split_the_gradient_evenly():
                          torch.cat([base.edge_attr, base.edge_attr[dup]]), base.batch, base.ptr, base.para,
                          base.num_graphs)
         oracle = oracle_model(64, 2, 1, 1, 1, 3, True, True, degree_histogram(base), seed=3).train()
+        st64 = {}
         with torch.no_grad():
-            want64 = copy.deepcopy(oracle).double()(data)
-            probe = hip_twin(copy.deepcopy(oracle))
-            probe.fold_dst_term = False
-            got = probe(data.to(DEV)).cpu()
-        if float((got.double() - want64).abs().max()) <= 1e-5 * float(want64.abs().max()):
+            copy.deepcopy(oracle).double()(data, st64)
+        hip = hip_twin(copy.deepcopy(oracle))
+        dd = data.to(DEV)
+        pred = hip(dd)
+        if std_masks_agree(tape_std_masks(pred), st64):
             break
     else:
-        pytest.skip("no flip-free batch found")
+        pytest.skip("no batch without a std-mask difference found")
     loss64, g64 = grads_of(oracle, data, 3, torch.float64)
-    hip = hip_twin(copy.deepcopy(oracle))
-    dd = data.to(DEV)
-    mape_loss(hip(dd), dd.para.view(-1, 3)).backward()
+    mape_loss(pred, dd.para.view(-1, 3)).backward()
     gscale = max(float(g.abs().max()) for g in g64.values())
     for name, p in hip.named_parameters():
         scale = max(float(g64[name].abs().max()), 1e-3 * gscale)
