@@ -105,6 +105,11 @@ SIGNATURES = {
     "gnnsaft_wgrad_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "gnnsaft_linear_wgrad": (c_int32, [P, c_int64, P, c_int64, c_int32, c_int64, c_int32, c_int32, P, c_int64, c_int32,
                                        P, P, c_size_t, P]),
+    "gnnsaft_eval_pack_bytes": (c_size_t, [POINTER(ModelDesc), c_int32]),
+    "gnnsaft_eval_pack": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), c_int32, c_int32, P, c_size_t, P]),
+    "gnnsaft_graph_forward_workspace_bytes": (c_size_t, [POINTER(ModelDesc), c_int32, c_int64, c_int64, c_int64]),
+    "gnnsaft_graph_forward": (c_int32, [POINTER(ModelDesc), c_int32, P, P, P, P, P, c_int64, c_int64, c_int64, P, P, P,
+                                        c_size_t, P]),
     "gnnsaft_profile_create": (c_int32, [c_int32, ctypes.c_uint32, POINTER(c_void_p)]),
     "gnnsaft_profile_destroy": (None, [P]),
     "gnnsaft_profile_reset": (c_int32, [P]),
@@ -112,6 +117,7 @@ SIGNATURES = {
 }
 
 PROF_AGGREGATE, PROF_UPDATE, PROF_NODE_TERMS, PROF_LIN = 1, 2, 4, 8
+DTYPE_F32, DTYPE_F64 = 0, 1
 
 
 def _load() -> ctypes.CDLL:

@@ -6,8 +6,12 @@ in hand-written gfx950 kernels behind the C ABI of ``include/gnnsaft.h``.
 The sub-modules below are parameter containers only (they reproduce the
 attribute names PyG / ogb give their parameters -- SURVEY.md Appendix C -- so
 reference checkpoints load with ``load_state_dict``); none of them computes
-anything.  There is no CPU, fp64 or PyTorch-eager fallback: tensors that are
-not float32 on a HIP device raise.
+anything.  There is no CPU or PyTorch-eager fallback: tensors that are not on
+a HIP device raise.  float32 modules run the batched pipeline (``gnnsaft_forward``,
+train and eval, with backward) or -- eval mode, small batches -- the per-graph
+fused kernel (``gnnsaft_graph_forward``); float64 modules (``.to(torch.float64)``,
+what ``evaluate_ensemble.py:67-77`` and ``demo/utils.py:23-27`` do) run that
+per-graph kernel in double precision, eval mode only.
 """
 
 from __future__ import annotations
@@ -166,6 +170,14 @@ class PNAPCSAFT(nn.Module):
         # backward fast path: set .grad to views of the one flat gradient buffer when every .grad is None
         self.direct_grads = True
         self._profile = None  # gnnsaft_profile* (bench.py attaches one to time kernels with HIP events)
+        # Per-graph fused kernel (csrc/graph_eval.hip: one workgroup per molecule, whole network in one launch):
+        # always for float64 modules; for float32 in eval mode without autograd when the batch has at most this many
+        # graphs (a batch that does not fill the 256 CUs is latency-bound in the ~50-launch batched pipeline).
+        # 0 switches the float32 use off.
+        self.graph_kernel_max_graphs = 256
+        self._eval_pack = None      # (key, packed weights): BatchNorm-folded, transposed; rebuilt when weights change
+        self._pack_generation = 0   # bumped by whoever rewrites parameters behind torch's version counters
+        self._graph_ws: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ host glue
     def _weight_tensors(self) -> List[torch.Tensor]:
@@ -289,12 +301,22 @@ class PNAPCSAFT(nn.Module):
         if self.training and (n < 2 or g < 2):
             raise ValueError("Expected more than 1 value per channel when training")  # torch BatchNorm1d
         weights = self._weight_tensors()
+        fdtype = weights[0].dtype
         for t in weights:
             if t.device != dev or not t.is_contiguous():
                 raise RuntimeError("all parameters and buffers must be contiguous and on the input's device")
-            if t.dtype not in (torch.float32, torch.int64):
-                raise NotImplementedError("only float32 parameters are supported on the MI355X path "
-                                          "(fp64 callers such as evaluate_ensemble.py:68 are out of scope)")
+            if t.dtype != torch.int64 and (t.dtype != fdtype or fdtype not in (torch.float32, torch.float64)):
+                raise NotImplementedError("parameters and buffers must be uniformly float32 or float64 "
+                                          "(module.to(torch.float32) / .to(torch.float64))")
+        if fdtype == torch.float64 or (not tape and not self.training and target is None and
+                                       self._profile is None and 0 < g <= self.graph_kernel_max_graphs and
+                                       desc.hidden % 64 == 0 and desc.hidden <= 256 and
+                                       getattr(data, "gnnsaft_structure", None) is None):
+            if fdtype == torch.float64 and (tape or self.training or target is not None):
+                raise NotImplementedError("float64 modules run the eval-mode forward only (model.eval() under "
+                                          "torch.no_grad(), as evaluate_ensemble.py:67-77 / demo/utils.py:141-152 "
+                                          "use them); train in float32")
+            return self._launch_graph(desc, weights, fdtype, x, edge_index, edge_attr, batch, n, e, g), None, None
         nw = len(weights)
         if nw != lib.gnnsaft_num_weights(ctypes.byref(desc)):
             raise RuntimeError("internal error: weight table length mismatch")
@@ -343,6 +365,54 @@ class PNAPCSAFT(nn.Module):
             ctx = dict(desc=desc, weights=weights, x=x, batch=batch, n=n, e=e, g=g, ws=ws, ws_ptr=ws_ptr,
                        ws_bytes=ws_bytes, dev=dev)
         return out, loss, ctx
+
+    def invalidate_eval_pack(self) -> None:
+        """Forget the packed inference weights.  Needed only after parameters were rewritten behind torch's version
+        counters (raw kernels, ``p.data`` tricks); in-place torch ops, ``load_state_dict``, ``.to()``, ``train()`` /
+        ``eval()`` switches and this package's fused optimizers are noticed without it."""
+        self._pack_generation += 1
+        self._eval_pack = None
+
+    def train(self, mode: bool = True):
+        self._eval_pack = None      # weights move while training: the pack is rebuilt at the next inference call
+        return super().train(mode)
+
+    def _launch_graph(self, desc, weights, fdtype, x, edge_index, edge_attr, batch, n, e, g) -> torch.Tensor:
+        """gnnsaft_graph_forward: eval-mode forward, one workgroup per graph, float32 or float64."""
+        dev = x.device
+        code = _native.DTYPE_F64 if fdtype == torch.float64 else _native.DTYPE_F32
+        if desc.hidden % 64 != 0 or desc.hidden > 256:
+            raise NotImplementedError("the per-graph kernel (float64 modules) supports hidden_dim 64, 128 and 256")
+        key = (self._pack_generation, code, dev, tuple((t.data_ptr(), t._version) for t in weights))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        nw = len(weights)
+        with torch.cuda.device(dev):
+            if self._eval_pack is None or self._eval_pack[0] != key:
+                nbytes = lib.gnnsaft_eval_pack_bytes(ctypes.byref(desc), code)
+                if nbytes == 0:
+                    raise _native.GnnsaftError("configuration outside the per-graph kernel's shape envelope")
+                pack = torch.empty(nbytes + 16, dtype=torch.uint8, device=dev)
+                wtab = (ctypes.c_void_p * nw)(*[t.data_ptr() for t in weights])
+                pp = (pack.data_ptr() + 15) // 16 * 16
+                check(lib.gnnsaft_eval_pack(ctypes.byref(desc), wtab, nw, code, pp, nbytes, stream), "gnnsaft_eval_pack")
+                self._eval_pack = (key, pack, pp)
+            pp = self._eval_pack[2]
+            need = lib.gnnsaft_graph_forward_workspace_bytes(ctypes.byref(desc), code, n, e, g)
+            if need == 0:
+                raise _native.GnnsaftError("configuration outside the per-graph kernel's shape envelope")
+            if self._graph_ws is None or self._graph_ws.device != dev or self._graph_ws.numel() < need + 256:
+                self._graph_ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=dev)
+            ws = self._graph_ws
+            ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+            if self._err_flag is None or self._err_flag.device != dev:
+                self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            out = torch.empty((g, desc.num_para), dtype=fdtype, device=dev)
+            check(lib.gnnsaft_graph_forward(ctypes.byref(desc), code, pp, x.data_ptr(),
+                                            edge_index.data_ptr() if e else None, edge_attr.data_ptr() if e else None,
+                                            None if batch is None else batch.data_ptr(), n, e, g, out.data_ptr(),
+                                            self._err_flag.data_ptr(), ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()),
+                                            stream), "gnnsaft_graph_forward")
+        return out
 
     def flat_layout(self):
         """``(params, offsets, total)``: the slice of ONE flat f32 buffer each trainable tensor of the weight table
@@ -447,6 +517,8 @@ class PNAPCSAFT(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self._workspace = None
+        self._graph_ws = None
+        self._eval_pack = None
         return super()._apply(fn, *args, **kwargs)
 
 
@@ -555,6 +627,7 @@ class PNApcsaftL(nn.Module):
                            weight_decay=_cfg(self.config, "weight_decay"), nesterov=True, layout=layout)
         else:
             raise ValueError(f"Unsupported optimizer: {opt_name}.")
+        opt.on_parameters_rewritten = self.model.invalidate_eval_pack   # fused steps bypass torch's version counters
         sched = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, _cfg(self.config, "warmup_steps"))
         return {"optimizer": opt, "lr_scheduler": {"scheduler": sched, "interval": "step", "frequency": 1}}
 

@@ -57,6 +57,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self._reduced: Optional[torch.Tensor] = None   # flat gradient handed over by the data-parallel exchange
         self._steps = 0
         self.grad_scale = 1.0          # set to 1 / world_size by the data-parallel loop (SUM all-reduce)
+        self.on_parameters_rewritten = None   # callable: the step kernel writes parameters behind torch's version counters
         self._adopt()
 
     # ---- flat parameter buffer
@@ -149,6 +150,8 @@ class _FlatOptimizer(torch.optim.Optimizer):
 
     def _tick(self) -> int:
         self._steps += 1
+        if self.on_parameters_rewritten is not None:
+            self.on_parameters_rewritten()
         for p in self._params:
             self.state[p]["step"] = torch.tensor(float(self._steps))   # host scalar, as torch keeps it
         return self._steps

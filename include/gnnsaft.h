@@ -391,6 +391,35 @@ int gnnsaft_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t l
                          int32_t accumulate, float *dbias, void *scratch, size_t scratch_bytes,
                          gnnsaft_stream_t stream);
 
+/* ------------------------------------------------------------------------ */
+/* Per-graph fused EVAL-mode forward (one workgroup per molecular graph, the   */
+/* whole network in one launch), in float32 or float64.  Serves the reference's */
+/* inference callers, which run the module in float64 / eval mode on one        */
+/* un-batched Data at a time (evaluations/evaluate_ensemble.py:67-77,145,185;   */
+/* demo/utils.py:23-27,141-152; validation_step models.py:204-211), and the     */
+/* single-molecule latency path in float32.                                     */
+/*   gnnsaft_eval_pack: the module's parameters (weights_host as for            */
+/*     gnnsaft_forward, every float tensor of type `dtype`) -> one PACK: Linears  */
+/*     transposed, eval-mode BatchNorm folded, edge branch collapsed to a table   */
+/*     per bond-attribute class.  Rebuild whenever a parameter / buffer changes.  */
+/*   gnnsaft_graph_forward: out[G,P] (dtype) = PNAPCSAFT.forward(data).eval().    */
+/* Supported: hidden in {64,128,256}; desc->training must be 0.                  */
+/* ------------------------------------------------------------------------ */
+#define GNNSAFT_DTYPE_F32 0
+#define GNNSAFT_DTYPE_F64 1
+size_t gnnsaft_eval_pack_bytes(const gnnsaft_model_desc *desc, int32_t dtype);
+int gnnsaft_eval_pack(const gnnsaft_model_desc *desc, const void *const *weights_host,
+                      int32_t num_weights, int32_t dtype, void *pack, size_t pack_bytes,
+                      gnnsaft_stream_t stream);
+size_t gnnsaft_graph_forward_workspace_bytes(const gnnsaft_model_desc *desc, int32_t dtype,
+                                             int64_t num_nodes, int64_t num_edges, int64_t num_graphs);
+int gnnsaft_graph_forward(const gnnsaft_model_desc *desc, int32_t dtype, const void *pack,
+                          const int64_t *x, const int64_t *edge_index, const int64_t *edge_attr,
+                          const int64_t *batch /* NULL => single graph */, int64_t num_nodes,
+                          int64_t num_edges, int64_t num_graphs, void *out /* [G,P] of dtype */,
+                          int32_t *err_flag, void *workspace, size_t workspace_bytes,
+                          gnnsaft_stream_t stream);
+
 /* Debug / test taps: after gnnsaft_forward, byte offsets of intermediate      */
 /* tensors inside the workspace (node state after each layer etc.).            */
 typedef struct gnnsaft_workspace_map {

@@ -1,16 +1,17 @@
 """End-to-end parity of the HIP ``PNAPCSAFT`` against the CPU oracle and the committed golden
 vectors, plus size-independent properties at the BASELINE.json sizes.
 
-Tolerance.  north_star asks for 1e-5 relative f32.  The reference arithmetic has a
-discontinuity (PyG StdAggregation zeroes std where var <= 1e-5) that makes ANY two f32
-evaluations of it -- including the oracle run in f32 vs f64 -- disagree by ~1e-4 on the few
-graphs whose segment variance lands on the threshold (measured: DESIGN.md section 2).  Therefore:
-  * golden fixtures are generated threshold-free, and there the bar is the plain one:
-        max|hip - f64 oracle| <= 1e-5 * max|oracle|          (TOL)
-    relaxed only to 3x the f32 oracle's own distance from the f64 oracle when that is
-    already above 1e-5/3 (4-graph train-mode BatchNorm cases);
-  * at full size the bar is: >= 99% of graphs within TOL, and the worst graph no further from
-    the f64 truth than 3x the f32 oracle's own worst graph.
+Tolerance.  north_star asks for 1e-5 relative f32; SURVEY 8(d) states the gate per element:
+|a - b| / max(|b|, 1e-6 max|b|) <= 1e-5.  Measured facts that shape how it is asserted (helpers.check_population):
+the reference arithmetic has a discontinuity (PyG StdAggregation zeroes std where var <= 1e-5) that makes ANY two
+f32 evaluations of it -- including the oracle run in f32 vs f64 -- disagree by 1e-4..1e-3 on the graphs whose segment
+variance lands on the threshold, and outputs of a random batch pass through zero, where no f32 evaluation is
+1e-5-accurate relative to the element itself.  Therefore:
+  * golden fixtures are generated threshold-free; there the per-element gate is asserted outright in eval mode
+    (<= 1e-5) and against 3x the f32 oracle's own value in train mode (BatchNorm over FOUR rows);
+  * on random batches (shape envelope, BASELINE config 2 at full size) the per-graph distribution of the gate must be
+    as good as the f32 oracle's own (50 % / 90 % quantiles within 3x, fraction within 1e-5 not lower beyond sampling
+    noise, worst graph within 3x the f32 oracle's worst or one flip).  Both distributions are printed.
 """
 
 import copy
@@ -22,7 +23,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from golden_util import fill_deterministic, list_cases, load_case  # noqa: E402
-from helpers import gate_err, mini4, oracle_model, rel_err  # noqa: E402
+from helpers import check_population, gate_err, mini4, oracle_model, rel_err  # noqa: E402
 from oracle.pna_torch import OracleMlpParams, OraclePNAPCSAFT, OraclePnaParams, mape  # noqa: E402
 
 DEV = "cuda:0"
@@ -161,33 +162,6 @@ def test_shape_envelope_vs_oracle(cfg, mode):
                 assert rel_err(sd_h[k], sd_o[k]) < 1e-4, k
             if k.endswith("num_batches_tracked"):
                 assert int(sd_h[k]) == int(sd_o[k]) == 1
-
-
-FLIP = 5e-3  # upper bound on what one std-threshold flip moves an element of a graph's output (relative to itself)
-
-
-def check_population(out, want32, want64):
-    """Per-graph error against the exact (f64) oracle, compared with the error of the reference
-    arithmetic evaluated in f32 (the f32 oracle).
-
-    PyG's StdAggregation zeroes std where var <= 1e-5.  Whether a segment whose variance lies within
-    an ulp of that threshold is zeroed differs between ANY two f32 evaluations (it also differs between
-    the oracle in f32 and in f64); one such flip moves its graph's output by 1e-4 .. 1e-3.  So:
-      * the bulk of the graphs (50% and 90% quantiles) must be as close to the exact result as the
-        reference's own f32 evaluation is (factor 3), i.e. within 1e-5;
-      * the fraction of graphs beyond 1e-5 must not exceed the f32 oracle's by more than 5 points;
-      * no graph may be off by more than one flip (FLIP)."""
-    err_h = gate_err(out, want64, per_row=True)      # per graph: max over its P outputs of the per-element gate
-    err_o = gate_err(want32, want64, per_row=True)
-    qs = torch.tensor([0.5, 0.9, 0.99, 1.0], dtype=torch.float64)
-    qh, qo = torch.quantile(err_h, qs), torch.quantile(err_o, qs)
-    frac_h, frac_o = float((err_h <= TOL).float().mean()), float((err_o <= TOL).float().mean())
-    msg = (f"per-element gate |a-b|/max(|b|,1e-6 max|b|), per-graph quantiles (50/90/99/100%) hip {['%.1e' % v for v in qh.tolist()]} "
-           f"f32-oracle {['%.1e' % v for v in qo.tolist()]}; within {TOL}: hip {frac_h:.4f} f32-oracle {frac_o:.4f}")
-    print(msg)
-    assert bool((qh[:2] <= torch.clamp(3 * qo[:2], min=TOL)).all()), msg
-    assert frac_h >= min(0.99, frac_o - 0.05), msg
-    assert float(qh[3]) <= FLIP, msg
 
 
 def test_single_graph_unbatched_and_one_node_graphs():
