@@ -37,7 +37,7 @@ struct EvalShape {
 // element offsets inside the pack (all multiples of 4)
 struct EvalLayout {
   int64_t atoms, layer0, layer_stride;
-  int64_t wpq, rtab, prex, prex_stride, wpost, bpost, postx, postx_stride, wlin, blin, avg;   // inside a layer
+  int64_t wpq, rtab, prex, prex_stride, wpost, bpost, postx, postx_stride, wlin, slin, blin, avg;   // inside a layer
   int64_t readout0, tmp_cemb, tmp_cenc, total;
 };
 
@@ -67,6 +67,8 @@ __host__ __device__ inline EvalLayout eval_layout(const EvalShape &s) {
   p += (int64_t)(s.post - 1) * l.postx_stride;
   l.wlin = p;
   p += h * h;
+  l.slin = p;    // eval-mode BatchNorm: y = (x W^T) * slin + blin,  slin = gamma rstd, blin = (b - mean) slin + beta
+  p += h;
   l.blin = p;
   p += h;
   l.avg = p;
@@ -77,7 +79,7 @@ __host__ __device__ inline EvalLayout eval_layout(const EvalShape &s) {
   int width = s.h;
   for (int i = 0; i < s.mlp + 3; ++i) {
     const int n_out = i < s.mlp ? s.h : (i == s.mlp ? s.h / 2 : (i == s.mlp + 1 ? s.h / 4 : s.P));
-    o += up4((int64_t)width * n_out) + up4(n_out);
+    o += up4((int64_t)width * n_out) + 2 * up4(n_out);
     width = n_out;
   }
   l.tmp_cemb = o;
@@ -88,7 +90,7 @@ __host__ __device__ inline EvalLayout eval_layout(const EvalShape &s) {
   return l;
 }
 
-// readout block i: offsets of its k-major weight [n_in][n_out] and bias
+// readout block i: offsets of its k-major weight [n_in][n_out], scale [n_out] (at b_off - up4(n_out)) and shift
 __host__ __device__ inline void readout_block(const EvalShape &s, const EvalLayout &l, int i, int64_t &w_off,
                                               int64_t &b_off, int &n_in, int &n_out) {
   int64_t o = l.readout0;
@@ -97,19 +99,19 @@ __host__ __device__ inline void readout_block(const EvalShape &s, const EvalLayo
     const int no = j < s.mlp ? s.h : (j == s.mlp ? s.h / 2 : (j == s.mlp + 1 ? s.h / 4 : s.P));
     if (j == i) {
       w_off = o;
-      b_off = o + up4((int64_t)width * no);
+      b_off = o + up4((int64_t)width * no) + up4(no);
       n_in = width;
       n_out = no;
       return;
     }
-    o += up4((int64_t)width * no) + up4(no);
+    o += up4((int64_t)width * no) + 2 * up4(no);
     width = no;
   }
 }
 
 static int make_shape(const gnnsaft_model_desc *d, EvalShape &s) {
   GS_REQUIRE(d != nullptr, GNNSAFT_ERR_NULL);
-  GS_REQUIRE(d->hidden >= 64 && (d->hidden % 64) == 0 && d->hidden <= 256, GNNSAFT_ERR_UNSUPPORTED);
+  GS_REQUIRE(d->hidden >= 32 && (d->hidden % 32) == 0 && d->hidden <= 256, GNNSAFT_ERR_UNSUPPORTED);
   GS_REQUIRE(d->num_layers >= 0 && d->pre_layers >= 1 && d->pre_layers <= 8 && d->post_layers >= 1 &&
                  d->post_layers <= 8 && d->num_mlp_layers >= 0 && d->num_mlp_layers <= 8 && d->num_para >= 1 &&
                  d->num_para <= 64,
@@ -186,6 +188,14 @@ __global__ void k_pack_bias(const T *__restrict__ b, int n, T *__restrict__ dst,
   dst[c0 + j] = v;
 }
 
+// dst[j] = gamma_j / sqrt(var_j + eps)  (or 1)
+template <typename T>
+__global__ void k_pack_scale(int n, T *__restrict__ dst, const T *__restrict__ gamma, const T *__restrict__ var, T eps) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  dst[j] = gamma != nullptr ? gamma[j] / t_sqrt<T>(var[j] + eps) : (T)1;
+}
+
 template <typename T>
 struct PackTables {
   int n;
@@ -238,7 +248,7 @@ template <typename T>
 static int pack_impl(const gnnsaft_model_desc *d, const EvalShape &s, const EvalLayout &lay, const ParsedWeights &pw,
                      T *pack, hipStream_t st) {
   const int h = s.h;
-  const T eps = (T)d->bn_eps;
+  const T eps = d->bn_eps_f64 > 0.0 ? (T)d->bn_eps_f64 : (T)d->bn_eps;
   auto C = [](const float *p) { return reinterpret_cast<const T *>(p); };
   auto transpose = [&](const T *src, int64_t lds, int rows_j, int cols_k, T *dst, int64_t ldd, int c0, const T *gamma,
                        const T *var) {
@@ -251,6 +261,10 @@ static int pack_impl(const gnnsaft_model_desc *d, const EvalShape &s, const Eval
                        bn ? C(bn->gamma) : nullptr, bn ? C(bn->beta) : nullptr,
                        bn ? reinterpret_cast<const T *>(bn->rmean) : nullptr,
                        bn ? reinterpret_cast<const T *>(bn->rvar) : nullptr, eps);
+  };
+  auto scale = [&](int n, T *dst, const BnPtrs *bn) {
+    hipLaunchKernelGGL(k_pack_scale<T>, dim3((unsigned)gs_ceil_div(n, 256)), dim3(256), 0, st, n, dst,
+                       bn ? C(bn->gamma) : nullptr, bn ? reinterpret_cast<const T *>(bn->rvar) : nullptr, eps);
   };
   {
     PackTables<T> at, bt;
@@ -304,7 +318,8 @@ static int pack_impl(const gnnsaft_model_desc *d, const EvalShape &s, const Eval
         bias(C(w.bpost[t][j]), h / 2, px + (int64_t)(h / 2) * h, t * (h / 2), nullptr);
       }
     }
-    transpose(C(w.wlin), h, h, h, base + lay.wlin, h, 0, C(w.bn.gamma), reinterpret_cast<const T *>(w.bn.rvar));
+    transpose(C(w.wlin), h, h, h, base + lay.wlin, h, 0, nullptr, nullptr);
+    scale(h, base + lay.slin, &w.bn);
     bias(C(w.blin), h, base + lay.blin, 0, &w.bn);
     bias(C(w.avg), 1, base + lay.avg, 0, nullptr);
   }
@@ -314,8 +329,8 @@ static int pack_impl(const gnnsaft_model_desc *d, const EvalShape &s, const Eval
     readout_block(s, lay, i, wo, bo, n_in, n_out);
     const ReadoutW &r = pw.readout[i];
     const bool bn = i < s.mlp + 2;
-    transpose(C(r.w), n_in, n_out, n_in, pack + wo, n_out, 0, bn ? C(r.bn.gamma) : nullptr,
-              bn ? reinterpret_cast<const T *>(r.bn.rvar) : nullptr);
+    transpose(C(r.w), n_in, n_out, n_in, pack + wo, n_out, 0, nullptr, nullptr);
+    scale(n_out, pack + bo - up4(n_out), bn ? &r.bn : nullptr);
     bias(C(r.b), n_out, pack + bo, 0, bn ? &r.bn : nullptr);
   }
   GS_CHECK_LAUNCH();
@@ -343,15 +358,29 @@ struct GraphArgs {
   int32_t *err;
 };
 
+#define GS_LDS(T) __attribute__((address_space(3))) T
+
+#ifdef GS_GF_TIMING   // development probe: wall-clock (100 MHz) stamps of workgroup 0 at phase boundaries
+__device__ long long g_gf_stamp[256];
+#define GF_STAMP(i)                                                      \
+  do {                                                                   \
+    __syncthreads();                                                     \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && (i) < 256) g_gf_stamp[(i)] = wall_clock64(); \
+  } while (0)
+#else
+#define GF_STAMP(i) do {} while (0)
+#endif
+
 template <typename T, int R, class Accum, class Epi>
-__device__ __forceinline__ void wg_gemm(int n_out, int K, T *__restrict__ red, Accum accum, Epi epi) {
+__device__ __forceinline__ void wg_gemm(int n_out, int K, GS_LDS(T) *red, Accum accum, Epi epi) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kl = lane >> 4, cl = lane & 15;
   int np2 = 16;
   while (np2 < n_out && np2 < 256) np2 <<= 1;  // columns per pass
   const int groups = np2 >> 4;                 // waves side by side over the columns
   const int ksw = 16 / groups;                 // waves stacked over K
   const int cg = wave % groups, ks = wave / groups;
-  const int kper = (((K + ksw - 1) / ksw) + 3) & ~3;
+  constexpr int KSTEP = 4 * 16 / (int)sizeof(T);   // k covered by one wave step (4 k-lanes x 16 B)
+  const int kper = (((K + ksw - 1) / ksw) + KSTEP - 1) / KSTEP * KSTEP;
   const int kb = ks * kper;
   const int ke = K < kb + kper ? K : kb + kper;
   for (int c0 = 0; c0 < n_out; c0 += np2) {
@@ -360,7 +389,7 @@ __device__ __forceinline__ void wg_gemm(int n_out, int K, T *__restrict__ red, A
     T acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = (T)0;
-    accum(acc, col_ok ? col : n_out - 1, kb + kl, ke);
+    accum(acc, col_ok ? col : n_out - 1, kb, ke, kl);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       acc[r] += __shfl_xor(acc[r], 16);
@@ -390,30 +419,53 @@ __device__ __forceinline__ void wg_gemm(int n_out, int K, T *__restrict__ red, A
   }
 }
 
-// acc[r] += sum over k = k0, k0+4, ... < ke of f(A[r][k]) * W[k][col]; 8 weight loads in flight
+// acc[r] += sum over this lane's k of f(A[r][k]) * W[k][col] for the wave's K range [kb, ke).  The four k-lanes of a
+// wave take V = 16 B / sizeof(T) CONSECUTIVE k each per step (k = s + V kl + j): one ds_read_b128 per A row and step
+// (rows past the tile's fill hold garbage that is never stored), V weight loads from L2 per step, 64 B per lane in
+// flight while the previous batch is consumed.
 template <typename T, int R, bool RELU>
-__device__ __forceinline__ void dot_range(T (&acc)[R], const T *const (&arow)[R], const T *__restrict__ w, int64_t ldw,
-                                          int col, int k0, int ke) {
-  constexpr int U = 8;
-  for (int k = k0; k < ke; k += 4 * U) {
-    T wv[U];
-    int kc[U];
+__device__ __forceinline__ void dot_range(T (&acc)[R], const GS_LDS(T) *a, int lda, const T *__restrict__ w, int64_t ldw,
+                                          int col, int kb, int ke, int kl) {
+  constexpr int V = 16 / (int)sizeof(T);   // k per lane and step
+  // steps per batch: 64 B of weights per lane in flight (32 B with 8 accumulator rows: the register budget)
+  constexpr int S = (R >= 8 ? 8 : 16) / V / ((int)sizeof(T) / 4);
+  typedef T vecT __attribute__((ext_vector_type(V)));
+  if (kb >= ke) return;
+  // 32-bit unsigned element offsets from the (wave-uniform) base: `global_load v, v_off, s[base]` -- one address
+  // register per load in flight instead of two
+  const unsigned ld = (unsigned)ldw;
+  auto fetch = [&](int s0, T(&wv)[S * V]) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int kk = k + 4 * u;
-      kc[u] = kk < ke ? kk : ke - 1;  // ke > k0 here
-      wv[u] = w[(int64_t)kc[u] * ldw + col];
+    for (int st = 0; st < S; ++st) {
+      const int k4 = s0 + st * 4 * V + V * kl;
+      const unsigned o = (unsigned)(k4 < ke ? k4 : ke - V) * ld + (unsigned)col;
+#pragma unroll
+      for (int j2 = 0; j2 < V; ++j2) wv[st * V + j2] = w[o + (unsigned)j2 * ld];
     }
+  };
+  T wv[S * V];
+  fetch(kb, wv);
+  for (int s0 = kb; s0 < ke; s0 += S * 4 * V) {
+    T wn[S * V];
+    fetch(s0 + S * 4 * V < ke ? s0 + S * 4 * V : s0, wn);   // next batch (re-reads this one at the end: harmless)
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const T wu = (k + 4 * u < ke) ? wv[u] : (T)0;
+    for (int st = 0; st < S; ++st) {
+      const int k4 = s0 + st * 4 * V + V * kl;
+      const bool live = k4 < ke;
+      const int kc = live ? k4 : ke - V;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        T a = arow[r][kc[u]];
-        if (RELU) a = t_max<T>(a, (T)0);
-        acc[r] += a * wu;
+        const vecT av = *reinterpret_cast<const GS_LDS(vecT) *>(a + r * lda + kc);
+#pragma unroll
+        for (int j2 = 0; j2 < V; ++j2) {
+          T x = av[j2];
+          if (RELU) x = t_max<T>(x, (T)0);
+          acc[r] += x * (live ? wv[st * V + j2] : (T)0);
+        }
       }
     }
+#pragma unroll
+    for (int q = 0; q < S * V; ++q) wv[q] = wn[q];
   }
 }
 
@@ -424,16 +476,16 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
   const EvalLayout &lay = a.lay;
   const int h = s.h, f = s.h, tid = threadIdx.x;
   // ---- LDS carve-up
-  T *red = reinterpret_cast<T *>(smem);        // [256 R]
-  T *xt = red + 256 * R;                       // [R][F]   x tile (update) / scratch
-  T *agt = xt + R * f;                         // [R][2][4F] aggregates  (also: edge-row tiles of the extra pre layers)
-  T *ut = agt + R * 8 * f;                     // [R][H]   update output
-  T *ut2 = ut + R * h;                         // [R][H]   ping-pong for extra post layers
-  T *s_amp = ut2 + R * h;                      // [R] amp, [R] att
-  T *s_att = s_amp + R;
-  T *state = s_att + R;                        // optional: x0 [n][H], x1 [n][H], pq [n][4F]
+  GS_LDS(T) *red = (GS_LDS(T) *)smem;          // [256 R]
+  GS_LDS(T) *xt = red + 256 * R;               // [R][F]   x tile (update) / scratch
+  GS_LDS(T) *zt = xt + R * f;                  // [R][2][13F] update operand cat[x, A, A amp, A att] per tower
+                                               //             (also: edge-row tiles of the extra pre layers)
+  GS_LDS(T) *ut = zt + R * 26 * f;             // [R][H]   update output
+  GS_LDS(T) *ut2 = ut + R * h;                 // [R][H]   ping-pong for extra post layers
+  T *state = (T *)(ut2 + R * h + 2 * R);                 // optional: x0 [n][H], x1 [n][H], pq [n][4F] (flat: LDS or global)
   int32_t *l_int = reinterpret_cast<int32_t *>(state + a.lds_state_elems);  // in-kernel CSR (single small graph)
 
+  GF_STAMP(250);
   const int g = blockIdx.x;
   int64_t node0, n_g;
   if (a.graph_ptr != nullptr) {
@@ -539,6 +591,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
     }
   }
   __syncthreads();
+  GF_STAMP(0);
 
   for (int l = 0; l < s.L; ++l) {
     const T *lw = a.pack + lay.layer0 + (int64_t)l * lay.layer_stride;
@@ -547,24 +600,26 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
     // ---- P | Q for every node of the graph
     for (int t0 = 0; t0 < n; t0 += R) {
       const int rows = n - t0 < R ? n - t0 : R;
-      const T *arow[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) arow[r] = x_cur + (int64_t)(t0 + (r < rows ? r : rows - 1)) * h;
+      for (int idx = tid; idx < rows * f; idx += kGfThreads) {
+        const int r = idx / f, c = idx - r * f;
+        xt[r * f + c] = x_cur[(int64_t)(t0 + r) * h + c];
+      }
+      __syncthreads();
       const T *w = lw + lay.wpq;
       wg_gemm<T, R>(
           4 * f, h, red,
-          [&](T(&acc)[R], int col, int k0, int ke) {
-            if (k0 < ke) dot_range<T, R, false>(acc, arow, w, 4 * (int64_t)h, col, k0, ke);
-          },
+          [&](T(&acc)[R], int col, int kb, int ke, int kl) { dot_range<T, R, false>(acc, xt, f, w, 4 * (int64_t)h, col, kb, ke, kl); },
           [&](int r, int col, T v) {
             if (r < rows) pq[(int64_t)(t0 + r) * 4 * h + col] = v;
           });
+      __syncthreads();
     }
     __syncthreads();
+    GF_STAMP(1 + 5 * l);
     // ---- extra pre layers: messages of every CSR row of the graph -> gmsg[row, 2F]
     const int row_lo = rp[0], row_hi = rp[n];
     if (s.pre > 1) {
-      T *ea = agt, *eb = agt + R * 2 * f;  // two [R][2F] edge-row tiles
+      GS_LDS(T) *ea = zt, *eb = zt + R * 2 * f;  // two [R][2F] edge-row tiles
       for (int e0 = row_lo; e0 < row_hi; e0 += R) {
         const int rows = row_hi - e0 < R ? row_hi - e0 : R;
         // h1 = P[dst] + Q[src] + rtab[class]   (pre-activation of the first pre layer)
@@ -581,19 +636,15 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
           ea[r * 2 * f + c] = (pq[(int64_t)lo * 4 * h + c] + pq[sj * 4 * h + 2 * f + c]) + rtab[(int64_t)combos[row] * 2 * f + c];
         }
         __syncthreads();
-        T *cur = ea, *nxt = eb;
+        GS_LDS(T) *cur = ea, *nxt = eb;
         for (int j = 1; j < s.pre; ++j) {
           const T *px = lw + lay.prex + (int64_t)(j - 1) * lay.prex_stride;
           const T *bx = px + 2 * (int64_t)h * h;
           const bool last = j == s.pre - 1;
           wg_gemm<T, R>(
               2 * f, f, red,
-              [&](T(&acc)[R], int col, int k0, int ke) {
-                const T *arow[R];
-                const int toff = (col / f) * f;
-#pragma unroll
-                for (int r = 0; r < R; ++r) arow[r] = cur + (r < rows ? r : rows - 1) * 2 * f + toff;
-                if (k0 < ke) dot_range<T, R, true>(acc, arow, px, 2 * (int64_t)h, col, k0, ke);
+              [&](T(&acc)[R], int col, int kb, int ke, int kl) {
+                dot_range<T, R, true>(acc, cur + (col / f) * f, 2 * f, px, 2 * (int64_t)h, col, kb, ke, kl);
               },
               [&](int r, int col, T v) {
                 if (r >= rows) return;
@@ -602,7 +653,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
                 else nxt[r * 2 * f + col] = v;
               });
           __syncthreads();
-          T *tswap = cur;
+          GS_LDS(T) *tswap = cur;
           cur = nxt;
           nxt = tswap;
         }
@@ -615,12 +666,10 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
       const int rows = n - t0 < R ? n - t0 : R;
       for (int idx = tid; idx < rows * f; idx += kGfThreads) {
         const int r = idx / f, c = idx - r * f;
-        xt[r * f + c] = x_cur[(int64_t)(t0 + r) * h + c];
-      }
-      if (tid < rows) {
-        const int deg = rp[t0 + tid + 1] - rp[t0 + tid];
-        s_amp[tid] = t_log<T>((T)deg + (T)1) / avg;
-        s_att[tid] = avg / t_log<T>(t_max<T>((T)deg, (T)1) + (T)1);
+        const T xv = x_cur[(int64_t)(t0 + r) * h + c];
+        xt[r * f + c] = xv;
+        zt[(r * 2 + 0) * 13 * f + c] = xv;
+        zt[(r * 2 + 1) * 13 * f + c] = xv;
       }
       // mean | min | max | std over the in-edges (sums of m - m_first: no cancellation in the variance)
       for (int idx = tid; idx < rows * 2 * f; idx += kGfThreads) {
@@ -658,98 +707,73 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
           const T o = t_sqrt<T>(t_max<T>(var, (T)1e-5));
           sd = o <= (T)0.0031622776601683794 ? (T)0 : o;   // torch compares with the scalar rounded to T
         }
-        T *o4 = agt + (r * 2 + tw) * 4 * f + col;
-        o4[0] = mean;
-        o4[f] = mn;
-        o4[2 * f] = mx;
-        o4[3 * f] = sd;
+        // cat[A, A amp, A att] with A = [mean | min | max | std]: the three degree scalers applied while writing the tile
+        const int deg = end - beg;
+        const T amp = t_log<T>((T)deg + (T)1) / avg, att = avg / t_log<T>(t_max<T>((T)deg, (T)1) + (T)1);
+        GS_LDS(T) *o4 = zt + (r * 2 + tw) * 13 * f + f + col;
+        const T vals[4] = {mean, mn, mx, sd};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o4[q * f] = vals[q];
+          o4[4 * f + q * f] = vals[q] * amp;
+          o4[8 * f + q * f] = vals[q] * att;
+        }
       }
       __syncthreads();
-      // update: u[r, t F/2 + o] = W_t[o, :] . cat[x, A_t, amp A_t, att A_t] + b   (K = 13 F in 13 F-blocks)
+      if (t0 == 0) GF_STAMP(2 + 5 * l);
+      // update: u[r, t F/2 + o] = W_t[o, :] . cat[x, A_t, amp A_t, att A_t] + b   (K = 13 F, one weight stream)
       {
         const T *w = lw + lay.wpost, *b = lw + lay.bpost;
         wg_gemm<T, R>(
             f, 13 * f, red,
-            [&](T(&acc)[R], int col, int k0, int ke) {
-              const int tw = col / (f / 2);
-              const int kl4 = k0 & 3;
-              for (int blk = (k0 - kl4) / f; blk * f < ke; ++blk) {
-                // this thread's k values inside block blk: k = k0 + 4 i
-                int lo = blk * f > k0 ? blk * f + kl4 : k0;
-                const int hi = (blk + 1) * f < ke ? (blk + 1) * f : ke;
-                if (lo >= hi) continue;
-                const int seg = blk == 0 ? 0 : (blk - 1) / 4;          // 0 identity (and x), 1 amplification, 2 attenuation
-                const int sub = blk == 0 ? 0 : (blk - 1) % 4;          // mean | min | max | std
-                const T *arow[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                  const int rr = r < rows ? r : rows - 1;
-                  // pointer such that arow[r][k] is the operand for global k
-                  arow[r] = (blk == 0 ? xt + rr * f : agt + (rr * 2 + tw) * 4 * f + sub * f) - blk * f;
-                }
-                T part[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) part[r] = (T)0;
-                dot_range<T, R, false>(part, arow, w, (int64_t)h, col, lo, hi);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                  const int rr = r < rows ? r : rows - 1;
-                  const T sc = seg == 0 ? (T)1 : (seg == 1 ? s_amp[rr] : s_att[rr]);
-                  acc[r] += part[r] * sc;
-                }
-              }
+            [&](T(&acc)[R], int col, int kb, int ke, int kl) {
+              dot_range<T, R, false>(acc, zt + (col / (f / 2)) * 13 * f, 26 * f, w, (int64_t)h, col, kb, ke, kl);
             },
             [&](int r, int col, T v) {
               if (r < rows) ut[r * h + col] = v + b[col];
             });
       }
       __syncthreads();
-      T *ucur = ut, *unxt = ut2;
+      if (t0 == 0) GF_STAMP(3 + 5 * l);
+      GS_LDS(T) *ucur = ut, *unxt = ut2;
       for (int j = 1; j < s.post; ++j) {
         const T *px = lw + lay.postx + (int64_t)(j - 1) * lay.postx_stride;
         const T *bx = px + (int64_t)(h / 2) * h;
         wg_gemm<T, R>(
             h, h / 2, red,
-            [&](T(&acc)[R], int col, int k0, int ke) {
-              const T *arow[R];
-              const int toff = (col / (h / 2)) * (h / 2);
-#pragma unroll
-              for (int r = 0; r < R; ++r) arow[r] = ucur + (r < rows ? r : rows - 1) * h + toff;
-              if (k0 < ke) dot_range<T, R, true>(acc, arow, px, (int64_t)h, col, k0, ke);
+            [&](T(&acc)[R], int col, int kb, int ke, int kl) {
+              dot_range<T, R, true>(acc, ucur + (col / (h / 2)) * (h / 2), h, px, (int64_t)h, col, kb, ke, kl);
             },
             [&](int r, int col, T v) {
               if (r < rows) unxt[r * h + col] = v + bx[col];
             });
         __syncthreads();
-        T *tswap = ucur;
+        GS_LDS(T) *tswap = ucur;
         ucur = unxt;
         unxt = tswap;
       }
       // lin with the eval-mode BatchNorm folded in, ReLU, residual
       {
-        const T *w = lw + lay.wlin, *b = lw + lay.blin;
-        const T *arow[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) arow[r] = ucur + (r < rows ? r : rows - 1) * h;
+        const T *w = lw + lay.wlin, *sc = lw + lay.slin, *b = lw + lay.blin;
         wg_gemm<T, R>(
             h, h, red,
-            [&](T(&acc)[R], int col, int k0, int ke) {
-              if (k0 < ke) dot_range<T, R, false>(acc, arow, w, (int64_t)h, col, k0, ke);
-            },
+            [&](T(&acc)[R], int col, int kb, int ke, int kl) { dot_range<T, R, false>(acc, ucur, h, w, (int64_t)h, col, kb, ke, kl); },
             [&](int r, int col, T v) {
               if (r >= rows) return;
-              v = t_max<T>(v + b[col], (T)0);
+              v = t_max<T>(v * sc[col] + b[col], (T)0);
               if (s.skip) v += xt[r * f + col];
               x_nxt[(int64_t)(t0 + r) * h + col] = v;
             });
       }
       __syncthreads();
+      if (t0 == 0) GF_STAMP(4 + 5 * l);
     }
     T *tswap = x_cur;
     x_cur = x_nxt;
     x_nxt = tswap;
     __threadfence_block();
     __syncthreads();
+    GF_STAMP(5 + 5 * l);
   }
 
   // ---- global_add_pool + readout MLP (BatchNorm folded), one row
@@ -759,42 +783,44 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
     ut[c] = acc;
   }
   __syncthreads();
-  T *cur = ut, *nxt = ut2;
+  GS_LDS(T) *cur = ut, *nxt = ut2;
   for (int i = 0; i < s.mlp + 3; ++i) {
     int64_t wo, bo;
     int n_in, n_out;
     readout_block(s, lay, i, wo, bo, n_in, n_out);
-    const T *w = a.pack + wo, *b = a.pack + bo;
+    const T *w = a.pack + wo, *b = a.pack + bo, *sc = b - up4(n_out);
     const bool last = i == s.mlp + 2;
-    const T *arow[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) arow[r] = cur;
     wg_gemm<T, R>(
         n_out, n_in, red,
-        [&](T(&acc)[R], int col, int k0, int ke) {
-          if (k0 < ke) dot_range<T, R, false>(acc, arow, w, (int64_t)n_out, col, k0, ke);
+        [&](T(&acc)[R], int col, int kb, int ke, int kl) {   // lda = 0: every accumulator row sees the one pooled row
+          dot_range<T, R, false>(acc, cur, 0, w, (int64_t)n_out, col, kb, ke, kl);
         },
         [&](int r, int col, T v) {
           if (r != 0) return;
-          v += b[col];
+          v = v * sc[col] + b[col];
           if (last) a.out[(int64_t)g * s.P + col] = v;
           else nxt[col] = t_max<T>(v, (T)0);
         });
     __syncthreads();
-    T *tswap = cur;
+    GS_LDS(T) *tswap = cur;
     cur = nxt;
     nxt = tswap;
   }
+  GF_STAMP(251);
 }
 
-static size_t gf_fixed_lds_elems(int h, int r) { return (size_t)256 * r + (size_t)r * h + (size_t)r * 8 * h + 2 * (size_t)r * h + 2 * (size_t)r; }
+static size_t gf_fixed_lds_elems(int h, int r) { return (size_t)256 * r + (size_t)r * h + (size_t)r * 26 * h + 2 * (size_t)r * h + 2 * (size_t)r; }
 static size_t gf_csr_lds_bytes() { return (size_t)(kGfLdsNodes + 1 + kGfLdsNodes + 2 * (kGfLdsEdges + kGfLdsNodes)) * 4 + 16; }
 constexpr size_t kGfLdsBudget = 150 * 1024;  // of the 160 KB of a gfx950 CU
 
-// rows per node tile: R * F * sizeof(T) = 4 KB
-static int gf_tile_rows(int h, size_t elem) {
-  int r = (int)(4096 / ((size_t)h * elem));
-  return r < 2 ? 2 : (r > 16 ? 16 : r);
+// rows per node tile = accumulators per thread: at most 8 in float32 / 4 in float64 (128 VGPRs at 1024 threads), and
+// what the [R][2][13F] operand tile leaves of the LDS; halved for a single molecule that would leave the tile half empty
+static int gf_tile_rows(int h, size_t elem, int64_t n, int64_t g) {
+  int r = elem == 4 ? 8 : 4;
+  while (r > 2 && gf_fixed_lds_elems(h, r) * elem + gf_csr_lds_bytes() > kGfLdsBudget - 16 * 1024) r /= 2;
+  const int floor_r = elem == 4 ? 4 : 2;
+  if (g == 1 && n <= r / 2 && r / 2 >= floor_r) r /= 2;
+  return r;
 }
 
 struct GfPlan {
@@ -883,28 +909,34 @@ static int graph_forward_impl(const gnnsaft_model_desc *d, const void *pack, con
     a.combo = I(p.combo);
     a.graph_ptr = I(p.graph_ptr);
   }
-  const int r = gf_tile_rows(s.h, sizeof(T));
+  const int r = gf_tile_rows(s.h, sizeof(T), n, g);
   const size_t fixed = gf_fixed_lds_elems(s.h, r) * sizeof(T);
   const size_t csr_b = gf_csr_lds_bytes();
   GS_REQUIRE(fixed + csr_b <= kGfLdsBudget, GNNSAFT_ERR_UNSUPPORTED);
   size_t state_elems = (kGfLdsBudget - fixed - csr_b) / sizeof(T);
   state_elems &= ~(size_t)3;
-  // LDS is allocated per workgroup: do not reserve more state than the largest graph can use
-  const size_t want = (size_t)(g == 1 ? n : 64) * 6 * (size_t)s.h;
+  // LDS is allocated per workgroup: do not reserve more state than the graph can use (batches: room for 28-atom
+  // molecules, which keeps two workgroups per CU at H = 64; larger graphs keep their state in the global scratch)
+  const size_t want = (size_t)(g == 1 ? n : 28) * 6 * (size_t)s.h;
   if (state_elems > want) state_elems = (want + 3) & ~(size_t)3;
   a.lds_state_elems = (int)state_elems;
   const size_t lds_bytes = fixed + state_elems * sizeof(T) + csr_b;
-  switch (r) {
-    case 16: return gf_launch<T, 16>(a, g, lds_bytes, st);
-    case 8: return gf_launch<T, 8>(a, g, lds_bytes, st);
-    case 4: return gf_launch<T, 4>(a, g, lds_bytes, st);
-    default: return gf_launch<T, 2>(a, g, lds_bytes, st);
+  if constexpr (sizeof(T) == 4) {
+    return r == 8 ? gf_launch<T, 8>(a, g, lds_bytes, st) : gf_launch<T, 4>(a, g, lds_bytes, st);
+  } else {
+    return r == 4 ? gf_launch<T, 4>(a, g, lds_bytes, st) : gf_launch<T, 2>(a, g, lds_bytes, st);
   }
 }
 
 }  // namespace gs
 
 using namespace gs;
+
+#ifdef GS_GF_TIMING
+extern "C" int gnnsaft_debug_graph_stamps(long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gf_stamp), sizeof(long long) * 256);
+}
+#endif
 
 extern "C" size_t gnnsaft_eval_pack_bytes(const gnnsaft_model_desc *desc, int32_t dtype) {
   EvalShape s;

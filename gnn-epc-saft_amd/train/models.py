@@ -171,10 +171,12 @@ class PNAPCSAFT(nn.Module):
         self.direct_grads = True
         self._profile = None  # gnnsaft_profile* (bench.py attaches one to time kernels with HIP events)
         # Per-graph fused kernel (csrc/graph_eval.hip: one workgroup per molecule, whole network in one launch):
-        # always for float64 modules; for float32 in eval mode without autograd when the batch has at most this many
-        # graphs (a batch that does not fill the 256 CUs is latency-bound in the ~50-launch batched pipeline).
-        # 0 switches the float32 use off.
-        self.graph_kernel_max_graphs = 256
+        # always for float64 modules; for float32 in eval mode without autograd when the input has at most this many
+        # graphs and nodes.  Measured on MI355X (tools/single_molecule_latency.py, default model H=64 L=6): one
+        # molecule of <= 8 atoms 120-150 us vs 210 us in the ~50-launch batched pipeline; beyond one 8-row tile the
+        # single CU re-streams the layer's weights per tile and the batched pipeline wins again.  0 switches it off.
+        self.graph_kernel_max_graphs = 1
+        self.graph_kernel_max_nodes = 8
         self._eval_pack = None      # (key, packed weights): BatchNorm-folded, transposed; rebuilt when weights change
         self._pack_generation = 0   # bumped by whoever rewrites parameters behind torch's version counters
         self._graph_ws: Optional[torch.Tensor] = None
@@ -245,6 +247,7 @@ class PNAPCSAFT(nn.Module):
             d.bond_dims[k] = t.num_embeddings
         bn0 = self.batch_norms[0].module if len(self.batch_norms) else self.mlp[4 * d.num_mlp_layers][1]
         d.bn_eps = bn0.eps
+        d.bn_eps_f64 = bn0.eps
         d.bn_momentum = 0.1 if bn0.momentum is None else bn0.momentum
         d.fold_degree_scalers = int(self.fold_degree_scalers)
         d.fold_dst_term = int(self.fold_dst_term)
@@ -310,7 +313,8 @@ class PNAPCSAFT(nn.Module):
                                           "(module.to(torch.float32) / .to(torch.float64))")
         if fdtype == torch.float64 or (not tape and not self.training and target is None and
                                        self._profile is None and 0 < g <= self.graph_kernel_max_graphs and
-                                       desc.hidden % 64 == 0 and desc.hidden <= 256 and
+                                       n <= self.graph_kernel_max_nodes and
+                                       desc.hidden <= 256 and
                                        getattr(data, "gnnsaft_structure", None) is None):
             if fdtype == torch.float64 and (tape or self.training or target is not None):
                 raise NotImplementedError("float64 modules run the eval-mode forward only (model.eval() under "
@@ -381,8 +385,8 @@ class PNAPCSAFT(nn.Module):
         """gnnsaft_graph_forward: eval-mode forward, one workgroup per graph, float32 or float64."""
         dev = x.device
         code = _native.DTYPE_F64 if fdtype == torch.float64 else _native.DTYPE_F32
-        if desc.hidden % 64 != 0 or desc.hidden > 256:
-            raise NotImplementedError("the per-graph kernel (float64 modules) supports hidden_dim 64, 128 and 256")
+        if desc.hidden > 256:
+            raise NotImplementedError("the per-graph kernel (float64 modules) supports hidden_dim up to 256")
         key = (self._pack_generation, code, dev, tuple((t.data_ptr(), t._version) for t in weights))
         stream = torch.cuda.current_stream(dev).cuda_stream
         nw = len(weights)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNNSAFT_ABI_VERSION 1
+#define GNNSAFT_ABI_VERSION 2
 
 #define GNNSAFT_OK 0
 #define GNNSAFT_ERR_SHAPE (-1)      /* unsupported / inconsistent sizes          */
@@ -303,6 +303,8 @@ typedef struct gnnsaft_model_desc {
   int32_t fold_degree_scalers; /* 1: degree-folded update (in-degrees < gnnsaft_degree_buckets()) */
   int32_t fold_dst_term;       /* 1: also fold the message's destination term (needs the above, pre_layers == 1) */
   int32_t save_tape;           /* 1: every layer keeps its tensors in the workspace for gnnsaft_backward */
+  int32_t reserved0;           /* keeps the double below 8-byte aligned */
+  double bn_eps_f64;           /* BatchNorm eps in full precision for the float64 kernels (0: use bn_eps) */
 } gnnsaft_model_desc;
 
 int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);
@@ -403,7 +405,7 @@ int gnnsaft_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t l
 /*     transposed, eval-mode BatchNorm folded, edge branch collapsed to a table   */
 /*     per bond-attribute class.  Rebuild whenever a parameter / buffer changes.  */
 /*   gnnsaft_graph_forward: out[G,P] (dtype) = PNAPCSAFT.forward(data).eval().    */
-/* Supported: hidden in {64,128,256}; desc->training must be 0.                  */
+/* Supported: hidden a multiple of 32 up to 256; desc->training must be 0.      */
 /* ------------------------------------------------------------------------ */
 #define GNNSAFT_DTYPE_F32 0
 #define GNNSAFT_DTYPE_F64 1

@@ -20,6 +20,22 @@ DEV = "cuda:0"
 F64_TOL = 1e-12
 
 
+def assert_f64(got, want):
+    """float64 bar on random batches: 1e-13 of the output scale per element (measured: <= 1e-15).  The per-element
+    relative gate is printed; it is <= 1e-12 wherever no output lies within 1e-3 of zero (all fixtures: <= 1.1e-14),
+    and an output of 1e-4 of the scale necessarily shows rounding of 1e-15 of the scale as 1e-11 of itself."""
+    rel, gate = rel_err(got, want), gate_err(got, want)
+    print(f"float64: max|a-b| / max|b| = {rel:.1e}, per-element gate {gate:.1e}")
+    assert rel <= 1e-13 and gate <= 1e-9, (rel, gate)
+
+
+def force_graph_kernel(m):
+    """float32 modules take the per-graph kernel for single small molecules only (measured crossover); the tests
+    push every input through it."""
+    m.graph_kernel_max_graphs, m.graph_kernel_max_nodes = 1 << 30, 1 << 30
+    return m
+
+
 def twin64(oracle):
     """HIP module in float64 with the oracle's weights (what .to(device, torch.float64) gives the reference)."""
     m = hip_twin(copy.deepcopy(oracle)).to(DEV, torch.float64)
@@ -33,8 +49,9 @@ def test_float64_module_on_golden_vectors(name):
     hidden, depth, pre, post, mlp, num_para, skip, loops = (int(v) for v in case["config"])
     oracle = OraclePNAPCSAFT(hidden, OraclePnaParams(depth, pre, post, torch.from_numpy(case["deg"]),
                                                      skip_connections=bool(skip), self_loops=bool(loops)),
-                             OracleMlpParams(mlp, num_para)).double()
-    fill_deterministic(oracle, int(case["seed"][0]))
+                             OracleMlpParams(mlp, num_para))
+    fill_deterministic(oracle, int(case["seed"][0]))     # float32 weights, as the fixtures were generated
+    oracle = oracle.double()
     hip = twin64(oracle)
     assert all(p.dtype == torch.float64 for p in hip.parameters())
     data = graph_data(case)
@@ -42,10 +59,11 @@ def test_float64_module_on_golden_vectors(name):
         out = hip(data.to(DEV))
     assert out.dtype == torch.float64 and out.is_cuda and hip.input_error_flags() == 0
     gate = gate_err(out, torch.from_numpy(case["out_eval_f64"]))
-    print(f"{name}: float64 module, per-element gate vs the stored f64 oracle output {gate:.1e}")
+    print(f"{name}: float64 module, per-element gate vs the stored f64 oracle output {gate:.1e}, scale-relative "
+          f"{rel_err(out, torch.from_numpy(case['out_eval_f64'])):.1e}")
     assert gate <= F64_TOL
     # float32 module through the same kernel (small batch, eval): the plain 1e-5 bar per element
-    hip32 = hip_twin(copy.deepcopy(oracle).float()).eval()
+    hip32 = force_graph_kernel(hip_twin(copy.deepcopy(oracle).float()).eval())
     with torch.no_grad():
         out32 = hip32(data.to(DEV))
         hip32.graph_kernel_max_graphs = 0          # the batched pipeline (gnnsaft_forward) on the same input
@@ -81,13 +99,13 @@ def test_float64_shape_envelope(cfg):
     with torch.no_grad():
         want = oracle(data)
         got = hip(data.to(DEV))
-        assert gate_err(got, want) <= F64_TOL, gate_err(got, want)
+        assert_f64(got, want)
         # un-batched Data (batch=None -> [1, P]), as validation_step / predparams call the model
         for gi in (0, 5, 11):
             one = graphs[gi]
-            assert gate_err(hip(one.to(DEV)), oracle(one)) <= F64_TOL
+            assert_f64(hip(one.to(DEV)), oracle(one))
         # float32 twin of the same weights through the per-graph kernel: population bar against the f32 oracle
-        hip32 = hip_twin(copy.deepcopy(oracle).float()).eval()
+        hip32 = force_graph_kernel(hip_twin(copy.deepcopy(oracle).float()).eval())
         out32 = hip32(data.to(DEV)).cpu()
         check_population(out32, copy.deepcopy(oracle).float()(data), want)
     assert hip.input_error_flags() == 0 and hip32.input_error_flags() == 0
@@ -109,10 +127,10 @@ def test_large_single_graph_and_many_graphs_take_the_global_structure_path():
     oracle = oracle_model(128, 3, 1, 2, 1, 3, True, True, degree_histogram(big), seed=2, dtype=torch.float64).eval()
     hip = twin64(oracle)
     with torch.no_grad():
-        assert gate_err(hip(big.to(DEV)), oracle(big)) <= F64_TOL
+        assert_f64(hip(big.to(DEV)), oracle(big))
         many = make_synthetic_batch(700, 4)
         o2 = oracle_model(64, 2, 1, 1, 1, 3, True, True, degree_histogram(many), seed=3, dtype=torch.float64).eval()
-        assert gate_err(twin64(o2)(many.to(DEV)), o2(many)) <= F64_TOL
+        assert_f64(twin64(o2)(many.to(DEV)), o2(many))
 
 
 def test_float64_is_eval_only_and_float32_weights_are_tracked():
@@ -133,7 +151,7 @@ def test_float64_is_eval_only_and_float32_weights_are_tracked():
         hip.run(dd, target=dd.para.view(-1, 3))   # no float64 loss kernel
     # weights changed through torch (load_state_dict) and through the fused optimizer: the packed copy follows
     o32 = copy.deepcopy(oracle).float()
-    m = hip_twin(copy.deepcopy(o32)).eval()
+    m = force_graph_kernel(hip_twin(copy.deepcopy(o32)).eval())
     eth = ethanol_heavy().to(DEV)
     with torch.no_grad():
         before = m(eth).clone()
@@ -162,7 +180,7 @@ def test_float64_is_eval_only_and_float32_weights_are_tracked():
 def test_single_molecule_call_replays_from_a_hipgraph():
     from gnn_epc_saft_amd.data.synthetic import ethanol_all_atom
     oracle = oracle_model(64, 6, 1, 1, 1, 5, True, True, torch.tensor([0, 6, 2, 0, 1]), seed=4).eval()
-    hip = hip_twin(copy.deepcopy(oracle))
+    hip = force_graph_kernel(hip_twin(copy.deepcopy(oracle)))
     d = ethanol_all_atom().to(DEV)
     with torch.no_grad():
         eager = hip(d).clone()                    # builds the pack outside the capture
