@@ -42,7 +42,11 @@ def broadcast_training_state(lit: PNApcsaftL, optimizer, scheduler, step: int, s
     buffer per optimizer state, one packed buffer for the BatchNorm statistics."""
     if _world() == 1:
         return step
-    dist.broadcast(optimizer.flat_parameters(), src)
+    dist.broadcast(optimizer.flat_parameters(), src)          # every trainable parameter, one collective
+    owned = {id(p) for p in optimizer._params}
+    for p in lit.parameters():                                 # frozen parameters live outside the flat buffer
+        if id(p) not in owned:
+            dist.broadcast(p.data, src)
     bufs = [b for b in lit.buffers()]
     if bufs:
         packed = torch.cat([b.detach().reshape(-1).to(torch.float64) for b in bufs])
