@@ -33,7 +33,7 @@ class ModelDesc(ctypes.Structure):
         ("self_loops", c_int32), ("training", c_int32), ("num_atom_cols", c_int32), ("num_bond_cols", c_int32),
         ("atom_dims", c_int32 * MAX_TABLES), ("bond_dims", c_int32 * MAX_TABLES),
         ("bn_eps", c_float), ("bn_momentum", c_float), ("fold_degree_scalers", c_int32),
-        ("fold_dst_term", c_int32), ("save_tape", c_int32), ("reserved0", c_int32), ("bn_eps_f64", ctypes.c_double),
+        ("fold_dst_term", c_int32), ("save_tape", c_int32), ("unfused_readout", c_int32), ("bn_eps_f64", ctypes.c_double),
     ]
 
 

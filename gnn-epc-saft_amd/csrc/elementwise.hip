@@ -89,9 +89,11 @@ struct PrologueArgs {
   TableSet bonds;
   int64_t combos;
   float *cemb;
-  // zero fill
+  // zero fill (CSR histogram / cursors) + a few counters of later kernels (fused readout barriers)
   int32_t *zero_ptr;
   int64_t zero_count;
+  int32_t *zero2_ptr;
+  int zero2_count;
   // destination-term fold (dst_blocks == 0: off)
   FoldLayers fl;
   float *g_all;
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(256) void k_forward_prologue(PrologueArgs a) {
   } else {
     const int64_t i = (int64_t)(b - a.end_combo) * 256 + threadIdx.x;
     if (i < a.zero_count) a.zero_ptr[i] = 0;
+    if (b == a.end_combo && (int)threadIdx.x < a.zero2_count) a.zero2_ptr[threadIdx.x] = 0;
   }
 }
 
@@ -271,8 +274,9 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
                             int32_t *zero_ptr, int64_t zero_count, int32_t fold_layers,
                             const float *const *w_post0_host, const float *const *w_post1_host,
                             const float *const *w_pre0_host, const float *const *w_pre1_host, float *g_all,
-                            int32_t *err_flag, hipStream_t st) {
+                            int32_t *err_flag, hipStream_t st, int32_t *zero2_ptr, int zero2_count) {
   GS_REQUIRE(x_idx && x_out && cemb && num_rows >= 1, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(zero2_count >= 0 && zero2_count <= 256, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(hidden >= 4 && (hidden % 4) == 0, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(fold_layers >= 0 && fold_layers <= GNNSAFT_MAX_FOLD_LAYERS, GNNSAFT_ERR_SHAPE);
   PrologueArgs a;
@@ -291,6 +295,8 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
   a.cemb = cemb;
   a.zero_ptr = zero_ptr;
   a.zero_count = zero_ptr != nullptr ? zero_count : 0;
+  a.zero2_ptr = zero2_ptr;
+  a.zero2_count = zero2_ptr != nullptr ? zero2_count : 0;
   a.g_all = g_all;
   a.h = hidden;
   for (int i = 0; i < GNNSAFT_MAX_FOLD_LAYERS; ++i) {
@@ -305,7 +311,9 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
   a.dst_gx = hidden / 32;
   a.dst_gy = hidden / 64;
   const int64_t be = gs_ceil_div(num_rows * (hidden / 4), 256), bc = gs_ceil_div(a.combos * (hidden / 4), 256);
-  const int64_t bz = gs_ceil_div(a.zero_count, 256), bd = (int64_t)a.dst_gx * a.dst_gy * 6 * fold_layers;
+  int64_t bz = gs_ceil_div(a.zero_count, 256);
+  if (bz == 0 && a.zero2_count > 0) bz = 1;   // the counters ride on the first zero-fill workgroup
+  const int64_t bd = (int64_t)a.dst_gx * a.dst_gy * 6 * fold_layers;
   GS_REQUIRE(be + bc + bz + bd < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);
   a.dst_blocks = (unsigned)bd;
   a.end_embed = (unsigned)be;

@@ -18,6 +18,7 @@
 
 #include "common.hpp"
 #include "plan.hpp"
+#include "readout.hpp"
 
 // Event pairs recorded on the launch stream around selected launches (bench.py roofline).
 struct gnnsaft_profile {
@@ -458,7 +459,8 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     if (structure_in == nullptr) csr_zero_region(ws + p.csr_ws, n, &zero_ptr, &zero_count);
     GS_TRY(launch_forward_prologue(x_idx, n, d->num_atom_cols, atom_tab, d->atom_dims, d->num_bond_cols, bond_tab,
                                    d->bond_dims, h, F(p.x0), F(p.cemb), zero_ptr, zero_count,
-                                   dst_in_prologue ? d->num_layers : 0, w0, w1, p0, p1, F(p.gfold), err_flag, st));
+                                   dst_in_prologue ? d->num_layers : 0, w0, w1, p0, p1, F(p.gfold), err_flag, st,
+                                   I(p.rd_sync), kRdSyncInts));
   }
   hipStream_t sa = st;
   if (aux != nullptr) {
@@ -638,6 +640,37 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     }
   }
 
+  // ---- readout: one launch (readout.hip) while its workgroups are co-resident, the per-op path beyond
+  if (readout_fused_supported(g, h, d->num_para, p.nb) && !d->unfused_readout) {
+    ReadoutFusedParams rp{};
+    rp.x = xc;
+    rp.graph_ptr = I(p.graph_ptr);
+    rp.g = g;
+    rp.n = n;
+    rp.h = h;
+    rp.num_para = d->num_para;
+    rp.nblocks = p.nb;
+    rp.training = d->training;
+    rp.momentum = d->bn_momentum;
+    rp.eps = d->bn_eps;
+    for (int i = 0; i <= p.nb; ++i) {
+      rp.w[i] = wc.f();
+      rp.b[i] = wc.f();
+      if (i < p.nb) rp.bn[i] = wc.bn();
+    }
+    GS_REQUIRE(wc.ok && wc.i == num_weights, GNNSAFT_ERR_SHAPE);
+    rp.target = loss3 != nullptr ? target : nullptr;
+    rp.out = out;
+    rp.loss3 = target != nullptr ? loss3 : nullptr;
+    rp.pooled = F(p.pooled);
+    rp.ry = F(p.ry);
+    rp.ro = F(p.ro);
+    rp.rstat = F(p.rstat);
+    rp.scratch = ws + p.rd_scratch;
+    rp.sync = I(p.rd_sync);
+    rp.err = err_flag;
+    return launch_readout_fused(rp, st);
+  }
   // ---- readout
   GS_TRY(gnnsaft_add_pool(xc, I(p.graph_ptr), g, n, h, F(p.pooled), st));
   const float *cur = F(p.pooled);

@@ -1,0 +1,331 @@
+// Readout of the PNAPCSAFT forward in ONE launch: global_add_pool -> [Linear -> BatchNorm1d -> ReLU] x (m + 2) ->
+// Linear(H/4, P) -> MAPE  (/root/reference/gnnepcsaft/train/models.py:84-103,133-134,191-194).
+//
+// The per-op form (k_add_pool, 4 GEMM launches, 3 BatchNorm launches, k_mape) is 9 dependent launches of ~5 us each
+// for < 0.1 % of the step's FLOPs: 58 us of a 467 us step at BASELINE config 2.  Here a workgroup owns 64 graphs
+// (rows): it pools them, keeps the activations of all layers in LDS, runs the four small GEMMs on the matrix cores
+// (v_mfma_f32_32x32x2_f32, weights straight from L2 -- they total < 100 KB -- in the k order of gemm.hip), and writes
+// the outputs.  Train-mode BatchNorm needs column statistics over ALL graphs: every workgroup publishes the (mean, M2)
+// of its 64 rows, the grid meets at a device-scope barrier (release / acquire atomics on a counter zeroed by the
+// forward's prologue kernel), and every workgroup folds the <= 256 partials itself (f64, same pivot scheme as
+// bn_train.hip).  The barrier is only safe while all workgroups are co-resident: the launcher uses this kernel for up
+// to 256 workgroups (16 384 graphs, one per CU is always resident) and the per-op path beyond; the spin is bounded and
+// raises GNNSAFT_FLAG_BARRIER_TIMEOUT instead of hanging.  The MAPE sum is closed by the last workgroup to arrive (an
+// atomic ticket), which adds the per-workgroup partials in workgroup order: deterministic, no float atomics.
+#include "plan.hpp"
+#include "readout.hpp"
+
+namespace gs {
+
+constexpr int kRdRows = 64;  // graphs per workgroup
+constexpr int kRdPad = 4;    // floats of row padding in the LDS tiles
+
+struct ReadoutArgs {
+  const float *x;            // [N, H] node state after the last layer
+  const int32_t *graph_ptr;  // [G + 1]
+  int64_t g, n;
+  int h, num_para, nblocks;  // nblocks BatchNorm blocks (m + 2), then the final Linear
+  int training;
+  float momentum, eps;
+  const float *w[kRdMaxBlocks + 1], *b[kRdMaxBlocks + 1];
+  const float *gamma[kRdMaxBlocks], *beta[kRdMaxBlocks];
+  float *rmean[kRdMaxBlocks], *rvar[kRdMaxBlocks];
+  int64_t *nbt[kRdMaxBlocks];
+  int n_in[kRdMaxBlocks + 1], n_out[kRdMaxBlocks + 1];
+  const float *target;       // [G, P] or null
+  float *out;                // [G, P]
+  float *loss3;              // [3] or null
+  float *pooled, *ry, *ro, *rstat;   // tape: [G,H], [nb][G,H], [nb][G,H], [nb][2][H]   (ry / ro row stride H)
+  float *part;               // [nb][W][2][H] per-workgroup (mean, M2)
+  float *mape_part;          // [W]
+  int32_t *sync;             // [nb + 1] counters, zero at launch
+  int32_t *err;
+};
+
+// all workgroups of the grid meet here; returns after every one of them has arrived (or the spin bound is hit)
+__device__ __forceinline__ void grid_barrier(int32_t *counter, int expected, int32_t *err) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    long spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1L << 22)) {  // ~1 s: a workgroup never became resident; give up loudly instead of hanging
+        if (err) atomicOr(err, GNNSAFT_FLAG_BARRIER_TIMEOUT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// y[64][n_out] = a[64][n_in] (LDS) x W^T + bias : 32 x 32 output tiles round-robin over the 4 waves, k in the order
+// of gemm.hip (8 k per step, lane half h takes k0 + 4h .. k0 + 4h + 3)
+__device__ __forceinline__ void rd_gemm(const float *a, int lda, const float *__restrict__ w, const float *__restrict__ bias,
+                                        int n_in, int n_out, float *y, int ldy) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int col_tiles = (n_out + 31) >> 5;
+  for (int t = wave; t < 2 * col_tiles; t += 4) {
+    const int rt = t & 1, ct = t >> 1;
+    const int col = ct * 32 + l31;
+    const int colc = col < n_out ? col : n_out - 1;
+    const float *ap = a + (rt * 32 + l31) * lda + 4 * half;
+    const float *wp = w + (int64_t)colc * n_in + 4 * half;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4 bn = gs_ld4(wp);
+    for (int k0 = 0; k0 < n_in; k0 += 8) {
+      const f32x4 bf = bn;
+      const int kn = k0 + 8 < n_in ? k0 + 8 : k0;   // prefetch the next step's weights (clamped at the end)
+      bn = gs_ld4(wp + kn);
+      const f32x4 af = gs_ld4(ap + k0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
+    }
+    const float bv = bias != nullptr ? bias[colc] : 0.f;
+    if (col < n_out) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        y[row * ldy + col] = acc[r] + bv;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_readout_fused(ReadoutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rd_lds[];
+  const int tid = threadIdx.x;
+  const int h = a.h, ld = h + kRdPad;
+  float *at = rd_lds;                 // [64][ld] activations (input of the current GEMM)
+  float *yt = at + kRdRows * ld;      // [64][ld] pre-BatchNorm output
+  float *s_scale = yt + kRdRows * ld; // [H]
+  float *s_shift = s_scale + h;       // [H]
+  float *s_red = s_shift + h;         // [4]
+  const int64_t row0 = (int64_t)blockIdx.x * kRdRows;
+  const int rows = a.g - row0 < kRdRows ? (int)(a.g - row0) : kRdRows;   // >= 1
+  const int nwg = gridDim.x;
+
+  // ---- global_add_pool: 64 graphs x H, float4 per thread, rows summed in node order
+  for (int idx = tid; idx < kRdRows * (h / 4); idx += 256) {
+    const int r = idx / (h / 4), c = (idx - r * (h / 4)) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      int64_t beg = a.graph_ptr[row0 + r], end = a.graph_ptr[row0 + r + 1];
+      beg = beg < 0 ? 0 : (beg > a.n ? a.n : beg);
+      end = end < beg ? beg : (end > a.n ? a.n : end);
+      int64_t i = beg;
+      for (; i + 4 <= end; i += 4) {
+        const f32x4 v0 = gs_ld4(a.x + (i + 0) * h + c), v1 = gs_ld4(a.x + (i + 1) * h + c);
+        const f32x4 v2 = gs_ld4(a.x + (i + 2) * h + c), v3 = gs_ld4(a.x + (i + 3) * h + c);
+        acc += v0;
+        acc += v1;
+        acc += v2;
+        acc += v3;
+      }
+      for (; i < end; ++i) acc += gs_ld4(a.x + i * h + c);
+      if (a.pooled != nullptr) gs_st4(a.pooled + (row0 + r) * h + c, acc);
+    }
+    gs_st4(at + r * ld + c, acc);
+  }
+  __syncthreads();
+
+  const int64_t rs = a.g * (int64_t)h;  // floats per tape block buffer
+  for (int b = 0; b < a.nblocks; ++b) {
+    const int n_in = a.n_in[b], n_out = a.n_out[b];
+    rd_gemm(at, ld, a.w[b], a.b[b], n_in, n_out, yt, ld);
+    __syncthreads();
+    if (a.ry != nullptr)
+      for (int idx = tid; idx < rows * n_out; idx += 256) {
+        const int r = idx / n_out, c = idx - r * n_out;
+        a.ry[b * rs + (row0 + r) * n_out + c] = yt[r * ld + c];
+      }
+    if (a.training) {
+      // (mean, M2) of this workgroup's rows per column, two passes over LDS
+      if (tid < n_out) {
+        float sum = 0.f;
+        for (int r = 0; r < rows; ++r) sum += yt[r * ld + tid];
+        const float mean = sum / (float)rows;
+        float m2 = 0.f;
+        for (int r = 0; r < rows; ++r) {
+          const float d = yt[r * ld + tid] - mean;
+          m2 += d * d;
+        }
+        float *p = a.part + ((int64_t)b * nwg + blockIdx.x) * 2 * h;
+        p[tid] = mean;
+        p[h + tid] = m2;
+      }
+      grid_barrier(a.sync + b, nwg, a.err);
+      if (tid < n_out) {
+        const float *p = a.part + (int64_t)b * nwg * 2 * h;
+        const double pivot = (double)p[tid];
+        double s1 = 0.0, s2 = 0.0;
+        for (int w0 = 0; w0 < nwg; w0 += 8) {
+          float gm[8], g2[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int w = w0 + u < nwg ? w0 + u : nwg - 1;
+            gm[u] = __builtin_nontemporal_load(p + (int64_t)w * 2 * h + tid);
+            g2[u] = __builtin_nontemporal_load(p + (int64_t)w * 2 * h + h + tid);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int w = w0 + u;
+            if (w < nwg) {
+              const int64_t left = a.g - (int64_t)w * kRdRows;
+              const double gn = (double)(left < kRdRows ? left : kRdRows);
+              const double m = (double)gm[u] - pivot;
+              s1 += gn * m;
+              s2 += (double)g2[u] + gn * m * m;
+            }
+          }
+        }
+        const double nn = (double)a.g;
+        const double dmean = s1 / nn;
+        const double mean = pivot + dmean;
+        double m2 = s2 - nn * dmean * dmean;
+        m2 = m2 > 0.0 ? m2 : 0.0;
+        const float mean_f = (float)mean;
+        const float var_f = (float)(m2 / nn);
+        const float rstd = 1.f / sqrtf(var_f + a.eps);
+        const float sc = rstd * a.gamma[b][tid];
+        s_scale[tid] = sc;
+        s_shift[tid] = a.beta[b][tid] - mean_f * sc;
+        if (blockIdx.x == 0) {
+          if (a.rstat != nullptr) {
+            a.rstat[(int64_t)b * 2 * h + tid] = mean_f;           // layout of k_bn_train_apply: [mean | rstd] of n_out
+            a.rstat[(int64_t)b * 2 * h + n_out + tid] = rstd;
+          }
+          const float unbiased = (float)(nn > 1.0 ? m2 / (nn - 1.0) : m2);
+          a.rmean[b][tid] = (1.f - a.momentum) * a.rmean[b][tid] + a.momentum * mean_f;
+          a.rvar[b][tid] = (1.f - a.momentum) * a.rvar[b][tid] + a.momentum * unbiased;
+          if (tid == 0 && a.nbt[b] != nullptr) a.nbt[b][0] += 1;
+        }
+      }
+    } else if (tid < n_out) {
+      const float rstd = 1.f / sqrtf(a.rvar[b][tid] + a.eps);
+      const float sc = rstd * a.gamma[b][tid];
+      s_scale[tid] = sc;
+      s_shift[tid] = a.beta[b][tid] - a.rmean[b][tid] * sc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kRdRows * n_out; idx += 256) {
+      const int r = idx / n_out, c = idx - r * n_out;
+      const float v = fmaxf(yt[r * ld + c] * s_scale[c] + s_shift[c], 0.f);
+      at[r * ld + c] = v;
+      if (a.ro != nullptr && r < rows) a.ro[b * rs + (row0 + r) * n_out + c] = v;
+    }
+    __syncthreads();
+  }
+  // ---- final Linear(H/4, P)
+  {
+    const int b = a.nblocks;
+    rd_gemm(at, ld, a.w[b], a.b[b], a.n_in[b], a.num_para, yt, ld);
+    __syncthreads();
+    float ape = 0.f;
+    for (int idx = tid; idx < rows * a.num_para; idx += 256) {
+      const int r = idx / a.num_para, c = idx - r * a.num_para;
+      const float v = yt[r * ld + c];
+      a.out[(row0 + r) * a.num_para + c] = v;
+      if (a.target != nullptr) {
+        const float t = a.target[(row0 + r) * a.num_para + c];
+        ape += fabsf(v - t) / fmaxf(fabsf(t), 1.17e-06f);
+      }
+    }
+    if (a.target != nullptr && a.loss3 != nullptr) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ape += __shfl_xor(ape, o);
+      if ((tid & 63) == 0) s_red[tid >> 6] = ape;
+      __syncthreads();
+      if (tid == 0) {
+        a.mape_part[blockIdx.x] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+        const int ticket = __hip_atomic_fetch_add(a.sync + a.nblocks, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == nwg - 1) {  // last workgroup: add the partials in workgroup order
+          float tot = 0.f;
+          for (int w = 0; w < nwg; ++w) tot += __builtin_nontemporal_load(a.mape_part + w);
+          const float cnt = (float)(a.g * a.num_para);
+          a.loss3[0] = tot / cnt;
+          a.loss3[1] = tot;
+          a.loss3[2] = cnt;
+        }
+      }
+    }
+  }
+}
+
+size_t readout_fused_scratch_bytes(int64_t g, int h, int nblocks) {
+  const int64_t wgs = gs_ceil_div(g > 0 ? g : 1, (int64_t)kRdRows);
+  return gs_align_up((size_t)nblocks * wgs * 2 * h * 4, 256) + gs_align_up((size_t)wgs * 4, 256);
+}
+
+bool readout_fused_supported(int64_t g, int h, int num_para, int nblocks) {
+  return g >= 1 && gs_ceil_div(g, (int64_t)kRdRows) <= kRdMaxWorkgroups && h >= 32 && h <= 256 && (h % 32) == 0 &&
+         num_para >= 1 && num_para <= 32 && nblocks >= 2 && nblocks <= kRdMaxBlocks;
+}
+
+int launch_readout_fused(const ReadoutFusedParams &p, hipStream_t st) {
+  GS_REQUIRE(readout_fused_supported(p.g, p.h, p.num_para, p.nblocks), GNNSAFT_ERR_UNSUPPORTED);
+  GS_REQUIRE(p.x && p.graph_ptr && p.out && p.scratch && p.sync, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(!p.training || p.g >= 2, GNNSAFT_ERR_SHAPE);   // torch: "Expected more than 1 value per channel"
+  ReadoutArgs a;
+  a.x = p.x;
+  a.graph_ptr = p.graph_ptr;
+  a.g = p.g;
+  a.n = p.n;
+  a.h = p.h;
+  a.num_para = p.num_para;
+  a.nblocks = p.nblocks;
+  a.training = p.training;
+  a.momentum = p.momentum;
+  a.eps = p.eps;
+  int width = p.h;
+  for (int i = 0; i <= kRdMaxBlocks; ++i) {
+    const bool live = i <= p.nblocks;
+    a.w[i] = live ? p.w[i] : nullptr;
+    a.b[i] = live ? p.b[i] : nullptr;
+    a.n_in[i] = width;
+    int n_out = p.h;
+    if (i == p.nblocks - 2) n_out = p.h / 2;
+    if (i == p.nblocks - 1) n_out = p.h / 4;
+    if (i == p.nblocks) n_out = p.num_para;
+    a.n_out[i] = n_out;
+    width = n_out;
+    GS_REQUIRE(!live || (a.w[i] != nullptr && a.b[i] != nullptr), GNNSAFT_ERR_NULL);
+    if (i < kRdMaxBlocks) {
+      const bool bl = i < p.nblocks;
+      a.gamma[i] = bl ? p.bn[i].gamma : nullptr;
+      a.beta[i] = bl ? p.bn[i].beta : nullptr;
+      a.rmean[i] = bl ? p.bn[i].rmean : nullptr;
+      a.rvar[i] = bl ? p.bn[i].rvar : nullptr;
+      a.nbt[i] = bl ? p.bn[i].nbt : nullptr;
+      GS_REQUIRE(!bl || (a.gamma[i] && a.beta[i] && a.rmean[i] && a.rvar[i]), GNNSAFT_ERR_NULL);
+    }
+  }
+  a.target = p.target;
+  a.out = p.out;
+  a.loss3 = p.loss3;
+  a.pooled = p.pooled;
+  a.ry = p.ry;
+  a.ro = p.ro;
+  a.rstat = p.rstat;
+  const int64_t wgs = gs_ceil_div(p.g, (int64_t)kRdRows);
+  a.part = static_cast<float *>(p.scratch);
+  a.mape_part = reinterpret_cast<float *>(static_cast<char *>(p.scratch) +
+                                          gs_align_up((size_t)p.nblocks * wgs * 2 * p.h * 4, 256));
+  a.sync = p.sync;
+  a.err = p.err;
+  const size_t lds = ((size_t)2 * kRdRows * (p.h + kRdPad) + 2 * (size_t)p.h + 8) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_readout_fused),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_readout_fused, dim3((unsigned)wgs), dim3(256), lds, st, a);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+}  // namespace gs

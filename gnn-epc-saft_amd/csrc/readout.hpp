@@ -1,0 +1,31 @@
+// Fused readout (readout.hip): parameters of the one-launch add-pool -> MLP -> MAPE kernel.
+#pragma once
+#include "plan.hpp"
+
+namespace gs {
+
+constexpr int kRdMaxBlocks = 10;        // BatchNorm blocks of the readout: num_mlp_layers (<= 8) + 2
+constexpr int kRdMaxWorkgroups = 256;   // all workgroups must be co-resident for the grid barrier: one per CU
+constexpr int kRdSyncInts = 16;         // barrier / ticket counters, zeroed by the forward's prologue kernel
+
+struct ReadoutFusedParams {
+  const float *x;
+  const int32_t *graph_ptr;
+  int64_t g, n;
+  int h, num_para, nblocks, training;
+  float momentum, eps;
+  const float *w[kRdMaxBlocks + 1], *b[kRdMaxBlocks + 1];   // nblocks BatchNorm blocks, then the final Linear
+  BnPtrs bn[kRdMaxBlocks];
+  const float *target;
+  float *out, *loss3;
+  float *pooled, *ry, *ro, *rstat;       // kept for the backward (may be null)
+  void *scratch;                          // readout_fused_scratch_bytes
+  int32_t *sync;                          // kRdSyncInts ints, zero at launch
+  int32_t *err;
+};
+
+size_t readout_fused_scratch_bytes(int64_t g, int h, int nblocks);
+bool readout_fused_supported(int64_t g, int h, int num_para, int nblocks);
+int launch_readout_fused(const ReadoutFusedParams &p, hipStream_t st);
+
+}  // namespace gs

@@ -170,6 +170,9 @@ class PNAPCSAFT(nn.Module):
         # backward fast path: set .grad to views of the one flat gradient buffer when every .grad is None
         self.direct_grads = True
         self._profile = None  # gnnsaft_profile* (bench.py attaches one to time kernels with HIP events)
+        # add-pool -> readout MLP (train-mode BatchNorm across the batch through a grid barrier) -> MAPE in ONE launch
+        # (csrc/readout.hip) for up to 16 384 graphs; False restores the nine per-op launches
+        self.fused_readout = True
         # Per-graph fused kernel (csrc/graph_eval.hip: one workgroup per molecule, whole network in one launch):
         # always for float64 modules; for float32 in eval mode without autograd when the input has at most this many
         # graphs and nodes.  Measured on MI355X (tools/single_molecule_latency.py, default model H=64 L=6): one
@@ -251,6 +254,7 @@ class PNAPCSAFT(nn.Module):
         d.bn_momentum = 0.1 if bn0.momentum is None else bn0.momentum
         d.fold_degree_scalers = int(self.fold_degree_scalers)
         d.fold_dst_term = int(self.fold_dst_term)
+        d.unfused_readout = int(not self.fused_readout)
         return d
 
     def _check_mode(self, x: torch.Tensor) -> None:

@@ -44,6 +44,9 @@ extern "C" {
 #define GNNSAFT_FLAG_BAD_BATCH 4    /* batch not sorted / outside [0,G)          */
 #define GNNSAFT_FLAG_BAD_DEGREE 8   /* in-degree >= gnnsaft_degree_buckets() with */
                                     /* degree folding on: disable folding         */
+#define GNNSAFT_FLAG_BARRIER_TIMEOUT 16 /* a grid barrier of the fused readout gave  */
+                                    /* up waiting (workgroups not co-resident):    */
+                                    /* the outputs of that call are invalid         */
 
 #define GNNSAFT_MAX_TABLES 16
 #define GNNSAFT_TOWERS 2            /* models.py:76 towers=2                      */
@@ -303,7 +306,7 @@ typedef struct gnnsaft_model_desc {
   int32_t fold_degree_scalers; /* 1: degree-folded update (in-degrees < gnnsaft_degree_buckets()) */
   int32_t fold_dst_term;       /* 1: also fold the message's destination term (needs the above, pre_layers == 1) */
   int32_t save_tape;           /* 1: every layer keeps its tensors in the workspace for gnnsaft_backward */
-  int32_t reserved0;           /* keeps the double below 8-byte aligned */
+  int32_t unfused_readout;     /* 1: per-op readout (pool, GEMMs, BatchNorm, MAPE launches) instead of readout.hip */
   double bn_eps_f64;           /* BatchNorm eps in full precision for the float64 kernels (0: use bn_eps) */
 } gnnsaft_model_desc;
 

@@ -1,0 +1,107 @@
+"""The one-launch readout (csrc/readout.hip: add-pool -> Linear/BatchNorm/ReLU blocks -> Linear -> MAPE, train-mode
+BatchNorm statistics across workgroups through a grid barrier) against the nine per-op launches it replaces
+(``fused_readout = False``) and against the f64 oracle (reference: models.py:84-103,133-134,191-194)."""
+
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import oracle_model, rel_err  # noqa: E402
+from oracle.pna_torch import mape  # noqa: E402
+from test_gpu_forward import hip_twin  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("hidden,mlp,num_para,graphs", [(128, 1, 3, 1024), (64, 1, 5, 511), (256, 2, 3, 200),
+                                                        (64, 0, 5, 2), (32, 1, 3, 70), (128, 2, 5, 65)])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_fused_readout_equals_per_op_readout_and_oracle(hidden, mlp, num_para, graphs, mode):
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    data = make_synthetic_batch(graphs, 10 + graphs, num_para=num_para)
+    oracle = oracle_model(hidden, 1, 1, 1, mlp, num_para, True, True, degree_histogram(data), seed=graphs)
+    oracle.train(mode == "train")
+    dd, tgt = data.to(DEV), data.para.view(-1, num_para).to(DEV)
+    runs = {}
+    for fused in (True, False):
+        m = hip_twin(copy.deepcopy(oracle))
+        m.fused_readout = fused
+        m.graph_kernel_max_graphs = 0
+        with torch.no_grad():
+            pred, loss3 = m.run(dd, target=tgt)
+            pred2 = m(dd)                              # no target: the loss part is skipped
+        assert m.input_error_flags() == 0
+        assert torch.equal(pred, pred2) or mode == "train"   # train mode: same batch statistics, same outputs
+        runs[fused] = (pred.cpu(), loss3.cpu(), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    (p1, l1, s1), (p0, l0, s0) = runs[True], runs[False]
+    assert rel_err(p1, p0) < 2e-6, rel_err(p1, p0)
+    assert abs(float(l1[0]) - float(l0[0])) < 1e-6 * abs(float(l0[0])) and float(l1[2]) == float(l0[2]) == graphs * num_para
+    for k in s0:
+        if "running_" in k:
+            assert rel_err(s1[k], s0[k]) < 2e-6, k
+        if k.endswith("num_batches_tracked"):
+            assert int(s1[k]) == int(s0[k])
+    o64 = copy.deepcopy(oracle).double()
+    with torch.no_grad():
+        want = o64(data)
+    assert rel_err(p1, want) < (3e-5 if mode == "train" else 1e-5)
+    assert abs(float(l1[0]) - float(mape(want, data.para.view(-1, num_para).double()))) < 1e-4 * float(l1[0])
+    if mode == "train":
+        for k, v in o64.state_dict().items():
+            if k.startswith("mlp") and "running_" in k:
+                assert rel_err(s1[k], v) < 1e-4, k
+
+
+def test_fused_readout_feeds_the_backward_tape():
+    """Gradients through the taped forward are the same whether the readout ran fused or per-op."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    from gnn_epc_saft_amd.train.models import mape_loss
+    data = make_synthetic_batch(96, 3)
+    oracle = oracle_model(64, 2, 1, 1, 1, 3, True, True, degree_histogram(data), seed=5).train()
+    dd = data.to(DEV)
+    grads = {}
+    for fused in (True, False):
+        m = hip_twin(copy.deepcopy(oracle))
+        m.fused_readout = fused
+        mape_loss(m(dd), dd.para.view(-1, 3)).backward()
+        grads[fused] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    for k in grads[True]:
+        scale = float(grads[False][k].abs().max())
+        assert float((grads[True][k] - grads[False][k]).abs().max()) <= 2e-5 * max(scale, 1e-6), k
+
+
+def test_large_batches_take_the_per_op_readout_and_many_steps_reuse_the_counters():
+    """More than 256 workgroups' worth of graphs (16 384) cannot be co-resident: per-op path, same results API;
+    repeated steps and a hipGraph replay keep working because the prologue re-zeroes the barrier counters."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    data = make_synthetic_batch(300, 8)
+    oracle = oracle_model(64, 1, 1, 1, 1, 3, True, True, degree_histogram(data), seed=1).train()
+    m = hip_twin(copy.deepcopy(oracle))
+    dd, tgt = data.to(DEV), data.para.view(-1, 3).to(DEV)
+    ref = hip_twin(copy.deepcopy(oracle))
+    ref.fused_readout = False
+    with torch.no_grad():
+        for _ in range(5):
+            p1, l1 = m.run(dd, target=tgt)
+            p0, l0 = ref.run(dd, target=tgt)
+            assert rel_err(p1, p0) < 2e-6 and abs(float(l1[0]) - float(l0[0])) < 1e-6 * float(l0[0])
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            pg, lg = m.run(dd, target=tgt)
+        for _ in range(3):
+            g.replay()
+            p0, l0 = ref.run(dd, target=tgt)
+        torch.cuda.synchronize()
+        assert rel_err(pg, p0) < 2e-6
+    assert m.input_error_flags() == 0
+    big = make_synthetic_batch(16384 + 64, 9, n_min=2, n_max=3)
+    ob = oracle_model(64, 1, 1, 1, 0, 3, False, True, degree_histogram(big), seed=2).eval()
+    mb, rb = hip_twin(copy.deepcopy(ob)), hip_twin(copy.deepcopy(ob))
+    rb.fused_readout = False
+    with torch.no_grad():
+        assert torch.equal(mb(big.to(DEV)), rb(big.to(DEV)))      # both take the per-op path
