@@ -642,6 +642,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
 
   // ---- readout: one launch (readout.hip) while its workgroups are co-resident, the per-op path beyond
   if (readout_fused_supported(g, h, d->num_para, p.nb) && !d->unfused_readout) {
+    GS_TRY(gnnsaft_add_pool(xc, I(p.graph_ptr), g, n, h, F(p.pooled), st));
     ReadoutFusedParams rp{};
     rp.x = xc;
     rp.graph_ptr = I(p.graph_ptr);

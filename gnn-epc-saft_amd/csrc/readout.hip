@@ -1,9 +1,9 @@
-// Readout of the PNAPCSAFT forward in ONE launch: global_add_pool -> [Linear -> BatchNorm1d -> ReLU] x (m + 2) ->
+// Readout MLP of the PNAPCSAFT forward in ONE launch (after k_add_pool): [Linear -> BatchNorm1d -> ReLU] x (m + 2) ->
 // Linear(H/4, P) -> MAPE  (/root/reference/gnnepcsaft/train/models.py:84-103,133-134,191-194).
 //
-// The per-op form (k_add_pool, 4 GEMM launches, 3 BatchNorm launches, k_mape) is 9 dependent launches of ~5 us each
+// The per-op form (4 GEMM launches, 3 BatchNorm launches, k_mape after k_add_pool) is 8 dependent launches of ~5 us each
 // for < 0.1 % of the step's FLOPs: 58 us of a 467 us step at BASELINE config 2.  Here a workgroup owns 64 graphs
-// (rows): it pools them, keeps the activations of all layers in LDS, runs the four small GEMMs on the matrix cores
+// (rows): it loads their pooled rows, keeps the activations of all layers in LDS, runs the four small GEMMs on the matrix cores
 // (v_mfma_f32_32x32x2_f32, weights straight from L2 -- they total < 100 KB -- in the k order of gemm.hip), and writes
 // the outputs.  Train-mode BatchNorm needs column statistics over ALL graphs: every workgroup publishes the (mean, M2)
 // of its 64 rows, the grid meets at a device-scope barrier (release / acquire atomics on a counter zeroed by the
@@ -17,7 +17,19 @@
 
 namespace gs {
 
-constexpr int kRdRows = 64;  // graphs per workgroup
+#ifdef GS_GF_TIMING   // development probe (make timing): wall-clock (100 MHz) stamps of workgroup 0
+__device__ long long g_rd_stamp[64];
+#define RD_STAMP(i)                                                                        \
+  do {                                                                                     \
+    __syncthreads();                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && (i) < 64) g_rd_stamp[(i)] = wall_clock64(); \
+  } while (0)
+#else
+#define RD_STAMP(i) do {} while (0)
+#endif
+
+constexpr int kRdRows = 64;      // graphs per workgroup
+constexpr int kRdThreads = 512;  // 8 waves: one 32 x 32 output tile each at n_out = 128
 constexpr int kRdPad = 4;    // floats of row padding in the LDS tiles
 
 struct ReadoutArgs {
@@ -59,14 +71,17 @@ __device__ __forceinline__ void grid_barrier(int32_t *counter, int expected, int
   __syncthreads();
 }
 
-// y[64][n_out] = a[64][n_in] (LDS) x W^T + bias : 32 x 32 output tiles round-robin over the 4 waves, k in the order
-// of gemm.hip (8 k per step, lane half h takes k0 + 4h .. k0 + 4h + 3)
+// y[64][n_out] = a[64][n_in] (LDS) x W^T + bias : 32 x 32 output tiles round-robin over the 8 waves, k in the order
+// of gemm.hip (8 k per step, lane half h takes k0 + 4h .. k0 + 4h + 3).  The weight fragments come straight from L2;
+// a wave issues the loads of a whole 128-wide K chunk (16 float4 per lane) before its first MFMA -- one exposed
+// round trip per chunk instead of one per step (measured: 84 us -> for the whole readout with a 1-deep prefetch).
 __device__ __forceinline__ void rd_gemm(const float *a, int lda, const float *__restrict__ w, const float *__restrict__ bias,
                                         int n_in, int n_out, float *y, int ldy) {
+  constexpr int kChunk = 128, kSteps = kChunk / 8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int col_tiles = (n_out + 31) >> 5;
-  for (int t = wave; t < 2 * col_tiles; t += 4) {
+  for (int t = wave; t < 2 * col_tiles; t += kRdThreads / 64) {
     const int rt = t & 1, ct = t >> 1;
     const int col = ct * 32 + l31;
     const int colc = col < n_out ? col : n_out - 1;
@@ -75,14 +90,22 @@ __device__ __forceinline__ void rd_gemm(const float *a, int lda, const float *__
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    f32x4 bn = gs_ld4(wp);
-    for (int k0 = 0; k0 < n_in; k0 += 8) {
-      const f32x4 bf = bn;
-      const int kn = k0 + 8 < n_in ? k0 + 8 : k0;   // prefetch the next step's weights (clamped at the end)
-      bn = gs_ld4(wp + kn);
-      const f32x4 af = gs_ld4(ap + k0);
+    for (int kc = 0; kc < n_in; kc += kChunk) {
+      f32x4 bf[kSteps];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc, 0, 0, 0);
+      for (int i = 0; i < kSteps; ++i) {
+        const int k0 = kc + 8 * i;
+        bf[i] = gs_ld4(wp + (k0 < n_in ? k0 : 0));   // past the end: any valid address, the step is skipped below
+      }
+#pragma unroll
+      for (int i = 0; i < kSteps; ++i) {
+        const int k0 = kc + 8 * i;
+        if (k0 < n_in) {                              // wave-uniform
+          const f32x4 af = gs_ld4(ap + k0);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[i][s], acc, 0, 0, 0);
+        }
+      }
     }
     const float bv = bias != nullptr ? bias[colc] : 0.f;
     if (col < n_out) {
@@ -95,7 +118,7 @@ __device__ __forceinline__ void rd_gemm(const float *a, int lda, const float *__
   }
 }
 
-__global__ __launch_bounds__(256) void k_readout_fused(ReadoutArgs a) {
+__global__ __launch_bounds__(kRdThreads) void k_readout_fused(ReadoutArgs a) {
   extern __shared__ __attribute__((aligned(16))) float rd_lds[];
   const int tid = threadIdx.x;
   const int h = a.h, ld = h + kRdPad;
@@ -103,76 +126,94 @@ __global__ __launch_bounds__(256) void k_readout_fused(ReadoutArgs a) {
   float *yt = at + kRdRows * ld;      // [64][ld] pre-BatchNorm output
   float *s_scale = yt + kRdRows * ld; // [H]
   float *s_shift = s_scale + h;       // [H]
-  float *s_red = s_shift + h;         // [4]
+  float *s_red = s_shift + h;         // [8]
+  double *s_d = reinterpret_cast<double *>(s_red + 8);   // [2][kRdThreads] doubles | [2][kRdThreads] floats + [H] pivots
+  float *s_f = reinterpret_cast<float *>(s_d);
   const int64_t row0 = (int64_t)blockIdx.x * kRdRows;
   const int rows = a.g - row0 < kRdRows ? (int)(a.g - row0) : kRdRows;   // >= 1
   const int nwg = gridDim.x;
 
-  // ---- global_add_pool: 64 graphs x H, float4 per thread, rows summed in node order
-  for (int idx = tid; idx < kRdRows * (h / 4); idx += 256) {
+  // ---- the pooled rows of this workgroup's graphs (k_add_pool ran as its own launch: one thread per (graph, float4)
+  //      keeps ~1e5 loads in flight over the whole chip; pooling here, 64 graphs per workgroup, was measured at 20 us
+  //      of pure load latency)
+  for (int idx = tid; idx < kRdRows * (h / 4); idx += kRdThreads) {
     const int r = idx / (h / 4), c = (idx - r * (h / 4)) * 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (r < rows) {
-      int64_t beg = a.graph_ptr[row0 + r], end = a.graph_ptr[row0 + r + 1];
-      beg = beg < 0 ? 0 : (beg > a.n ? a.n : beg);
-      end = end < beg ? beg : (end > a.n ? a.n : end);
-      int64_t i = beg;
-      for (; i + 4 <= end; i += 4) {
-        const f32x4 v0 = gs_ld4(a.x + (i + 0) * h + c), v1 = gs_ld4(a.x + (i + 1) * h + c);
-        const f32x4 v2 = gs_ld4(a.x + (i + 2) * h + c), v3 = gs_ld4(a.x + (i + 3) * h + c);
-        acc += v0;
-        acc += v1;
-        acc += v2;
-        acc += v3;
-      }
-      for (; i < end; ++i) acc += gs_ld4(a.x + i * h + c);
-      if (a.pooled != nullptr) gs_st4(a.pooled + (row0 + r) * h + c, acc);
-    }
-    gs_st4(at + r * ld + c, acc);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) v = gs_ld4(a.pooled + (row0 + r) * h + c);
+    gs_st4(at + r * ld + c, v);
   }
   __syncthreads();
 
   const int64_t rs = a.g * (int64_t)h;  // floats per tape block buffer
+  RD_STAMP(0);
   for (int b = 0; b < a.nblocks; ++b) {
     const int n_in = a.n_in[b], n_out = a.n_out[b];
     rd_gemm(at, ld, a.w[b], a.b[b], n_in, n_out, yt, ld);
     __syncthreads();
+    RD_STAMP(1 + 6 * b);
+    const int q = n_out >> 2;           // float4 per row (n_out is a multiple of 4: H, H/2, H/4 with H % 32 == 0)
     if (a.ry != nullptr)
-      for (int idx = tid; idx < rows * n_out; idx += 256) {
-        const int r = idx / n_out, c = idx - r * n_out;
-        a.ry[b * rs + (row0 + r) * n_out + c] = yt[r * ld + c];
+      for (int idx = tid; idx < rows * q; idx += kRdThreads) {
+        const int r = idx / q, c = (idx - r * q) * 4;
+        gs_st4(a.ry + b * rs + (row0 + r) * n_out + c, gs_ld4(yt + r * ld + c));
       }
+    // columns x row-slices: thread (c, part) of np2 x tpc
+    int np2 = 8;
+    while (np2 < n_out) np2 <<= 1;
+    const int tpc = kRdThreads / np2;
+    const int c = tid & (np2 - 1), part = tid / np2;
+    const bool col_ok = c < n_out;
     if (a.training) {
-      // (mean, M2) of this workgroup's rows per column, two passes over LDS
-      if (tid < n_out) {
-        float sum = 0.f;
-        for (int r = 0; r < rows; ++r) sum += yt[r * ld + tid];
-        const float mean = sum / (float)rows;
-        float m2 = 0.f;
-        for (int r = 0; r < rows; ++r) {
-          const float d = yt[r * ld + tid] - mean;
-          m2 += d * d;
+      // (mean, M2) of this workgroup's rows per column: one pass over d = y - y[row 0] (no cancellation), the
+      // row slices meet in LDS
+      {
+        const float p0 = col_ok ? yt[c] : 0.f;
+        float sd = 0.f, sd2 = 0.f;
+        if (col_ok)
+          for (int r = part; r < rows; r += tpc) {
+            const float d = yt[r * ld + c] - p0;
+            sd += d;
+            sd2 += d * d;
+          }
+        s_f[tid] = sd;
+        s_f[kRdThreads + tid] = sd2;
+        __syncthreads();
+        if (part == 0 && col_ok) {
+          for (int o = 1; o < tpc; ++o) {
+            sd += s_f[o * np2 + c];
+            sd2 += s_f[kRdThreads + o * np2 + c];
+          }
+          const float n_w = (float)rows;
+          float *p = a.part + ((int64_t)b * nwg + blockIdx.x) * 2 * h;
+          const float mean_w = p0 + sd / n_w;
+          p[c] = mean_w;
+          p[h + c] = fmaxf(sd2 - sd * sd / n_w, 0.f);
+          s_f[2 * kRdThreads + c] = mean_w;   // pivot of this workgroup's fold (behind the two reduction arrays)
         }
-        float *p = a.part + ((int64_t)b * nwg + blockIdx.x) * 2 * h;
-        p[tid] = mean;
-        p[h + tid] = m2;
       }
+      RD_STAMP(2 + 6 * b);
       grid_barrier(a.sync + b, nwg, a.err);
-      if (tid < n_out) {
+      RD_STAMP(3 + 6 * b);
+      {
+        // every workgroup folds all partials: S1 = sum n_w (mean_w - K), S2 = sum (M2_w + n_w (mean_w - K)^2) in f64
+        // around the pivot K = mean of workgroup 0 (bn_train.hip's scheme); partial slices per thread, LDS combine
+        // The pivot is this workgroup's OWN column mean (already here: no extra cross-XCD round trip, ~2 us each);
+        // any value near the mean serves, the f64 sums differ between workgroups by ~1e-16 relative.
         const float *p = a.part + (int64_t)b * nwg * 2 * h;
-        const double pivot = (double)p[tid];
+        const int cc = col_ok ? c : 0;
+        const double pivot = (double)s_f[2 * kRdThreads + cc];
         double s1 = 0.0, s2 = 0.0;
-        for (int w0 = 0; w0 < nwg; w0 += 8) {
+        for (int w0 = part; w0 < nwg; w0 += 8 * tpc) {
           float gm[8], g2[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int w = w0 + u < nwg ? w0 + u : nwg - 1;
-            gm[u] = __builtin_nontemporal_load(p + (int64_t)w * 2 * h + tid);
-            g2[u] = __builtin_nontemporal_load(p + (int64_t)w * 2 * h + h + tid);
+            const int w = w0 + u * tpc < nwg ? w0 + u * tpc : nwg - 1;
+            gm[u] = __builtin_nontemporal_load(p + (int64_t)w * 2 * h + cc);
+            g2[u] = __builtin_nontemporal_load(p + (int64_t)w * 2 * h + h + cc);
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int w = w0 + u;
+            const int w = w0 + u * tpc;
             if (w < nwg) {
               const int64_t left = a.g - (int64_t)w * kRdRows;
               const double gn = (double)(left < kRdRows ? left : kRdRows);
@@ -182,42 +223,59 @@ __global__ __launch_bounds__(256) void k_readout_fused(ReadoutArgs a) {
             }
           }
         }
-        const double nn = (double)a.g;
-        const double dmean = s1 / nn;
-        const double mean = pivot + dmean;
-        double m2 = s2 - nn * dmean * dmean;
-        m2 = m2 > 0.0 ? m2 : 0.0;
-        const float mean_f = (float)mean;
-        const float var_f = (float)(m2 / nn);
-        const float rstd = 1.f / sqrtf(var_f + a.eps);
-        const float sc = rstd * a.gamma[b][tid];
-        s_scale[tid] = sc;
-        s_shift[tid] = a.beta[b][tid] - mean_f * sc;
-        if (blockIdx.x == 0) {
-          if (a.rstat != nullptr) {
-            a.rstat[(int64_t)b * 2 * h + tid] = mean_f;           // layout of k_bn_train_apply: [mean | rstd] of n_out
-            a.rstat[(int64_t)b * 2 * h + n_out + tid] = rstd;
+        __syncthreads();   // s_f (aliases s_d) was read above
+        s_d[tid] = s1;
+        s_d[kRdThreads + tid] = s2;
+        __syncthreads();
+        if (part == 0 && col_ok) {
+          for (int o = 1; o < tpc; ++o) {
+            s1 += s_d[o * np2 + c];
+            s2 += s_d[kRdThreads + o * np2 + c];
           }
-          const float unbiased = (float)(nn > 1.0 ? m2 / (nn - 1.0) : m2);
-          a.rmean[b][tid] = (1.f - a.momentum) * a.rmean[b][tid] + a.momentum * mean_f;
-          a.rvar[b][tid] = (1.f - a.momentum) * a.rvar[b][tid] + a.momentum * unbiased;
-          if (tid == 0 && a.nbt[b] != nullptr) a.nbt[b][0] += 1;
+          const double nn = (double)a.g;
+          const double dmean = s1 / nn;
+          const double mean = pivot + dmean;
+          double m2 = s2 - nn * dmean * dmean;
+          m2 = m2 > 0.0 ? m2 : 0.0;
+          const float mean_f = (float)mean;
+          const float var_f = (float)(m2 / nn);
+          const float rstd = 1.f / sqrtf(var_f + a.eps);
+          const float sc = rstd * a.gamma[b][c];
+          s_scale[c] = sc;
+          s_shift[c] = a.beta[b][c] - mean_f * sc;
+          if (blockIdx.x == 0) {
+            if (a.rstat != nullptr) {
+              a.rstat[(int64_t)b * 2 * h + c] = mean_f;           // layout of k_bn_train_apply: [mean | rstd] of n_out
+              a.rstat[(int64_t)b * 2 * h + n_out + c] = rstd;
+            }
+            const float unbiased = (float)(nn > 1.0 ? m2 / (nn - 1.0) : m2);
+            a.rmean[b][c] = (1.f - a.momentum) * a.rmean[b][c] + a.momentum * mean_f;
+            a.rvar[b][c] = (1.f - a.momentum) * a.rvar[b][c] + a.momentum * unbiased;
+            if (c == 0 && a.nbt[b] != nullptr) a.nbt[b][0] += 1;
+          }
         }
       }
-    } else if (tid < n_out) {
-      const float rstd = 1.f / sqrtf(a.rvar[b][tid] + a.eps);
-      const float sc = rstd * a.gamma[b][tid];
-      s_scale[tid] = sc;
-      s_shift[tid] = a.beta[b][tid] - a.rmean[b][tid] * sc;
+    } else if (part == 0 && col_ok) {
+      const float rstd = 1.f / sqrtf(a.rvar[b][c] + a.eps);
+      const float sc = rstd * a.gamma[b][c];
+      s_scale[c] = sc;
+      s_shift[c] = a.beta[b][c] - a.rmean[b][c] * sc;
     }
     __syncthreads();
-    for (int idx = tid; idx < kRdRows * n_out; idx += 256) {
-      const int r = idx / n_out, c = idx - r * n_out;
-      const float v = fmaxf(yt[r * ld + c] * s_scale[c] + s_shift[c], 0.f);
-      at[r * ld + c] = v;
-      if (a.ro != nullptr && r < rows) a.ro[b * rs + (row0 + r) * n_out + c] = v;
+    RD_STAMP(4 + 6 * b);
+    for (int idx = tid; idx < kRdRows * q; idx += kRdThreads) {
+      const int r = idx / q, c4 = (idx - r * q) * 4;
+      const f32x4 sc = gs_ld4(s_scale + c4), sh = gs_ld4(s_shift + c4);
+      f32x4 v = gs_ld4(yt + r * ld + c4) * sc + sh;
+      v.x = fmaxf(v.x, 0.f);
+      v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f);
+      v.w = fmaxf(v.w, 0.f);
+      gs_st4(at + r * ld + c4, v);
+      if (a.ro != nullptr && r < rows) gs_st4(a.ro + b * rs + (row0 + r) * n_out + c4, v);
     }
     __syncthreads();
+    RD_STAMP(5 + 6 * b);
   }
   // ---- final Linear(H/4, P)
   {
@@ -225,7 +283,7 @@ __global__ __launch_bounds__(256) void k_readout_fused(ReadoutArgs a) {
     rd_gemm(at, ld, a.w[b], a.b[b], a.n_in[b], a.num_para, yt, ld);
     __syncthreads();
     float ape = 0.f;
-    for (int idx = tid; idx < rows * a.num_para; idx += 256) {
+    for (int idx = tid; idx < rows * a.num_para; idx += kRdThreads) {
       const int r = idx / a.num_para, c = idx - r * a.num_para;
       const float v = yt[r * ld + c];
       a.out[(row0 + r) * a.num_para + c] = v;
@@ -240,7 +298,9 @@ __global__ __launch_bounds__(256) void k_readout_fused(ReadoutArgs a) {
       if ((tid & 63) == 0) s_red[tid >> 6] = ape;
       __syncthreads();
       if (tid == 0) {
-        a.mape_part[blockIdx.x] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+        float wsum = 0.f;
+        for (int w = 0; w < kRdThreads / 64; ++w) wsum += s_red[w];
+        a.mape_part[blockIdx.x] = wsum;
         const int ticket = __hip_atomic_fetch_add(a.sync + a.nblocks, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (ticket == nwg - 1) {  // last workgroup: add the partials in workgroup order
           float tot = 0.f;
@@ -253,7 +313,14 @@ __global__ __launch_bounds__(256) void k_readout_fused(ReadoutArgs a) {
       }
     }
   }
+  RD_STAMP(60);
 }
+
+#ifdef GS_GF_TIMING
+extern "C" int gnnsaft_debug_readout_stamps(long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_rd_stamp), sizeof(long long) * 64);
+}
+#endif
 
 size_t readout_fused_scratch_bytes(int64_t g, int h, int nblocks) {
   const int64_t wgs = gs_ceil_div(g > 0 ? g : 1, (int64_t)kRdRows);
@@ -267,7 +334,7 @@ bool readout_fused_supported(int64_t g, int h, int num_para, int nblocks) {
 
 int launch_readout_fused(const ReadoutFusedParams &p, hipStream_t st) {
   GS_REQUIRE(readout_fused_supported(p.g, p.h, p.num_para, p.nblocks), GNNSAFT_ERR_UNSUPPORTED);
-  GS_REQUIRE(p.x && p.graph_ptr && p.out && p.scratch && p.sync, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(p.pooled && p.out && p.scratch && p.sync, GNNSAFT_ERR_NULL);
   GS_REQUIRE(!p.training || p.g >= 2, GNNSAFT_ERR_SHAPE);   // torch: "Expected more than 1 value per channel"
   ReadoutArgs a;
   a.x = p.x;
@@ -316,14 +383,15 @@ int launch_readout_fused(const ReadoutFusedParams &p, hipStream_t st) {
                                           gs_align_up((size_t)p.nblocks * wgs * 2 * p.h * 4, 256));
   a.sync = p.sync;
   a.err = p.err;
-  const size_t lds = ((size_t)2 * kRdRows * (p.h + kRdPad) + 2 * (size_t)p.h + 8) * sizeof(float);
+  const size_t lds = ((size_t)2 * kRdRows * (p.h + kRdPad) + 2 * (size_t)p.h + 8) * sizeof(float) +
+                     2 * (size_t)kRdThreads * sizeof(double);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_readout_fused),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_readout_fused, dim3((unsigned)wgs), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k_readout_fused, dim3((unsigned)wgs), dim3(kRdThreads), lds, st, a);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }

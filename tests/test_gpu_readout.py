@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import oracle_model, rel_err  # noqa: E402
+from helpers import check_population, oracle_model, rel_err  # noqa: E402
 from oracle.pna_torch import mape  # noqa: E402
 from test_gpu_forward import hip_twin  # noqa: E402
 
@@ -47,9 +47,15 @@ def test_fused_readout_equals_per_op_readout_and_oracle(hidden, mlp, num_para, g
     o64 = copy.deepcopy(oracle).double()
     with torch.no_grad():
         want = o64(data)
-    assert rel_err(p1, want) < (3e-5 if mode == "train" else 1e-5)
+        want32 = copy.deepcopy(oracle)(data)
+    if graphs >= 16:
+        check_population(p1, want32, want)        # std-threshold flips: judged against the f32 oracle's own figures
+    else:
+        assert rel_err(p1, want) < max(1e-5, 3 * rel_err(want32, want))
     assert abs(float(l1[0]) - float(mape(want, data.para.view(-1, num_para).double()))) < 1e-4 * float(l1[0])
     if mode == "train":
+        with torch.no_grad():
+            o64(data)                                      # the HIP module above saw the batch twice (run + forward)
         for k, v in o64.state_dict().items():
             if k.startswith("mlp") and "running_" in k:
                 assert rel_err(s1[k], v) < 1e-4, k
@@ -68,9 +74,10 @@ def test_fused_readout_feeds_the_backward_tape():
         m.fused_readout = fused
         mape_loss(m(dd), dd.para.view(-1, 3)).backward()
         grads[fused] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
-    for k in grads[True]:
-        scale = float(grads[False][k].abs().max())
-        assert float((grads[True][k] - grads[False][k]).abs().max()) <= 2e-5 * max(scale, 1e-6), k
+    gscale = max(float(v.abs().max()) for v in grads[False].values())
+    for k in grads[True]:     # biases in front of a train-mode BatchNorm have an exactly-zero gradient: global floor
+        scale = max(float(grads[False][k].abs().max()), 1e-4 * gscale)
+        assert float((grads[True][k] - grads[False][k]).abs().max()) <= 2e-5 * scale + 1e-7 * gscale, k
 
 
 def test_large_batches_take_the_per_op_readout_and_many_steps_reuse_the_counters():

@@ -11,7 +11,7 @@ ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name
 steps, cur = [], []
 for k in ks:
     cur.append(k)
-    if "k_mape" in k[2] and "bwd" not in k[2]:
+    if ("k_mape" in k[2] or "k_readout_fused" in k[2]) and "bwd" not in k[2]:
         steps.append(cur)
         cur = []
 if not steps:
