@@ -38,6 +38,19 @@ __global__ void k_pad_cols(const float *__restrict__ in, int64_t rows, int cols,
   out[i] = c < cols ? in[r * cols + c] : 0.f;
 }
 
+// gradients that are exactly zero by construction (biases in front of a train-mode BatchNorm: the normalisation
+// removes any per-column constant): written as zeros in one launch instead of a column-sum pass each
+constexpr int kMaxZeroList = 24;
+struct ZeroList {
+  float *p[kMaxZeroList];
+  int n[kMaxZeroList];
+};
+__global__ void k_fill_zero_list(ZeroList z) {
+  float *p = z.p[blockIdx.y];
+  const int n = z.n[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 __global__ void k_fill_zero(float *__restrict__ p, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0.f;
@@ -420,10 +433,13 @@ static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
   add((size_t)p.combos * 2 * h * 4);                     // dr
   add((size_t)p.combos * h * 4 * 2);                     // dcenc, dcemb
   add(1024 * 2 * h * 4);                                 // bn partials
-  add(h * h * 4 * 3);                                    // wlinT, wxT, weT
+  add(h * h * 4);                                        // wlinT (extra pre / post layers)
+  {
+    const size_t nlay = (size_t)(d->num_layers > 0 ? d->num_layers : 1);
+    add(nlay * 9 * h * h * 4);                           // per layer: wlinT | [wxT | wpqT] | wcT | weT
+    add((size_t)(d->num_mlp_layers + 2) * h * h * 4);    // readout: W^T of every BatchNorm block
+  }
   add((size_t)kDegreeBuckets * 2 * 4 * h * (h / 2) * 4); // wta
-  add(h * 4 * h * 4);                                    // wpqT
-  add(h * 2 * h * 4);                                    // wcT
   add((nn + 1) * 4);                                     // rowptr_s
   add(ee * 4);                                           // rows_s
   add((size_t)(p.combos + 1) * 4);                        // rowptr_c
@@ -495,11 +511,8 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   float *dr = sc.take<float>(C * 2 * h);
   float *dcenc = sc.take<float>(C * h), *dcemb = sc.take<float>(C * h);
   float *bnpart = sc.take<float>(1024 * 2 * h);
-  float *wlinT = sc.take<float>((size_t)h * h), *wxT = sc.take<float>((size_t)h * h),
-        *weT = sc.take<float>((size_t)h * h);
+  float *wlinT = sc.take<float>((size_t)h * h);
   float *wta = sc.take<float>((size_t)kDegreeBuckets * 2 * 4 * h * (h / 2));
-  float *wpqT = sc.take<float>((size_t)h * 4 * h);
-  float *wcT = sc.take<float>((size_t)h * 2 * h);
   int32_t *rowptr_s = sc.take<int32_t>(n + 1);
   int32_t *rows_s = sc.take<int32_t>(p.ep > 0 ? p.ep : 1);
   int32_t *rowptr_c = sc.take<int32_t>(C + 1);
@@ -510,7 +523,10 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   float *w3T = sc.take<float>((size_t)h * 8);
   const int vocab_pad = 192;
   float *det = sc.take<float>((size_t)h * vocab_pad);
-  GS_REQUIRE(det != nullptr, GNNSAFT_ERR_WORKSPACE);
+  const size_t per_layer_t = 9 * (size_t)h * h;      // wlinT [H][H] | wxpqT [H][5H] = [wxT | wpqT] | wcT [H][2H] | weT [H][H]
+  float *wt_layers = sc.take<float>((size_t)(L > 0 ? L : 1) * per_layer_t);
+  float *wt_readout = sc.take<float>((size_t)p.nb * h * h);
+  GS_REQUIRE(det != nullptr && wt_layers != nullptr && wt_readout != nullptr, GNNSAFT_ERR_WORKSPACE);
   const size_t slab_bytes = bs.slab;
 
   auto transpose1 = [&](const float *in, int64_t ld_in, float *out, int64_t ld_out, int rows, int cols) {
@@ -531,6 +547,67 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   const int nb = p.nb;
   const int64_t rs = g * (int64_t)h;
   GS_REQUIRE(P <= 8, GNNSAFT_ERR_UNSUPPORTED);
+  {  // biases in front of a train-mode BatchNorm (lin of every layer, every readout block): gradient exactly zero
+    ZeroList z;
+    int cnt = 0;
+    auto flush = [&]() {
+      if (cnt == 0) return;
+      for (int i = cnt; i < kMaxZeroList; ++i) {
+        z.p[i] = z.p[0];
+        z.n[i] = 0;
+      }
+      hipLaunchKernelGGL(k_fill_zero_list, dim3(2, (unsigned)cnt), dim3(256), 0, st, z);
+      cnt = 0;
+    };
+    auto push = [&](float *ptr, int count) {
+      if (ptr == nullptr) return;
+      z.p[cnt] = ptr;
+      z.n[cnt] = count;
+      if (++cnt == kMaxZeroList) flush();
+    };
+    for (int l = 0; l < L; ++l) {
+      const int i_lin = pw.layer_base[l] + 3 + 4 * d->pre_layers + 4 * d->post_layers;
+      push(G(i_lin + 1), h);
+    }
+    for (int bi = 0; bi < nb; ++bi) push(G(pw.readout_base[bi] + 1), pw.readout[bi].n_out);
+    flush();
+  }
+  {  // every weight transpose the dgrads of this backward need, in one launch (64 matrices per launch)
+    TransposeItem items[kMaxTransposeBatch];
+    int cnt = 0;
+    auto flush = [&]() -> int {
+      if (cnt == 0) return GNNSAFT_OK;
+      const int rc = launch_transpose_list(cnt, items, st);
+      cnt = 0;
+      return rc;
+    };
+    auto push = [&](const TransposeItem &it) -> int {
+      items[cnt++] = it;
+      return cnt == kMaxTransposeBatch ? flush() : GNNSAFT_OK;
+    };
+    const int64_t h3 = 3 * (int64_t)h, h13 = 13 * (int64_t)h, h5 = 5 * (int64_t)h, h2 = 2 * (int64_t)h;
+    for (int l = 0; l < L; ++l) {
+      const LayerW &w = pw.layers[l];
+      float *wl = wt_layers + (size_t)l * per_layer_t;
+      float *wlinT_l = wl, *wxpqT_l = wl + (size_t)h * h, *wcT_l = wl + 6 * (size_t)h * h, *weT_l = wl + 8 * (size_t)h * h;
+      // wxpqT[j][0:H] = [W_x,0 ; W_x,1]^T,  wxpqT[j][H + blk F + f] = W_pre,t[f][part F + j]  (blk = 2 part + t)
+      GS_TRY(push({w.wlin, wlinT_l, h, h, h, h}));
+      GS_TRY(push({w.wpost[0][0], wxpqT_l, h13, h5, h / 2, h}));
+      GS_TRY(push({w.wpost[1][0], wxpqT_l + h / 2, h13, h5, h / 2, h}));
+      GS_TRY(push({w.wpre[0][0], wxpqT_l + h, h3, h5, h, h}));
+      GS_TRY(push({w.wpre[1][0], wxpqT_l + 2 * h, h3, h5, h, h}));
+      GS_TRY(push({w.wpre[0][0] + h, wxpqT_l + 3 * h, h3, h5, h, h}));
+      GS_TRY(push({w.wpre[1][0] + h, wxpqT_l + 4 * h, h3, h5, h, h}));
+      GS_TRY(push({w.wpre[0][0] + 2 * h, wcT_l, h3, h2, h, h}));
+      GS_TRY(push({w.wpre[1][0] + 2 * h, wcT_l + h, h3, h2, h, h}));
+      GS_TRY(push({w.we, weT_l, h, h, h, h}));
+    }
+    for (int bi = 0; bi < nb; ++bi) {
+      const ReadoutW &rw = pw.readout[bi];
+      GS_TRY(push({rw.w, wt_readout + (size_t)bi * h * h, rw.n_in, rw.n_out, rw.n_out, rw.n_in}));  // [n_in][n_out]
+    }
+    GS_TRY(flush());
+  }
   {
     // final Linear(H/4 -> P): pad dOut to 8 columns so that the GEMMs can use 16-byte loads
     hipLaunchKernelGGL(k_pad_cols, dim3((unsigned)gs_ceil_div(g * 8, 256)), dim3(256), 0, st, grad_out, g, P, 8, dout_pad);
@@ -554,9 +631,8 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     GS_TRY(bn_relu_backward(yb, dcur, stat, rw.bn.gamma, rw.bn.beta, g, rw.n_out, G(ib + 2), G(ib + 3), dyr, bnpart, st));
     GS_TRY(launch_wgrad_plain(dyr, rw.n_out, in, rw.n_in, 0, g, rw.n_out, rw.n_in, G(ib), rw.n_in, 0, slabs, slab_bytes,
                               st));
-    GS_TRY(launch_colsum(dyr, rw.n_out, g, rw.n_out, G(ib + 1), 0, slabs, slab_bytes, st));
-    GS_TRY(transpose1(rw.w, rw.n_in, wlinT, rw.n_out, rw.n_out, rw.n_in));  // [n_in][n_out]
-    GS_TRY(dgrad(dyr, rw.n_out, wlinT, rw.n_out, dnext, rw.n_in, g, rw.n_in, rw.n_out, nullptr));
+    // (bias gradient: exactly zero, written above)
+    GS_TRY(dgrad(dyr, rw.n_out, wt_readout + (size_t)bi * h * h, rw.n_out, dnext, rw.n_in, g, rw.n_in, rw.n_out, nullptr));
     float *t = dcur;
     dcur = dnext;
     dnext = t;
@@ -594,31 +670,17 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     const float *rtab = F(p.rtab) + l * C * (int64_t)(2 * h);
     const float *cenc = F(p.cenc) + l * C * (int64_t)h;
 
-    // every weight transpose this layer's dgrads need, in one launch:
-    //   wlinT | wxT[j][t F/2 + o] = W_post,t[o][j] | wpqT[j][blk F + f] = W_pre,t[f][part F + j] |
-    //   wcT[j][t F + f] = W_pre,t[f][2F + j] | weT
-    {
-      const int64_t h3 = 3 * (int64_t)h, h13 = 13 * (int64_t)h, h4 = 4 * (int64_t)h, h2 = 2 * (int64_t)h;
-      const TransposeItem items[10] = {
-          {w.wlin, wlinT, h, h, h, h},
-          {w.wpost[0][0], wxT, h13, h, h / 2, h},
-          {w.wpost[1][0], wxT + h / 2, h13, h, h / 2, h},
-          {w.wpre[0][0], wpqT, h3, h4, h, h},
-          {w.wpre[1][0], wpqT + h, h3, h4, h, h},
-          {w.wpre[0][0] + h, wpqT + 2 * h, h3, h4, h, h},
-          {w.wpre[1][0] + h, wpqT + 3 * h, h3, h4, h, h},
-          {w.wpre[0][0] + 2 * h, wcT, h3, h2, h, h},
-          {w.wpre[1][0] + 2 * h, wcT + h, h3, h2, h, h},
-          {w.we, weT, h, h, h, h},
-      };
-      GS_TRY(launch_transpose_list(10, items, st));
-    }
+    // transposed weights of this layer (built by the one batched launch at the top):
+    //   wlinT | wxpqT[j][0:H] = W_post,t[o][j] (x block), wxpqT[j][H + blk F + f] = W_pre,t[f][part F + j] | wcT | weT
+    float *wl = wt_layers + (size_t)l * per_layer_t;
+    float *wlinT_l = wl, *wxpqT_l = wl + (size_t)h * h, *wcT_l = wl + 6 * (size_t)h * h, *weT_l = wl + 8 * (size_t)h * h;
+    const int64_t h5 = 5 * (int64_t)h;
     // x_{l+1} = relu(bn(y)) + x_l : dy through BN+ReLU; the skip gradient stays in dx
     GS_TRY(bn_relu_backward(y_l, dx, stat, w.bn.gamma, w.bn.beta, n, h, G(i_bn), G(i_bn + 1), dy, bnpart, st));
     // lin
     GS_TRY(launch_wgrad_plain(dy, h, u_l, h, 0, n, h, h, G(i_lin), h, 0, slabs, slab_bytes, st));
-    GS_TRY(launch_colsum(dy, h, n, h, G(i_lin + 1), 0, slabs, slab_bytes, st));
-    GS_TRY(dgrad(dy, h, wlinT, h, du, h, n, h, h, nullptr));
+    // (lin.bias sits in front of the BatchNorm: gradient exactly zero, written by the zero list)
+    GS_TRY(dgrad(dy, h, wlinT_l, h, du, h, n, h, h, nullptr));
     // extra post layers (Linear(F/2,F/2) after a ReLU, per tower), last to first: du_j -> du_{j-1}
     for (int j = q - 1; j >= 1; --j) {
       const float *u_prev = u_first + (int64_t)(j - 1) * n * h;  // pre-ReLU input of post layer j
@@ -651,7 +713,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     }
     // update dgrad, x part: dx_in = (skip ? dx : 0) + du [N,F] x [W_x,0 ; W_x,1]
     {
-      GS_TRY(dgrad(du, h, wxT, h, dx_other, h, n, h, h, d->skip_connections ? dx : nullptr));
+      GS_TRY(dgrad(du, h, wxpqT_l, h5, dx_other, h, n, h, h, d->skip_connections ? dx : nullptr));
     }
     // update dgrad, aggregate part (degree-tiled, scalers folded): dagg[i,t,:] = du_t[i] W_A,eff(d_i, t)
     {
@@ -715,7 +777,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     }
     // message GEMMs: dx_in += [dP | dQ] W_pq ; dW_dst,t / dW_src,t = dP_t^T x / dQ_t^T x
     {
-      GS_TRY(dgrad(dpq, 4 * (int64_t)h, wpqT, 4 * (int64_t)h, dx, h, n, h, 4 * h, dx_other));
+      GS_TRY(dgrad(dpq, 4 * (int64_t)h, wxpqT_l + h, h5, dx, h, n, h, 4 * h, dx_other));
       {  // dW_dst,t0 | dW_dst,t1 | dW_src,t0 | dW_src,t1 = dPQ^T x: one TN GEMM, four [F,F] blocks of two matrices
         float *blocks[4] = {G(i_pre0), G(i_pre1), G(i_pre0) + h, G(i_pre1) + h};
         GS_TRY(launch_wgrad_plain_blocks(dpq, 4 * (int64_t)h, x_l, h, n, 4, h, h, blocks, 3 * (int64_t)h, slabs,
@@ -733,10 +795,10 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       GS_TRY(launch_colsum_blocks(dr, 2 * (int64_t)h, C, 2, h, outs, slabs, slab_bytes, st));
     }
     {
-      GS_TRY(dgrad(dr, 2 * (int64_t)h, wcT, 2 * (int64_t)h, dcenc, h, C, h, 2 * h, nullptr));
+      GS_TRY(dgrad(dr, 2 * (int64_t)h, wcT_l, 2 * (int64_t)h, dcenc, h, C, h, 2 * h, nullptr));
       GS_TRY(launch_wgrad_plain(dcenc, h, F(p.cemb), h, 0, C, h, h, G(base + 1), h, 0, slabs, slab_bytes, st));
       GS_TRY(launch_colsum(dcenc, h, C, h, G(base + 2), 0, slabs, slab_bytes, st));
-      GS_TRY(dgrad(dcenc, h, weT, h, dcemb, h, C, h, h, dcemb));  // accumulate over layers (in place)
+      GS_TRY(dgrad(dcenc, h, weT_l, h, dcemb, h, C, h, h, dcemb));  // accumulate over layers (in place)
     }
     // dx now holds dL/dx_l; dx_other is free again
   }

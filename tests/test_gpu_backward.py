@@ -113,6 +113,11 @@ def test_parameter_gradients_match_oracle_autograd(cfg):
         assert torch.isfinite(p.grad).all(), name
         e_hip = err(p.grad, name)
         e_f32 = err(g32[name], name)
+        if float(g64[name].abs().max()) < 1e-6 * global_scale:
+            # exactly-zero gradient (a bias in front of a train-mode BatchNorm): what any f32 evaluation returns is
+            # rounding noise of the column sums; bound it absolutely instead of against the f32 oracle's noise
+            worst.append((float(p.grad.detach().abs().max()) / (2e-5 * global_scale), e_hip, e_f32, name))
+            continue
         worst.append((e_hip / max(3 * e_f32, 2e-5), e_hip, e_f32, name))
     worst.sort(reverse=True)
     for ratio, e_hip, e_f32, name in worst[:6]:
