@@ -63,9 +63,21 @@ struct TnOneHot {
 // Y_CLASS: the left operand is not a matrix but the one-hot encoding of an int32 class id per row
 // (`dy` reinterpreted): out[c][:] = sum of the A rows of class c, i.e. a segmented reduction by an arbitrary key on
 // the matrix cores, in the fixed summation order of the slab scheme (no atomics).
+// `direct` (single slab, i.e. few rows: edge classes, small batches): the tile goes straight to its destination
+// (SlabOut row blocks, leading dimension ld_out) -- no slab, no k_sum_slabs launch.
+struct SlabOut {
+  float *base[4];
+  int64_t rows_per_block;
+};
+struct TnDirect {
+  SlabOut so;
+  int64_t ld_out;
+  int on, accumulate;
+};
 template <class AProv, bool Y_CLASS>
 __global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dy, int64_t ldy, AProv ap, int64_t m,
-                                                 int n_out, int k, float *__restrict__ slabs, int64_t rows_per_z) {
+                                                 int n_out, int k, float *__restrict__ slabs, int64_t rows_per_z,
+                                                 TnDirect direct) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * kTnBK * kTnLd];  // [buf][dy | a][32][68]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -133,6 +145,18 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dy, i
   // C/D: col = lane & 31 (k), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (n)
   float *slab = slabs + (int64_t)blockIdx.z * n_out * (int64_t)k;
   const int kc = k0 + wk * 32 + (lane & 31);
+  if (direct.on) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int nr = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (nr < n_out && kc < k) {
+        const int64_t blk = nr / direct.so.rows_per_block;
+        float *o = direct.so.base[blk] + (nr - blk * direct.so.rows_per_block) * direct.ld_out + kc;
+        *o = direct.accumulate ? *o + acc[r] : acc[r];
+      }
+    }
+    return;
+  }
   if (n0 + kTnTile <= n_out && k0 + kTnTile <= k) {  // full tile: unguarded stores, issued back to back (gemm.hip)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -281,10 +305,6 @@ __global__ __launch_bounds__(256) void k_gemm_tn_postfold(TnFoldArgs a, float *_
 // out[i] (+)= sum over the slabs; 8 slab lanes per output float4, combined in a fixed order
 // The dense result [rows, cols] may be scattered by row blocks: block b = row / rows_per_block goes to base[b]
 // (several weight gradients that share one TN GEMM, e.g. the four [F,F] blocks of the message weights).
-struct SlabOut {
-  float *base[4];
-  int64_t rows_per_block;
-};
 __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ slabs, int64_t per_slab, int64_t chunks,
                                                    SlabOut so, int64_t ld_out, int cols, int accumulate,
                                                    int64_t slab_stride) {
@@ -447,10 +467,16 @@ static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, i
   chunks = gs_ceil_div(m, rows_per_z);
   GS_REQUIRE(slab_bytes >= (size_t)chunks * n_out * k * 4, GNNSAFT_ERR_WORKSPACE);
   const dim3 grid((unsigned)gs_ceil_div(k, kTnTile), (unsigned)gs_ceil_div(n_out, kTnTile), (unsigned)chunks);
-  hipLaunchKernelGGL((k_gemm_tn<AProv, Y_CLASS>), grid, dim3(256), 0, st, dy, ldy, ap, m, n_out, k, slabs, rows_per_z);
   const int64_t per_slab = (int64_t)n_out * k;
   SlabOut so{{out, out, out, out}, (int64_t)1 << 40};
   if (scatter != nullptr) so = *scatter;
+  TnDirect direct{so, ld_out, chunks == 1 ? 1 : 0, accumulate};
+  hipLaunchKernelGGL((k_gemm_tn<AProv, Y_CLASS>), grid, dim3(256), 0, st, dy, ldy, ap, m, n_out, k, slabs, rows_per_z,
+                     direct);
+  if (chunks == 1) {   // one slab: the GEMM wrote the result itself
+    GS_CHECK_LAUNCH();
+    return GNNSAFT_OK;
+  }
   hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)gs_ceil_div(per_slab / 4, 32)), dim3(256), 0, st, slabs, per_slab,
                      chunks, so, ld_out, k, accumulate, per_slab);
   GS_CHECK_LAUNCH();
