@@ -42,7 +42,7 @@ class WorkspaceMap(ctypes.Structure):
 
     _fields_ = [(n, c_size_t) for n in (
         "rowptr", "src", "dst", "combo", "log_amp", "log_att", "graph_ptr", "x_embed", "x_final", "pq", "agg", "u",
-        "y", "rtab", "pooled", "total")]
+        "y", "rtab", "pooled", "total", "ro", "x_stride")]
 
 
 P = c_void_p
@@ -100,7 +100,7 @@ SIGNATURES = {
     "gnnsaft_aux_destroy": (None, [P]),
     "gnnsaft_backward_scratch_bytes": (c_size_t, [POINTER(ModelDesc), c_int64, c_int64, c_int64]),
     "gnnsaft_backward": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), POINTER(c_void_p), c_int32, P, P, c_int64,
-                                   c_int64, c_int64, P, P, c_size_t, P, c_size_t, P]),
+                                   c_int64, c_int64, P, P, c_size_t, P, c_size_t, POINTER(c_void_p), P]),
     "gnnsaft_mape_backward": (c_int32, [P, P, c_int64, c_int32, P, P, P]),
     "gnnsaft_wgrad_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "gnnsaft_linear_wgrad": (c_int32, [P, c_int64, P, c_int64, c_int32, c_int64, c_int32, c_int32, P, c_int64, c_int32,

@@ -477,7 +477,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
                                 void *const *grads_host, int32_t num_weights, const int64_t *x_idx,
                                 const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
                                 const float *grad_out /* [G,P] */, void *tape, size_t tape_bytes, void *scratch,
-                                size_t scratch_bytes, gnnsaft_stream_t stream) {
+                                size_t scratch_bytes, void *const *segment_events, gnnsaft_stream_t stream) {
   (void)batch;
   GS_REQUIRE(d && weights_host && grads_host && grad_out && tape && scratch && x_idx, GNNSAFT_ERR_NULL);
   GS_REQUIRE(d->save_tape && d->training, GNNSAFT_ERR_UNSUPPORTED);
@@ -637,6 +637,14 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     dcur = dnext;
     dnext = t;
   }
+  // gradient segments complete in the order readout, layer L-1 .. 0, embeddings: an event per segment lets the
+  // data-parallel exchange of a finished segment run under the rest of the backward (parallel.py)
+  auto segment_done = [&](int i) -> int {
+    if (segment_events != nullptr && segment_events[i] != nullptr)
+      GS_HIP(hipEventRecord(static_cast<hipEvent_t>(segment_events[i]), st));
+    return GNNSAFT_OK;
+  };
+  GS_TRY(segment_done(0));
   // pool backward: dx_L
   float *dx = dxa, *dx_other = dxb;
   hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)gs_ceil_div(g * (h / 4), 256)), dim3(256), 0, st, dcur,
@@ -801,6 +809,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       GS_TRY(dgrad(dcenc, h, weT_l, h, dcemb, h, C, h, h, dcemb));  // accumulate over layers (in place)
     }
     // dx now holds dL/dx_l; dx_other is free again
+    GS_TRY(segment_done(1 + (L - 1 - l)));
   }
 
   // =========================== embeddings ===========================
@@ -833,5 +842,6 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
                        vocab_pad, h, tg, total);
   }
   GS_CHECK_LAUNCH();
+  GS_TRY(segment_done(L + 1));
   return GNNSAFT_OK;
 }

@@ -317,6 +317,8 @@ extern "C" int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int
   map->rtab = p.rtab;
   map->pooled = p.pooled;
   map->total = p.total;
+  map->ro = p.ro;
+  map->x_stride = (size_t)p.sx * 4;
   return GNNSAFT_OK;
 }
 

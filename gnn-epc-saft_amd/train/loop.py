@@ -19,7 +19,7 @@ from typing import Callable, Iterable, List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-from ..parallel import allreduce_flat_sum
+from ..parallel import OverlappedGradientExchange, allreduce_flat_sum, common_gradient_buffer
 from .checkpoint import lightning_checkpoint, resume, save_checkpoint
 from .models import PNApcsaftL, _cfg
 
@@ -78,7 +78,8 @@ def broadcast_training_state(lit: PNApcsaftL, optimizer, scheduler, step: int, s
 def training_loop(lit: PNApcsaftL, batches: Iterable, max_steps: Optional[int] = None, *,
                   log_every_steps: Optional[int] = None, checkpoint_every_steps: Optional[int] = None,
                   workdir: Optional[str] = None, resume_from=None,
-                  on_log: Optional[Callable[[int, float, float], None]] = None) -> List[Tuple[int, float]]:
+                  on_log: Optional[Callable[[int, float, float], None]] = None,
+                  overlap_gradient_exchange: bool = False) -> List[Tuple[int, float]]:
     """Runs ``max_steps`` (default ``config.num_train_steps``) training steps over ``batches`` (any re-iterable of
     device-resident PyG-like batches with ``para``; iterated again when exhausted, i.e. epochs) and returns the
     logged ``(step, train_mape)`` pairs.  Rank 0 writes Lightning-dialect checkpoints under
@@ -99,6 +100,9 @@ def training_loop(lit: PNApcsaftL, batches: Iterable, max_steps: Optional[int] =
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = _world()
     step = broadcast_training_state(lit, opt, sched, step)
+    # world > 1, opt-in: all-reduce every finished gradient segment under the rest of the backward (needs the
+    # gradients in backward's own flat buffer, i.e. no frozen parameters; otherwise the single flat all-reduce)
+    exchange = OverlappedGradientExchange(lit.model) if (overlap_gradient_exchange and world > 1) else None
     history: List[Tuple[int, float]] = []
     epoch = 0
     while step < max_steps:
@@ -110,7 +114,12 @@ def training_loop(lit: PNApcsaftL, batches: Iterable, max_steps: Optional[int] =
             opt.zero_grad(set_to_none=True)
             loss = lit.training_step(batch, seen - 1)
             loss.backward()
-            allreduce_gradients(opt)
+            flat = common_gradient_buffer(opt._params) if exchange is not None else None
+            if flat is not None and flat.numel() >= opt._total:
+                opt.use_reduced_gradient(flat, exchange.launch(flat))
+                exchange.wait()
+            else:
+                allreduce_gradients(opt)
             opt.step()
             sched.step()
             step += 1
@@ -134,6 +143,8 @@ def training_loop(lit: PNApcsaftL, batches: Iterable, max_steps: Optional[int] =
         if seen == 0:
             raise ValueError("training_loop got an empty batch iterable")
         epoch += 1
+    if exchange is not None:
+        exchange.close()
     return history
 
 

@@ -183,6 +183,8 @@ class PNAPCSAFT(nn.Module):
         self._eval_pack = None      # (key, packed weights): BatchNorm-folded, transposed; rebuilt when weights change
         self._pack_generation = 0   # bumped by whoever rewrites parameters behind torch's version counters
         self._graph_ws: Optional[torch.Tensor] = None
+        self.gradient_segment_events = None   # L + 2 torch.cuda.Event: recorded by gnnsaft_backward per finished segment
+        self._last_flat_grad: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ host glue
     def _weight_tensors(self) -> List[torch.Tensor]:
@@ -454,13 +456,38 @@ class PNAPCSAFT(nn.Module):
         sp = (scratch.data_ptr() + 255) // 256 * 256
         grad_out = grad_out.to(torch.float32).contiguous()
         stream = torch.cuda.current_stream(dev).cuda_stream
+        events = None
+        if self.gradient_segment_events is not None:   # set by parallel.OverlappedGradientExchange
+            evs = self.gradient_segment_events
+            if len(evs) != desc.num_layers + 2:
+                raise ValueError("gradient_segment_events must hold num_layers + 2 events")
+            events = (ctypes.c_void_p * len(evs))(*[e.cuda_event for e in evs])
         with torch.cuda.device(dev):
             rc = lib.gnnsaft_backward(ctypes.byref(desc), wtab, gtab, nw, ctx["x"].data_ptr(),
                                       None if ctx["batch"] is None else ctx["batch"].data_ptr(), ctx["n"], ctx["e"],
                                       ctx["g"], grad_out.data_ptr(), ctx["ws_ptr"], ctx["ws_bytes"], sp,
-                                      scratch.numel() - (sp - scratch.data_ptr()), stream)
+                                      scratch.numel() - (sp - scratch.data_ptr()), events, stream)
         check(rc, "gnnsaft_backward")
+        self._last_flat_grad = flat
         return grads
+
+    def gradient_segments(self):
+        """``[(start, end)]`` float offsets into the flat gradient buffer (``flat_layout``), in the order
+        ``gnnsaft_backward`` completes them: readout, layer L-1 .. layer 0, embeddings."""
+        params, offsets, total = self.flat_layout()
+        n_embed = len(self.node_embed.tables()) + len(self.edge_embed.tables())
+        per_layer = []
+        idx = n_embed
+        for conv in self.convs:
+            k = sum(1 for _ in conv.parameters()) + 2            # + BatchNorm weight, bias
+            per_layer.append((idx, idx + k))
+            idx += k
+        bounds = offsets + [total]
+        segs = [(bounds[idx], total)]                               # readout
+        for a, b in reversed(per_layer):
+            segs.append((bounds[a], bounds[b]))
+        segs.append((0, bounds[n_embed]))                           # embeddings
+        return segs
 
     @torch.no_grad()
     def build_structure(self, data) -> torch.Tensor:

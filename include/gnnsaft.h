@@ -377,6 +377,11 @@ int gnnsaft_structure_build(const gnnsaft_model_desc *desc, const int64_t *edge_
 /* entries of buffers -- avg_deg_log, running statistics, counters -- are       */
 /* ignored and may be NULL) given grad_out = dL/d(forward output) [G,P].        */
 /* Supported: 1 <= pre_layers, post_layers <= 8, hidden % 64 == 0.              */
+/* `segment_events` (HOST array of num_layers + 2 hipEvent_t, or NULL): the      */
+/* gradients complete in the order readout, layer L-1 .. layer 0, embeddings     */
+/* (contiguous segments of the canonical weight order); event i is recorded on   */
+/* `stream` when segment i is complete, so that a data-parallel caller can        */
+/* all-reduce it on another stream under the remaining backward kernels.         */
 /* ------------------------------------------------------------------------ */
 size_t gnnsaft_backward_scratch_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes,
                                       int64_t num_edges, int64_t num_graphs);
@@ -384,7 +389,7 @@ int gnnsaft_backward(const gnnsaft_model_desc *desc, const void *const *weights_
                      void *const *grads_host, int32_t num_weights, const int64_t *x,
                      const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
                      const float *grad_out, void *tape, size_t tape_bytes, void *scratch,
-                     size_t scratch_bytes, gnnsaft_stream_t stream);
+                     size_t scratch_bytes, void *const *segment_events, gnnsaft_stream_t stream);
 /* d(MAPE)/d(pred) * dloss[0] (dloss NULL => 1): sign(p-t) / max(|t|,1.17e-6) / (G*P) */
 int gnnsaft_mape_backward(const float *pred, const float *target, int64_t num_graphs,
                           int32_t num_para, const float *dloss, float *dpred,
@@ -433,6 +438,8 @@ typedef struct gnnsaft_workspace_map {
   size_t x_final;   /* [N,H] node state after the last layer                   */
   size_t pq, agg, u, y, rtab, pooled;
   size_t total;
+  size_t ro;        /* [num_mlp_layers + 2][G, n_out] outputs of the readout's BatchNorm + ReLU blocks (block stride G*H) */
+  size_t x_stride;  /* tape (save_tape): x_0 .. x_L contiguous from x_embed, x_stride BYTES apart; 0 without a tape */
 } gnnsaft_workspace_map;
 
 int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int64_t num_nodes,

@@ -28,23 +28,30 @@ CFG = dict(propagation_depth=2, hidden_dim=64, pre_layers=1, post_layers=1, num_
 FROZEN = "model.node_embed.atom_embedding_list.3.weight"
 
 
-def build(seed, graphs):
+def build(seed, graphs, frozen=True):
     torch.manual_seed(seed)
     lit = G.create_model(CFG, degree_histogram(graphs)).to("cuda:0")
-    dict(lit.named_parameters())[FROZEN].requires_grad_(False)
+    if frozen:
+        dict(lit.named_parameters())[FROZEN].requires_grad_(False)
     return lit
 
 
 def main():
     out_dir = sys.argv[1]
-    rank, _, world = parallel.init_from_env("gloo")
+    overlap = len(sys.argv) > 2 and sys.argv[2] == "overlap"   # segment-wise exchange under the backward: no frozen
+    rank, _, world = parallel.init_from_env("gloo")            # parameter, so the gradients sit in backward's buffer
     assert world == 2 and dist.get_backend() == "gloo"
     torch.cuda.set_device(0)
     graphs = synthetic_dataset(96, 31, num_para=3)
-    lit = build(100 + rank, graphs)                       # ranks start from different weights on purpose
+    lit = build(100 + rank, graphs, frozen=not overlap)   # ranks start from different weights on purpose
     loader = GraphLoader(graphs, 24, shuffle=False, device="cuda:0", rank=rank, world_size=world)
     assert len(loader) == 2
-    hist = training_loop(lit, loader)                      # 2 steps: broadcast, forward, backward, all-reduce, step
+    hist = training_loop(lit, loader, overlap_gradient_exchange=overlap)   # 2 steps: broadcast, fwd, bwd, all-reduce, step
+    if overlap:
+        segs = lit.model.gradient_segments()
+        total = lit.model.flat_layout()[2]
+        assert sorted(segs)[0][0] == 0 and max(b for _, b in segs) == total and len(segs) == CFG["propagation_depth"] + 2
+        assert sum(b - a for a, b in segs) == total
     # eval-mode global MAPE over all 96 graphs from the per-rank [sum(ape), count] pairs
     lit.eval()
     parts = torch.zeros(3, device="cuda:0")

@@ -109,6 +109,134 @@ def tape_std_masks(pred: torch.Tensor):
     return [(a[..., 3 * h:] > 0).cpu() for a in agg.view(layers, n, 2, 4 * h)]
 
 
+def oracle_decisions(model: torch.nn.Module, data, skip: bool):
+    """The discrete decisions of one oracle evaluation (train mode, no grad): per layer the std mask and the ReLU
+    gate of the node update, then the ReLU gates of the readout blocks.  Returns (stages, decisions)."""
+    stages: Dict[str, torch.Tensor] = {}
+    gates = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: gates.append(out.detach() > 0))
+             for m in model.mlp.modules() if isinstance(m, torch.nn.ReLU)]
+    try:
+        with torch.no_grad():
+            model(data, stages)
+    finally:
+        for hk in hooks:
+            hk.remove()
+    dec = []
+    layer, prev = 0, stages["embed"]
+    while f"l{layer}.agg" in stages:
+        a = stages[f"l{layer}.agg"]
+        f = a.shape[-1] // 4
+        dec.append(a[..., 3 * f:] > 0)
+        out = stages[f"l{layer}.out"]
+        dec.append(((out - prev) if skip else out) > 0)
+        prev = out
+        layer += 1
+    return stages, dec + gates
+
+
+def tape_decisions(pred: torch.Tensor, skip: bool):
+    """The same list of decisions as ``oracle_decisions``, read from the tape of the HIP forward behind ``pred``
+    (std masks from the aggregates, node ReLU gates from x_{l+1} - x_l, readout gates from the block outputs)."""
+    import ctypes
+
+    from gnn_epc_saft_amd._native import WorkspaceMap, lib
+    tape = pred.grad_fn.tape
+    desc, n, e, g = tape["desc"], tape["n"], tape["e"], tape["g"]
+    wmap = WorkspaceMap()
+    assert lib.gnnsaft_forward_workspace_map(ctypes.byref(desc), n, e, g, ctypes.byref(wmap)) == 0
+    base = tape["ws_ptr"] - tape["ws"].data_ptr()
+    h, layers = desc.hidden, desc.num_layers
+
+    def tap(off, count):
+        return tape["ws"][base + off: base + off + 4 * count].view(torch.float32)
+
+    agg = tap(wmap.agg, layers * n * 8 * h).view(layers, n, 2, 4 * h)
+    xs = tap(wmap.x_embed, (layers + 1) * n * h).view(layers + 1, n, h)
+    dec = []
+    for layer in range(layers):
+        dec.append((agg[layer][..., 3 * h:] > 0).cpu())
+        dec.append((((xs[layer + 1] - xs[layer]) if skip else xs[layer + 1]) > 0).cpu())
+    widths = [h] * desc.num_mlp_layers + [h // 2, h // 4]
+    for b, w in enumerate(widths):
+        dec.append((tap(wmap.ro + 4 * b * g * h, g * w).view(g, w) > 0).cpu())
+    return dec
+
+
+def _csr_order(data, loops: bool):
+    """Permutation of the oracle's edge list (real edges, then the appended self-loops) into the HIP path's CSR row
+    order: by destination, edge-list order inside a destination, self-loop last."""
+    n = data.x.shape[0]
+    dst = data.edge_index[1]
+    if loops:
+        dst = torch.cat([dst, torch.arange(n)])
+    return torch.argsort(dst, stable=True), dst
+
+
+def oracle_routing(stages, data, loops: bool):
+    """Per layer, which message rows attain the min / the max of their segment ([E', T*F] bool, CSR row order): the
+    routing of the min / max aggregators' gradient."""
+    order, dst = _csr_order(data, loops)
+    out, layer = [], 0
+    n = data.x.shape[0]
+    while f"l{layer}.msgs" in stages:
+        m = stages[f"l{layer}.msgs"]
+        m = m.reshape(m.shape[0], -1)[order]
+        seg = dst[order].view(-1, 1).expand_as(m)
+        for red in ("amin", "amax"):
+            ext = torch.zeros((n, m.shape[1]), dtype=m.dtype).scatter_reduce_(0, seg, m, reduce=red, include_self=False)
+            out.append(m == ext.gather(0, seg))
+        layer += 1
+    return out
+
+
+def tape_routing(pred: torch.Tensor):
+    """The same masks for the taped HIP forward (pre_layers == 1): the float32 messages are recomputed on the CPU from
+    the tape exactly as k_pna_aggregate / k_agg_bwd form them, (P[dst] + Q[src]) + R[class], in CSR row order."""
+    import ctypes
+
+    from gnn_epc_saft_amd._native import WorkspaceMap, lib
+    tape = pred.grad_fn.tape
+    desc, n, e, g = tape["desc"], tape["n"], tape["e"], tape["g"]
+    assert desc.pre_layers == 1
+    wmap = WorkspaceMap()
+    assert lib.gnnsaft_forward_workspace_map(ctypes.byref(desc), n, e, g, ctypes.byref(wmap)) == 0
+    base = tape["ws_ptr"] - tape["ws"].data_ptr()
+    h, layers = desc.hidden, desc.num_layers
+    ep = e + (n if desc.self_loops else 0)
+    combos = 1
+    for k in range(desc.num_bond_cols):
+        combos *= desc.bond_dims[k]
+
+    def tap(off, count, dtype):
+        return tape["ws"][base + off: base + off + 4 * count].view(dtype).cpu()
+
+    rowptr = tap(wmap.rowptr, n + 1, torch.int32).long()
+    src = tap(wmap.src, ep, torch.int32).long()
+    combo = tap(wmap.combo, ep, torch.int32).long()
+    dst = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+    pq = tap(wmap.pq, layers * n * 4 * h, torch.float32).view(layers, n, 4 * h)
+    rtab = tap(wmap.rtab, layers * combos * 2 * h, torch.float32).view(layers, combos, 2 * h)
+    out = []
+    for layer in range(layers):
+        m = (pq[layer][dst, :2 * h] + pq[layer][src, 2 * h:]) + rtab[layer][combo]
+        seg = dst.view(-1, 1).expand_as(m)
+        for red in ("amin", "amax"):
+            ext = torch.zeros((n, 2 * h)).scatter_reduce_(0, seg, m, reduce=red, include_self=False)
+            out.append(m == ext.gather(0, seg))
+    return out
+
+
+def decisions_agree(a, b) -> bool:
+    """Every discrete decision (std mask, ReLU gate, min / max routing) taken alike.  A gradient comparison is well
+    defined only between evaluations that agree here: one std entry masked differently moves a row of the layer's
+    message weights by ~1e-3 (1/std = 316 at the threshold), one ReLU gate flipped or one min / max gradient routed
+    to the other of two nearly tied messages moves a row of a weight gradient by ~1/N of its scale (1e-2 on a 24..64
+    graph batch; at f32 resolution a 64-graph H=128 batch holds a few such near-ties per layer) --
+    tests/analysis_gradient_flips_gpu.py."""
+    return len(a) == len(b) and all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(a, b))
+
+
 def std_masks_agree(stages_or_masks, stages64: Dict[str, torch.Tensor]) -> bool:
     """PyG's StdAggregation zeroes std where var <= 1e-5: a discrete decision per (node, tower, feature).  True when
     an evaluation (oracle ``stages`` dict, or the list ``tape_std_masks`` returns) took every one of them like the

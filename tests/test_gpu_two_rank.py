@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 
 
-def test_two_processes_on_one_gpu_match_a_single_process_replay(tmp_path):
+@pytest.mark.parametrize("overlap", [False, True], ids=["flat-allreduce", "segment-overlap"])
+def test_two_processes_on_one_gpu_match_a_single_process_replay(tmp_path, overlap):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gloo_hip_worker as W
     from gnn_epc_saft_amd.data.loader import GraphLoader
@@ -27,7 +28,7 @@ def test_two_processes_on_one_gpu_match_a_single_process_replay(tmp_path):
         port = s.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT)
     worker = os.path.join(ROOT, "tests", "gloo_hip_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(tmp_path)],
+    procs = [subprocess.Popen([sys.executable, worker, str(tmp_path)] + (["overlap"] if overlap else []),
                               env=dict(env, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2"),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=420)[0] for p in procs]
@@ -37,7 +38,7 @@ def test_two_processes_on_one_gpu_match_a_single_process_replay(tmp_path):
 
     # ---- single-process replay: both replicas start from rank 0's weights (seed 100), own BatchNorm buffers
     graphs = synthetic_dataset(96, 31, num_para=3)
-    reps = [W.build(100, graphs) for _ in range(2)]
+    reps = [W.build(100, graphs, frozen=not overlap) for _ in range(2)]
     confs = [m.configure_optimizers() for m in reps]
     shards = [list(GraphLoader(graphs, 24, shuffle=False, device=DEV, rank=r, world_size=2)) for r in range(2)]
     logged = []
@@ -68,7 +69,8 @@ def test_two_processes_on_one_gpu_match_a_single_process_replay(tmp_path):
     names = dict(reps[0].named_parameters())
     assert all(torch.equal(got[0]["state"][k], got[1]["state"][k]) for k in names)
     assert any(not torch.equal(got[0]["state"][k], got[1]["state"][k]) for k in got[0]["state"] if "running_mean" in k)
-    assert torch.equal(got[0]["state"][W.FROZEN], {k: v for k, v in W.build(100, graphs).state_dict().items()}[W.FROZEN].cpu())
+    if not overlap:
+        assert torch.equal(got[0]["state"][W.FROZEN], W.build(100, graphs).state_dict()[W.FROZEN].cpu())
     # global MAPE from the two ranks' [sum(ape), count] == one process over all 96 graphs (eval mode: rank 0's model)
     assert got[0]["global_mape"] == got[1]["global_mape"]
     reps[0].eval()
