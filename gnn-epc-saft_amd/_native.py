@@ -100,7 +100,7 @@ SIGNATURES = {
     "gnnsaft_aux_destroy": (None, [P]),
     "gnnsaft_backward_scratch_bytes": (c_size_t, [POINTER(ModelDesc), c_int64, c_int64, c_int64]),
     "gnnsaft_backward": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), POINTER(c_void_p), c_int32, P, P, c_int64,
-                                   c_int64, c_int64, P, P, c_size_t, P, c_size_t, POINTER(c_void_p), P]),
+                                   c_int64, c_int64, P, P, c_size_t, P, c_size_t, POINTER(c_void_p), P, P]),
     "gnnsaft_mape_backward": (c_int32, [P, P, c_int64, c_int32, P, P, P]),
     "gnnsaft_wgrad_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "gnnsaft_linear_wgrad": (c_int32, [P, c_int64, P, c_int64, c_int32, c_int64, c_int32, c_int32, P, c_int64, c_int32,
@@ -131,8 +131,8 @@ def _load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gnnsaft_abi_version() != 2:
-        raise ImportError(f"{LIB_PATH}: ABI version {lib.gnnsaft_abi_version()} != 2; rebuild the library")
+    if lib.gnnsaft_abi_version() != 3:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.gnnsaft_abi_version()} != 3; rebuild the library")
     return lib
 
 

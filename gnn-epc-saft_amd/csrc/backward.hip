@@ -423,14 +423,17 @@ static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
   size_t tot = 0;
   auto add = [&](size_t b) { tot += gs_align_up(b, 256); };
   add(slab);
+  const size_t nlay_b = (size_t)(d->num_layers > 0 ? d->num_layers : 1);
   for (int i = 0; i < 2; ++i) add(nn * h * 4);          // dxa, dxb
-  add(nn * h * 4);                                       // dy
-  add(nn * h * 4);                                       // du
+  // every layer keeps its own dy / du / dm / dpq / dr: the side stream reads them (weight gradients, class sums)
+  // while the main stream is already in the next layer
+  add(nlay_b * nn * h * 4);                              // dy
+  add(nlay_b * nn * h * 4);                              // du
   add(nn * 8 * h * 4);                                   // dagg
-  add(ee * 2 * h * 4);                                   // dm
+  add(nlay_b * ee * 2 * h * 4);                          // dm
   if (d->pre_layers > 1) add(ee * 2 * h * 4);            // dm2
-  add(nn * 4 * h * 4);                                   // dpq
-  add((size_t)p.combos * 2 * h * 4);                     // dr
+  add(nlay_b * nn * 4 * h * 4);                          // dpq
+  add(nlay_b * (size_t)p.combos * 2 * h * 4);            // dr
   add((size_t)p.combos * h * 4 * 2);                     // dcenc, dcemb
   add(1024 * 2 * h * 4);                                 // bn partials
   add(h * h * 4);                                        // wlinT (extra pre / post layers)
@@ -439,7 +442,7 @@ static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
     add(nlay * 9 * h * h * 4);                           // per layer: wlinT | [wxT | wpqT] | wcT | weT
     add((size_t)(d->num_mlp_layers + 2) * h * h * 4);    // readout: W^T of every BatchNorm block
   }
-  add((size_t)kDegreeBuckets * 2 * 4 * h * (h / 2) * 4); // wta
+  add(nlay_b * (size_t)kDegreeBuckets * 2 * 4 * h * (h / 2) * 4); // wta, per layer
   add((nn + 1) * 4);                                     // rowptr_s
   add(ee * 4);                                           // rows_s
   add((size_t)(p.combos + 1) * 4);                        // rowptr_c
@@ -477,7 +480,8 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
                                 void *const *grads_host, int32_t num_weights, const int64_t *x_idx,
                                 const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
                                 const float *grad_out /* [G,P] */, void *tape, size_t tape_bytes, void *scratch,
-                                size_t scratch_bytes, void *const *segment_events, gnnsaft_stream_t stream) {
+                                size_t scratch_bytes, void *const *segment_events, gnnsaft_aux *aux,
+                                gnnsaft_stream_t stream) {
   (void)batch;
   GS_REQUIRE(d && weights_host && grads_host && grad_out && tape && scratch && x_idx, GNNSAFT_ERR_NULL);
   GS_REQUIRE(d->save_tape && d->training, GNNSAFT_ERR_UNSUPPORTED);
@@ -499,24 +503,60 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   const int h = d->hidden, P = d->num_para, L = d->num_layers;
   const int64_t n = num_nodes, g = num_graphs;
   const int64_t C = p.combos;
+  const int q = d->post_layers, pl = d->pre_layers;
 
+  // Two branches.  The MAIN stream carries the chain every layer's input gradient depends on (BatchNorm backward ->
+  // lin dgrad -> update dgrads -> aggregation backward -> gather by source -> message dgrad); the SIDE stream
+  // (aux->stream) everything that only consumes that chain: weight and bias gradients, the per-edge-class sums and
+  // the edge-table chain, plus the one-off preparation (transposed CSR, folded transposed update weights).  Each of
+  // these kernels alone leaves most of the 256 CUs idle (a few hundred short workgroups), so the two streams
+  // overlap almost completely.  Layers keep their own dy / du / dm / dpq / dr so that the side stream may lag.
+  // Extra pre / post layers reuse buffers within a layer: they run single-stream.
+  const bool two = aux != nullptr && aux->stream != nullptr && pl == 1 && q == 1;
+  hipStream_t sa = two ? aux->stream : st;
+  size_t next_event = 0;
+  // `to` waits for everything enqueued on `from` so far
+  auto order = [&](hipStream_t from, hipStream_t to) -> int {
+    if (from == to) return GNNSAFT_OK;
+    hipEvent_t e = aux_event(aux, next_event++);
+    GS_REQUIRE(e != nullptr, GNNSAFT_ERR_WORKSPACE);
+    GS_HIP(hipEventRecord(e, from));
+    GS_HIP(hipStreamWaitEvent(to, e, 0));
+    return GNNSAFT_OK;
+  };
+  auto mark = [&](hipStream_t from, hipEvent_t &e) -> int {   // ... or wait later (`await`)
+    e = nullptr;
+    if (!two) return GNNSAFT_OK;
+    e = aux_event(aux, next_event++);
+    GS_REQUIRE(e != nullptr, GNNSAFT_ERR_WORKSPACE);
+    GS_HIP(hipEventRecord(e, from));
+    return GNNSAFT_OK;
+  };
+  auto await = [&](hipStream_t to, hipEvent_t e) -> int {
+    if (e != nullptr) GS_HIP(hipStreamWaitEvent(to, e, 0));
+    return GNNSAFT_OK;
+  };
+
+  const int64_t Ln = L > 0 ? L : 1;
+  const int64_t epn = p.ep > 0 ? p.ep : 1;
   Scratch sc{static_cast<char *>(scratch), 0, scratch_bytes};
   float *slabs = sc.take<float>(bs.slab / 4);
   float *dxa = sc.take<float>(n * h), *dxb = sc.take<float>(n * h);
-  float *dy = sc.take<float>(n * h), *du = sc.take<float>(n * h);
+  float *dy_all = sc.take<float>(Ln * n * h), *du_all = sc.take<float>(Ln * n * h);
   float *dagg = sc.take<float>(n * 8 * h);
-  float *dm = sc.take<float>((p.ep > 0 ? p.ep : 1) * 2 * h);
-  float *dm2 = d->pre_layers > 1 ? sc.take<float>((p.ep > 0 ? p.ep : 1) * 2 * h) : dm;
-  float *dpq = sc.take<float>(n * 4 * h);
-  float *dr = sc.take<float>(C * 2 * h);
+  float *dm_all = sc.take<float>(Ln * epn * 2 * h);
+  float *dm2 = pl > 1 ? sc.take<float>(epn * 2 * h) : nullptr;
+  float *dpq_all = sc.take<float>(Ln * n * 4 * h);
+  float *dr_all = sc.take<float>(Ln * C * 2 * h);
   float *dcenc = sc.take<float>(C * h), *dcemb = sc.take<float>(C * h);
   float *bnpart = sc.take<float>(1024 * 2 * h);
   float *wlinT = sc.take<float>((size_t)h * h);
-  float *wta = sc.take<float>((size_t)kDegreeBuckets * 2 * 4 * h * (h / 2));
+  const size_t wta_per_layer = (size_t)kDegreeBuckets * 2 * 4 * h * (h / 2);
+  float *wta_all = sc.take<float>((size_t)Ln * wta_per_layer);
   int32_t *rowptr_s = sc.take<int32_t>(n + 1);
-  int32_t *rows_s = sc.take<int32_t>(p.ep > 0 ? p.ep : 1);
+  int32_t *rows_s = sc.take<int32_t>(epn);
   int32_t *rowptr_c = sc.take<int32_t>(C + 1);
-  int32_t *rows_c = sc.take<int32_t>(p.ep > 0 ? p.ep : 1);
+  int32_t *rows_c = sc.take<int32_t>(epn);
   char *grp_ws = sc.take<char>(group_by_key_workspace_bytes(n > C ? n : C));
   float *dcur = sc.take<float>(g * h), *dnext = sc.take<float>(g * h), *dyr = sc.take<float>(g * h);
   float *dout_pad = sc.take<float>(g * 8);
@@ -524,7 +564,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   const int vocab_pad = 192;
   float *det = sc.take<float>((size_t)h * vocab_pad);
   const size_t per_layer_t = 9 * (size_t)h * h;      // wlinT [H][H] | wxpqT [H][5H] = [wxT | wpqT] | wcT [H][2H] | weT [H][H]
-  float *wt_layers = sc.take<float>((size_t)(L > 0 ? L : 1) * per_layer_t);
+  float *wt_layers = sc.take<float>((size_t)Ln * per_layer_t);
   float *wt_readout = sc.take<float>((size_t)p.nb * h * h);
   GS_REQUIRE(det != nullptr && wt_layers != nullptr && wt_readout != nullptr, GNNSAFT_ERR_WORKSPACE);
   const size_t slab_bytes = bs.slab;
@@ -534,16 +574,38 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     float *o1[1] = {out};
     return launch_transpose(1, i1, o1, &ld_in, &ld_out, rows, cols, st);
   };
-  auto dgrad = [&](const float *a, int64_t lda, const float *wT, int64_t ldw, float *out, int64_t ldo, int64_t rows,
-                   int n_out, int k, const float *residual) {
+  auto dgrad = [&](hipStream_t s_, const float *a, int64_t lda, const float *wT, int64_t ldw, float *out, int64_t ldo,
+                   int64_t rows, int n_out, int k, const float *residual) {
     GemmBatchEntry e{wT, nullptr, out, 0};
     LinearEpilogue epi;
     epi.residual = residual;
     epi.ldr = ldo;
-    return launch_linear(a, lda, 0, 1, &e, ldw, ldo, rows, n_out, k, epi, st);
+    return launch_linear(a, lda, 0, 1, &e, ldw, ldo, rows, n_out, k, epi, s_);
   };
 
-  // =========================== readout backward ===========================
+  // =========================== side branch: one-off preparation ===========================
+  GS_TRY(order(st, sa));  // fork: the tape and the scratch buffer belong to the caller's stream
+  hipEvent_t ev_wta = nullptr, ev_csr = nullptr;
+  for (int l = 0; l < L; ++l) {  // transposed, degree-folded update weights of every layer (weights only)
+    const LayerW &w = pw.layers[l];
+    PostPair pp{w.wpost[0][0], w.wpost[1][0]};
+    hipLaunchKernelGGL(k_fold_post_weights_t, dim3((unsigned)(4 * h / 32), (unsigned)(h / 2 / 32), kDegreeBuckets * 2),
+                       dim3(256), 0, sa, pp, w.avg, I(p.hist3), h, wta_all + (size_t)l * wta_per_layer);
+  }
+  GS_TRY(mark(sa, ev_wta));
+  // transposed CSR (rows grouped by source) ... and, with many edge classes, rows grouped by class.  Few classes
+  // (the reference has 5*6*2 = 60): the per-class sums of dm are a one-hot TN GEMM, no grouping needed.
+  const bool class_gemm = C <= kClassGemmMax;
+  if (L > 0) {
+    GS_TRY(launch_group_by_key(I(p.src), p.ep, n, rowptr_s, rows_s, grp_ws, group_by_key_workspace_bytes(n), 1, sa));
+    GS_TRY(mark(sa, ev_csr));
+    if (!class_gemm)
+      GS_TRY(launch_group_by_key(I(p.combo), p.ep, C, rowptr_c, rows_c, grp_ws,
+                                 group_by_key_workspace_bytes(n > C ? n : C), 0, sa));
+  }
+  hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * h, 256)), dim3(256), 0, sa, dcemb, C * h);
+
+  // =========================== readout backward (main) ===========================
   const int nb = p.nb;
   const int64_t rs = g * (int64_t)h;
   GS_REQUIRE(P <= 8, GNNSAFT_ERR_UNSUPPORTED);
@@ -620,7 +682,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div((int64_t)h * 8, 256)), dim3(256), 0, st, w3T,
                        (int64_t)h * 8);
     GS_TRY(transpose1(fin.w, fin.n_in, w3T, 8, P, fin.n_in));
-    GS_TRY(dgrad(dout_pad, 8, w3T, 8, dcur, fin.n_in, g, fin.n_in, 8, nullptr));
+    GS_TRY(dgrad(st, dout_pad, 8, w3T, 8, dcur, fin.n_in, g, fin.n_in, 8, nullptr));
   }
   for (int bi = nb - 1; bi >= 0; --bi) {
     const ReadoutW &rw = pw.readout[bi];
@@ -632,34 +694,28 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     GS_TRY(launch_wgrad_plain(dyr, rw.n_out, in, rw.n_in, 0, g, rw.n_out, rw.n_in, G(ib), rw.n_in, 0, slabs, slab_bytes,
                               st));
     // (bias gradient: exactly zero, written above)
-    GS_TRY(dgrad(dyr, rw.n_out, wt_readout + (size_t)bi * h * h, rw.n_out, dnext, rw.n_in, g, rw.n_in, rw.n_out, nullptr));
+    GS_TRY(dgrad(st, dyr, rw.n_out, wt_readout + (size_t)bi * h * h, rw.n_out, dnext, rw.n_in, g, rw.n_in, rw.n_out,
+                 nullptr));
     float *t = dcur;
     dcur = dnext;
     dnext = t;
   }
   // gradient segments complete in the order readout, layer L-1 .. 0, embeddings: an event per segment lets the
-  // data-parallel exchange of a finished segment run under the rest of the backward (parallel.py)
-  auto segment_done = [&](int i) -> int {
+  // data-parallel exchange of a finished segment run under the rest of the backward (parallel.py).  A layer's
+  // segment is finished by the side stream (its weight gradients come last).
+  auto segment_done = [&](int i, hipStream_t s_) -> int {
     if (segment_events != nullptr && segment_events[i] != nullptr)
-      GS_HIP(hipEventRecord(static_cast<hipEvent_t>(segment_events[i]), st));
+      GS_HIP(hipEventRecord(static_cast<hipEvent_t>(segment_events[i]), s_));
     return GNNSAFT_OK;
   };
-  GS_TRY(segment_done(0));
+  GS_TRY(segment_done(0, st));
   // pool backward: dx_L
   float *dx = dxa, *dx_other = dxb;
   hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)gs_ceil_div(g * (h / 4), 256)), dim3(256), 0, st, dcur,
                      I(p.graph_ptr), g, n, h, dx, gs_row_split(h / 4));
-
-  // =========================== transposed CSR (rows grouped by source) ===========================
-  GS_TRY(launch_group_by_key(I(p.src), p.ep, n, rowptr_s, rows_s, grp_ws, group_by_key_workspace_bytes(n), 1, st));
-  // ... and grouped by edge class (for the edge-table gradient)
-  // Few classes (the reference has 5*6*2 = 60): the per-class sums of dm are a one-hot TN GEMM, no grouping needed.
-  const bool class_gemm = C <= kClassGemmMax;
-  if (!class_gemm)
-    GS_TRY(launch_group_by_key(I(p.combo), p.ep, C, rowptr_c, rows_c, grp_ws,
-                               group_by_key_workspace_bytes(n > C ? n : C), 0, st));
-
-  hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * h, 256)), dim3(256), 0, st, dcemb, C * h);
+  // the readout's weight gradients used `slabs` on the main stream; from here on it belongs to the side stream
+  // (... which also orders the weight transposes above before the side stream's edge-table dgrads)
+  GS_TRY(order(st, sa));
 
   // =========================== layers, in reverse ===========================
   for (int l = L - 1; l >= 0; --l) {
@@ -667,7 +723,6 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     const int base = pw.layer_base[l];
     // table indices inside the layer (q = post_layers): avg 0 | we 1 be 2 | pre0 w3 b4 | pre1 w5 b6 |
     //   post0 (w,b) x q from 7 | post1 (w,b) x q from 7+2q | lin w,b | bn gamma, beta (running stats, counter)
-    const int q = d->post_layers, pl = d->pre_layers;
     const int i_pre0 = base + 3, i_pre1 = base + 3 + 2 * pl;
     const int i_post0 = base + 3 + 4 * pl, i_post1 = i_post0 + 2 * q, i_lin = i_post1 + 2 * q, i_bn = i_lin + 2;
     const float *x_l = F(p.x0) + l * p.sx, *pq_l = F(p.pq) + l * p.spq, *agg_l = F(p.agg) + l * p.sagg;
@@ -677,6 +732,10 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     const float *stat = F(p.bnstat) + (int64_t)l * 2 * h;
     const float *rtab = F(p.rtab) + l * C * (int64_t)(2 * h);
     const float *cenc = F(p.cenc) + l * C * (int64_t)h;
+    float *dy = dy_all + (int64_t)l * n * h, *du = du_all + (int64_t)l * n * h;
+    float *dm = dm_all + (int64_t)l * epn * 2 * h, *dpq = dpq_all + (int64_t)l * n * 4 * h;
+    float *dr = dr_all + (int64_t)l * C * 2 * h;
+    float *wta = wta_all + (size_t)l * wta_per_layer;
 
     // transposed weights of this layer (built by the one batched launch at the top):
     //   wlinT | wxpqT[j][0:H] = W_post,t[o][j] (x block), wxpqT[j][H + blk F + f] = W_pre,t[f][part F + j] | wcT | weT
@@ -685,11 +744,12 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     const int64_t h5 = 5 * (int64_t)h;
     // x_{l+1} = relu(bn(y)) + x_l : dy through BN+ReLU; the skip gradient stays in dx
     GS_TRY(bn_relu_backward(y_l, dx, stat, w.bn.gamma, w.bn.beta, n, h, G(i_bn), G(i_bn + 1), dy, bnpart, st));
-    // lin
-    GS_TRY(launch_wgrad_plain(dy, h, u_l, h, 0, n, h, h, G(i_lin), h, 0, slabs, slab_bytes, st));
+    // lin: weight gradient (side), input gradient (main)
+    GS_TRY(order(st, sa));
+    GS_TRY(launch_wgrad_plain(dy, h, u_l, h, 0, n, h, h, G(i_lin), h, 0, slabs, slab_bytes, sa));
     // (lin.bias sits in front of the BatchNorm: gradient exactly zero, written by the zero list)
-    GS_TRY(dgrad(dy, h, wlinT_l, h, du, h, n, h, h, nullptr));
-    // extra post layers (Linear(F/2,F/2) after a ReLU, per tower), last to first: du_j -> du_{j-1}
+    GS_TRY(dgrad(st, dy, h, wlinT_l, h, du, h, n, h, h, nullptr));
+    // extra post layers (Linear(F/2,F/2) after a ReLU, per tower), last to first: du_j -> du_{j-1}  (single stream)
     for (int j = q - 1; j >= 1; --j) {
       const float *u_prev = u_first + (int64_t)(j - 1) * n * h;  // pre-ReLU input of post layer j
       float *du_prev = dy;                                        // dy is free after the lin dgrad
@@ -712,22 +772,20 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       du = du_prev;
       dy = tsw;
     }
-    // update wgrad / bias
+    // update weight / bias gradients (side)
+    GS_TRY(order(st, sa));
     GS_TRY(launch_wgrad_post_folded(du, x_l, agg_l, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap,
-                                    pna_fold_tile_rows(h), w.avg, h, G(i_post0), G(i_post1), slabs, slab_bytes, st));
+                                    pna_fold_tile_rows(h), w.avg, h, G(i_post0), G(i_post1), slabs, slab_bytes, sa));
     {  // both towers' bias gradients: column sums of du, halves to two tensors
       float *outs[2] = {G(i_post0 + 1), G(i_post1 + 1)};
-      GS_TRY(launch_colsum_blocks(du, h, n, 2, h / 2, outs, slabs, slab_bytes, st));
+      GS_TRY(launch_colsum_blocks(du, h, n, 2, h / 2, outs, slabs, slab_bytes, sa));
     }
     // update dgrad, x part: dx_in = (skip ? dx : 0) + du [N,F] x [W_x,0 ; W_x,1]
-    {
-      GS_TRY(dgrad(du, h, wxpqT_l, h5, dx_other, h, n, h, h, d->skip_connections ? dx : nullptr));
-    }
+    GS_TRY(dgrad(st, du, h, wxpqT_l, h5, dx_other, h, n, h, h, d->skip_connections ? dx : nullptr));
     // update dgrad, aggregate part (degree-tiled, scalers folded): dagg[i,t,:] = du_t[i] W_A,eff(d_i, t)
     {
-      PostPair pp{w.wpost[0][0], w.wpost[1][0]};
-      hipLaunchKernelGGL(k_fold_post_weights_t, dim3((unsigned)(4 * h / 32), (unsigned)(h / 2 / 32), kDegreeBuckets * 2),
-                         dim3(256), 0, st, pp, w.avg, I(p.hist3), h, wta);
+      GS_TRY(await(st, ev_wta));
+      ev_wta = nullptr;
       const int64_t per_t = (int64_t)(4 * h) * (h / 2);
       GemmBatchEntry e[2] = {{wta, nullptr, dagg, 0}, {wta + per_t, nullptr, dagg + 4 * h, h / 2}};
       GS_TRY(launch_linear_degree_tiled(du, h, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap, 2 * per_t, 2, e,
@@ -739,7 +797,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
                          I(p.rowptr), I(p.src), I(p.combo), pq_l, rtab, nullptr, agg_l, dagg, dm, dpq, n, h,
                          gs_row_split(h / 2));
     } else {
-      // extra pre layers: messages = output of the last one (materialised per CSR row on the tape)
+      // extra pre layers: messages = output of the last one (materialised per CSR row on the tape)  (single stream)
       const int64_t ms = p.ep * (int64_t)(2 * h);
       const float *m_l = F(p.msg0) + l * p.smsg;
       hipLaunchKernelGGL(k_agg_bwd<true>, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st,
@@ -773,46 +831,54 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       hipLaunchKernelGGL(k_segment_sum, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, I(p.rowptr), dm,
                          dpq, n, h, gs_row_split(h / 2));
     }
-    hipLaunchKernelGGL(k_gather_rows_sum, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, rowptr_s,
-                       rows_s, dm, dpq, n, h, gs_row_split(h / 2));
+    // per-class sums of dm and the edge-class table chain (side):
+    //   rtab[c, tF:(t+1)F] = W_t[:,2F:3F] cenc[c] + b_t ; cenc = cemb W_e^T + b_e
+    GS_TRY(order(st, sa));
     if (class_gemm) {
       GS_TRY(launch_sum_rows_by_class(I(p.combo), (int)C, dm, 2 * (int64_t)h, p.ep, 2 * h, dr, 2 * (int64_t)h, slabs,
-                                      slab_bytes, st));
+                                      slab_bytes, sa));
     } else {
-      hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * 2 * h, 256)), dim3(256), 0, st, dr, C * 2 * h);
+      hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * 2 * h, 256)), dim3(256), 0, sa, dr, C * 2 * h);
       hipLaunchKernelGGL(k_class_reduce, dim3((unsigned)gs_ceil_div(gs_ceil_div(p.ep, 32) * (h / 2), 256)),
-                         dim3(256), 0, st, rows_c, I(p.combo), dm, p.ep, (int)C, h, dr, gs_row_split(h / 2));
+                         dim3(256), 0, sa, rows_c, I(p.combo), dm, p.ep, (int)C, h, dr, gs_row_split(h / 2));
     }
-    // message GEMMs: dx_in += [dP | dQ] W_pq ; dW_dst,t / dW_src,t = dP_t^T x / dQ_t^T x
-    {
-      GS_TRY(dgrad(dpq, 4 * (int64_t)h, wxpqT_l + h, h5, dx, h, n, h, 4 * h, dx_other));
-      {  // dW_dst,t0 | dW_dst,t1 | dW_src,t0 | dW_src,t1 = dPQ^T x: one TN GEMM, four [F,F] blocks of two matrices
-        float *blocks[4] = {G(i_pre0), G(i_pre1), G(i_pre0) + h, G(i_pre1) + h};
-        GS_TRY(launch_wgrad_plain_blocks(dpq, 4 * (int64_t)h, x_l, h, n, 4, h, h, blocks, 3 * (int64_t)h, slabs,
-                                         slab_bytes, st));
-      }
-    }
-    // edge-class table: rtab[c, tF:(t+1)F] = W_t[:,2F:3F] cenc[c] + b_t ; cenc = cemb W_e^T + b_e
     {
       float *blocks[2] = {G(i_pre0) + 2 * h, G(i_pre1) + 2 * h};
       GS_TRY(launch_wgrad_plain_blocks(dr, 2 * (int64_t)h, cenc, h, C, 2, h, h, blocks, 3 * (int64_t)h, slabs, slab_bytes,
-                                       st));
+                                       sa));
     }
     {
       float *outs[2] = {G(i_pre0 + 1), G(i_pre1 + 1)};
-      GS_TRY(launch_colsum_blocks(dr, 2 * (int64_t)h, C, 2, h, outs, slabs, slab_bytes, st));
+      GS_TRY(launch_colsum_blocks(dr, 2 * (int64_t)h, C, 2, h, outs, slabs, slab_bytes, sa));
     }
     {
-      GS_TRY(dgrad(dr, 2 * (int64_t)h, wcT_l, 2 * (int64_t)h, dcenc, h, C, h, 2 * h, nullptr));
-      GS_TRY(launch_wgrad_plain(dcenc, h, F(p.cemb), h, 0, C, h, h, G(base + 1), h, 0, slabs, slab_bytes, st));
-      GS_TRY(launch_colsum(dcenc, h, C, h, G(base + 2), 0, slabs, slab_bytes, st));
-      GS_TRY(dgrad(dcenc, h, weT_l, h, dcemb, h, C, h, h, dcemb));  // accumulate over layers (in place)
+      GemmBatchEntry e1{wcT_l, nullptr, dcenc, 0};
+      LinearEpilogue epi1;
+      GS_TRY(launch_linear(dr, 2 * (int64_t)h, 0, 1, &e1, 2 * (int64_t)h, h, C, h, 2 * h, epi1, sa));
+      GS_TRY(launch_wgrad_plain(dcenc, h, F(p.cemb), h, 0, C, h, h, G(base + 1), h, 0, slabs, slab_bytes, sa));
+      GS_TRY(launch_colsum(dcenc, h, C, h, G(base + 2), 0, slabs, slab_bytes, sa));
+      GS_TRY(dgrad(sa, dcenc, h, weT_l, h, dcemb, h, C, h, h, dcemb));  // accumulate over layers (in place)
     }
-    // dx now holds dL/dx_l; dx_other is free again
-    GS_TRY(segment_done(1 + (L - 1 - l)));
+    // dQ by source (main; the transposed CSR comes from the side stream's preparation)
+    GS_TRY(await(st, ev_csr));
+    ev_csr = nullptr;
+    hipLaunchKernelGGL(k_gather_rows_sum, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, rowptr_s,
+                       rows_s, dm, dpq, n, h, gs_row_split(h / 2));
+    // message GEMMs: dx_in += [dP | dQ] W_pq (main) ; dW_dst,t / dW_src,t = dP_t^T x / dQ_t^T x (side)
+    GS_TRY(order(st, sa));
+    {  // dW_dst,t0 | dW_dst,t1 | dW_src,t0 | dW_src,t1 = dPQ^T x: one TN GEMM, four [F,F] blocks of two matrices
+      float *blocks[4] = {G(i_pre0), G(i_pre1), G(i_pre0) + h, G(i_pre1) + h};
+      GS_TRY(launch_wgrad_plain_blocks(dpq, 4 * (int64_t)h, x_l, h, n, 4, h, h, blocks, 3 * (int64_t)h, slabs,
+                                       slab_bytes, sa));
+    }
+    GS_TRY(dgrad(st, dpq, 4 * (int64_t)h, wxpqT_l + h, h5, dx, h, n, h, 4 * h, dx_other));
+    // dx now holds dL/dx_l; dx_other is free again.  The layer's last gradient is written by the side stream (which
+    // has waited for this layer's BatchNorm backward, the only main-stream writer of the segment).
+    GS_TRY(segment_done(1 + (L - 1 - l), sa));
   }
 
   // =========================== embeddings ===========================
+  GS_TRY(order(sa, st));  // join: dcemb is complete, `slabs` is the main stream's again
   {
     TableGrads tg;
     tg.n = d->num_bond_cols;
@@ -842,6 +908,6 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
                        vocab_pad, h, tg, total);
   }
   GS_CHECK_LAUNCH();
-  GS_TRY(segment_done(L + 1));
+  GS_TRY(segment_done(L + 1, st));
   return GNNSAFT_OK;
 }

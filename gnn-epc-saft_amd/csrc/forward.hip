@@ -28,14 +28,10 @@ struct gnnsaft_profile {
   std::vector<uint32_t> kind;
 };
 
-// Side stream for the structure chain (K0: CSR, graph ptr, degree tiles, folded weights).  It depends only on
-// edge_index / batch / weights, the embedding + edge-table + first message GEMM chain only on x / weights, so the
-// two run concurrently between a fork and a join event (captured as parallel branches under hipGraph capture).
-struct gnnsaft_aux {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-};
-
+// gnnsaft_aux (plan.hpp): side stream for the structure chain (K0: CSR, graph ptr, degree tiles, folded weights).
+// It depends only on edge_index / batch / weights, the embedding + edge-table + first message GEMM chain only on
+// x / weights, so the two run concurrently between a fork and a join event (captured as parallel branches under
+// hipGraph capture).
 extern "C" int gnnsaft_aux_create(gnnsaft_aux **out) {
   if (out == nullptr) return GNNSAFT_ERR_NULL;
   gnnsaft_aux *a = new (std::nothrow) gnnsaft_aux();
@@ -55,6 +51,7 @@ extern "C" void gnnsaft_aux_destroy(gnnsaft_aux *a) {
   if (a == nullptr) return;
   if (a->fork) (void)hipEventDestroy(a->fork);
   if (a->join) (void)hipEventDestroy(a->join);
+  for (hipEvent_t e : a->pool) (void)hipEventDestroy(e);
   if (a->stream) (void)hipStreamDestroy(a->stream);
   delete a;
 }

@@ -4,7 +4,26 @@
 
 #include "common.hpp"
 
+// Side stream + events of one device (include/gnnsaft.h: gnnsaft_aux_create).  The forward runs its structure chain
+// on it, the backward everything that is off its critical path (weight / bias gradients, edge-class sums, the
+// edge-table chain).  One call at a time per handle.
+struct gnnsaft_aux {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  std::vector<hipEvent_t> pool;  // dependency events between the two streams, created on first use
+};
+
 namespace gs {
+
+// i-th dependency event of the handle (no timing), or nullptr when the runtime refuses to create one
+static inline hipEvent_t aux_event(gnnsaft_aux *a, size_t i) {
+  while (a->pool.size() <= i) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    a->pool.push_back(e);
+  }
+  return a->pool[i];
+}
 
 struct Plan {
   // sizes

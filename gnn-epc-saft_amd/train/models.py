@@ -167,6 +167,9 @@ class PNAPCSAFT(nn.Module):
         # hipGraph replay of the step is 0.490 ms with it and 0.491 ms without (C2), and the graph executor does
         # not reliably run the two branches concurrently (profiles/r01_c2_graph_replay_timeline.txt).
         self.use_side_stream = os.environ.get("GNNSAFT_SIDE_STREAM", "0") == "1"
+        # gnnsaft_backward runs weight / bias gradients, edge-class sums and the edge-table chain on a side stream
+        # (forked from and joined into the current stream inside the call); False = one stream
+        self.backward_side_stream = os.environ.get("GNNSAFT_BACKWARD_SIDE_STREAM", "1") == "1"
         # backward fast path: set .grad to views of the one flat gradient buffer when every .grad is None
         self.direct_grads = True
         self._profile = None  # gnnsaft_profile* (bench.py attaches one to time kernels with HIP events)
@@ -463,10 +466,12 @@ class PNAPCSAFT(nn.Module):
                 raise ValueError("gradient_segment_events must hold num_layers + 2 events")
             events = (ctypes.c_void_p * len(evs))(*[e.cuda_event for e in evs])
         with torch.cuda.device(dev):
+            aux = aux_for(dev.index if dev.index is not None else torch.cuda.current_device()) \
+                if self.backward_side_stream else None
             rc = lib.gnnsaft_backward(ctypes.byref(desc), wtab, gtab, nw, ctx["x"].data_ptr(),
                                       None if ctx["batch"] is None else ctx["batch"].data_ptr(), ctx["n"], ctx["e"],
                                       ctx["g"], grad_out.data_ptr(), ctx["ws_ptr"], ctx["ws_bytes"], sp,
-                                      scratch.numel() - (sp - scratch.data_ptr()), events, stream)
+                                      scratch.numel() - (sp - scratch.data_ptr()), events, aux, stream)
         check(rc, "gnnsaft_backward")
         self._last_flat_grad = flat
         return grads

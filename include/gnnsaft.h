@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNNSAFT_ABI_VERSION 2
+#define GNNSAFT_ABI_VERSION 3
 
 #define GNNSAFT_OK 0
 #define GNNSAFT_ERR_SHAPE (-1)      /* unsupported / inconsistent sizes          */
@@ -328,11 +328,12 @@ void gnnsaft_profile_destroy(gnnsaft_profile *prof);
 int gnnsaft_profile_reset(gnnsaft_profile *prof);
 int gnnsaft_profile_summary(gnnsaft_profile *prof, uint32_t kernel_bit, int32_t *count, float *total_ms);
 
-/* Optional side stream (+ fork / join events) lent to gnnsaft_forward: the structure chain  */
+/* Optional side stream (+ events) lent to gnnsaft_forward / gnnsaft_backward.  Forward: the structure chain */
 /* (CSR, graph ptr, degree tiles, folded weights) runs there, concurrently with the embedding */
 /* / edge-table / first message GEMM chain on `stream`, and is joined back before the first   */
 /* aggregation; capturable (the two chains become parallel branches of the hipGraph).  One    */
-/* handle per concurrently running forward; create it on the device it will be used on.       */
+/* handle per concurrently running call; create it on the device it will be used on.          */
+/* Backward: see gnnsaft_backward.                                                             */
 typedef struct gnnsaft_aux gnnsaft_aux;
 int gnnsaft_aux_create(gnnsaft_aux **out);
 void gnnsaft_aux_destroy(gnnsaft_aux *aux);
@@ -379,9 +380,14 @@ int gnnsaft_structure_build(const gnnsaft_model_desc *desc, const int64_t *edge_
 /* Supported: 1 <= pre_layers, post_layers <= 8, hidden % 64 == 0.              */
 /* `segment_events` (HOST array of num_layers + 2 hipEvent_t, or NULL): the      */
 /* gradients complete in the order readout, layer L-1 .. layer 0, embeddings     */
-/* (contiguous segments of the canonical weight order); event i is recorded on   */
-/* `stream` when segment i is complete, so that a data-parallel caller can        */
-/* all-reduce it on another stream under the remaining backward kernels.         */
+/* (contiguous segments of the canonical weight order); event i is recorded      */
+/* (on `stream`, or on the side stream for the layer segments) when segment i is  */
+/* complete, so that a data-parallel caller can all-reduce it on another stream    */
+/* under the remaining backward kernels.                                          */
+/* `aux` (or NULL: single stream): with pre_layers == post_layers == 1 everything  */
+/* off the critical path of the input gradients -- weight / bias gradients, edge-  */
+/* class sums, the edge-table chain, the transposed CSR -- runs on the handle's    */
+/* side stream, forked from and joined back into `stream` inside the call.         */
 /* ------------------------------------------------------------------------ */
 size_t gnnsaft_backward_scratch_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes,
                                       int64_t num_edges, int64_t num_graphs);
@@ -389,7 +395,8 @@ int gnnsaft_backward(const gnnsaft_model_desc *desc, const void *const *weights_
                      void *const *grads_host, int32_t num_weights, const int64_t *x,
                      const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
                      const float *grad_out, void *tape, size_t tape_bytes, void *scratch,
-                     size_t scratch_bytes, void *const *segment_events, gnnsaft_stream_t stream);
+                     size_t scratch_bytes, void *const *segment_events,
+                     gnnsaft_aux *aux /* or NULL */, gnnsaft_stream_t stream);
 /* d(MAPE)/d(pred) * dloss[0] (dloss NULL => 1): sign(p-t) / max(|t|,1.17e-6) / (G*P) */
 int gnnsaft_mape_backward(const float *pred, const float *target, int64_t num_graphs,
                           int32_t num_para, const float *dloss, float *dpred,

@@ -25,7 +25,7 @@ def test_library_exports_every_symbol_declared_in_the_header():
         assert hasattr(lib, name), f"{name} declared in include/gnnsaft.h but not exported"
         assert name in _native.SIGNATURES, f"{name} has no ctypes signature in _native.py"
     assert set(_native.SIGNATURES) <= declared
-    assert _native.lib.gnnsaft_abi_version() == 2
+    assert _native.lib.gnnsaft_abi_version() == 3
     assert _native.lib.gnnsaft_error_string(-2) == b"workspace too small"
 
 

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""N full training steps (forward + MAPE + backward + fused AdamW) at a bench configuration, for rocprofv3 runs.
-usage: train_step.py [config=2] [steps=10]"""
+"""Host-side (Python + launch) cost of a training step: cProfile of N steps at a bench configuration.
+usage: train_step_hostprofile.py [config=2] [steps=100]"""
+import cProfile
 import os
+import pstats
 import sys
-import time
 
 import torch
 
@@ -13,7 +14,7 @@ from bench import CONFIGS  # noqa: E402
 from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch  # noqa: E402
 
 cfg = CONFIGS[int(sys.argv[1]) if len(sys.argv) > 1 else 2]
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 data = make_synthetic_batch(cfg["graphs"], 1234, num_para=3)
 torch.manual_seed(0)
 lit = G.PNApcsaftL(G.PnaconvsParams(cfg["depth"], 1, 1, degree_histogram(data), skip_connections=True, self_loops=True),
@@ -33,13 +34,14 @@ def step():
     sched.step()
 
 
-for _ in range(3):
+for _ in range(5):
     step()
 torch.cuda.synchronize()
-t0 = time.perf_counter()
+pr = cProfile.Profile()
+pr.enable()
 for _ in range(steps):
     step()
-t_host = time.perf_counter() - t0          # everything enqueued (the host side of the steps)
+pr.disable()
 torch.cuda.synchronize()
-print(f"{cfg['name']}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms per training step "
-      f"(host enqueue {t_host / steps * 1e3:.3f} ms per step)")
+st = pstats.Stats(pr)
+st.sort_stats("cumulative").print_stats(45)
