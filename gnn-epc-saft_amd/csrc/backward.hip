@@ -75,36 +75,58 @@ __global__ __launch_bounds__(256) void k_pool_bwd(const float *__restrict__ dg, 
 
 // ------------------------------------------------------------------ BatchNorm (+ReLU) backward, train mode
 constexpr int kBwdCols = 32;
+// partial[chunk][0][col] = sum dz, partial[chunk][1][col] = sum dz yhat over the chunk's rows (dz = dout masked by the
+// ReLU).  A workgroup owns 32 columns x one row chunk: 8 float4 column lanes x 32 row lanes, four rows per thread in
+// flight (the first version read one float per thread per row: 1.7 TB/s on a 2 x [N,H] stream).  ch % 4 == 0.
 __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float *__restrict__ y, const float *__restrict__ dout,
                                                         const float *__restrict__ stat,
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, int64_t rows, int ch,
                                                         int64_t rows_per_chunk, float *__restrict__ partial) {
-  __shared__ double s1s[8][kBwdCols], s2s[8][kBwdCols];
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int col = blockIdx.x * kBwdCols + cl;
-  const int colc = col < ch ? col : ch - 1;
-  const float mean = stat[colc], rstd = stat[ch + colc], gm = gamma[colc], bt = beta[colc];
+  __shared__ double s1s[32][kBwdCols + 1], s2s[32][kBwdCols + 1];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int col = blockIdx.x * kBwdCols + cl * 4;
+  const bool col_ok = col < ch;
+  const int colc = col_ok ? col : 0;
+  const f32x4 mean = gs_ld4(stat + colc), rstd = gs_ld4(stat + ch + colc), gm = gs_ld4(gamma + colc),
+              bt = gs_ld4(beta + colc);
   const int64_t r_beg = (int64_t)blockIdx.y * rows_per_chunk;
   int64_t r_end = r_beg + rows_per_chunk;
   if (r_end > rows) r_end = rows;
-  double s1 = 0.0, s2 = 0.0;
-  for (int64_t r = r_beg + rl; r < r_end; r += 8) {
-    const float yh = (y[r * ch + colc] - mean) * rstd;
-    const float dz = (yh * gm + bt) > 0.f ? dout[r * ch + colc] : 0.f;
-    s1 += (double)dz;
-    s2 += (double)dz * (double)yh;
-  }
-  s1s[rl][cl] = s1;
-  s2s[rl][cl] = s2;
-  __syncthreads();
-  if (rl == 0 && col < ch) {
-    for (int o = 1; o < 8; ++o) {
-      s1 += s1s[o][cl];
-      s2 += s2s[o][cl];
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t r0 = r_beg + rl; r0 < r_end; r0 += 4 * 32) {
+    f32x4 yv[4], dv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int64_t r = r0 + 32 * u;
+      r = r < r_end ? r : r_end - 1;
+      yv[u] = gs_ld4(y + r * ch + colc);
+      dv[u] = gs_ld4(dout + r * ch + colc);
     }
-    partial[((int64_t)blockIdx.y * 2 + 0) * ch + col] = (float)s1;
-    partial[((int64_t)blockIdx.y * 2 + 1) * ch + col] = (float)s2;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = r0 + 32 * u < r_end;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float yh = (yv[u][j] - mean[j]) * rstd[j];
+        const float dz = (ok && (yh * gm[j] + bt[j]) > 0.f) ? dv[u][j] : 0.f;
+        s1[j] += (double)dz;
+        s2[j] += (double)dz * (double)yh;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s1s[rl][cl * 4 + j] = s1[j];
+    s2s[rl][cl * 4 + j] = s2[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * kBwdCols) {   // 32 columns x (sum dz | sum dz yhat), row lanes combined in a fixed order
+    const int which = threadIdx.x / kBwdCols, c = threadIdx.x % kBwdCols;
+    double t = 0.0;
+    for (int o = 0; o < 32; ++o) t += which == 0 ? s1s[o][c] : s2s[o][c];
+    const int cc = blockIdx.x * kBwdCols + c;
+    if (cc < ch) partial[((int64_t)blockIdx.y * 2 + which) * ch + cc] = (float)t;
   }
 }
 
@@ -172,6 +194,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
 static int bn_relu_backward(const float *y, const float *dout, const float *stat, const float *gamma,
                             const float *beta, int64_t rows, int ch, float *dgamma, float *dbeta, float *dy,
                             float *partial, hipStream_t st) {
+  GS_REQUIRE(ch >= 4 && (ch % 4) == 0, GNNSAFT_ERR_UNSUPPORTED);
   const int slabs = (ch + kBwdCols - 1) / kBwdCols;
   int64_t chunks = 512 / slabs;
   const int64_t max_chunks = gs_ceil_div(rows, 64);
@@ -354,6 +377,77 @@ __global__ __launch_bounds__(256) void k_fold_post_weights_t(PostPair pp, const 
   float *out = wta + (((int64_t)d * 2 + t) * (4 * f)) * (f / 2);
 #pragma unroll
   for (int j = 0; j < 4; ++j) out[(int64_t)(c0 + ty + 8 * j) * (f / 2) + o0 + tx] = tl[tx][ty + 8 * j];
+}
+
+// ---- edge-class table chain for few classes (the reference has 5*6*2 = 60 bond-feature combinations):
+//   rtab[c, tF + f] = sum_j W_t[f][2F + j] cenc[c][j] + b_t[f]       cenc[c][j] = sum_i W_e[j][i] cemb[c][i] + b_e[j]
+// Given dr = d rtab [C, 2F] of one layer, two launches replace six (two TN GEMMs, two column sums, two dgrads whose
+// contraction is only C rows long): every output element is one thread's loop over the classes / channels, in a fixed
+// order.
+struct EdgeTableBwd {
+  const float *dr;     // [C, 2F]
+  const float *cenc;   // [C, F]
+  const float *cemb;   // [C, F]
+  const float *wpre0, *wpre1;   // [F, 3F]
+  const float *we;     // [F, F]
+  float *dwpre0, *dwpre1;       // [F, 3F]: columns 2F.. written
+  float *dbpre0, *dbpre1;       // [F]
+  float *dwe, *dbe;    // [F, F], [F]
+  float *dcenc;        // [C, F] scratch
+  float *dcemb;        // [C, F] accumulated over the layers
+  int classes, f;
+};
+// phase A: dW_t[:, 2F:3F] = dr_t^T cenc, db_t = column sums of dr_t, dcenc = sum_t dr_t W_t[:, 2F:3F]
+__global__ __launch_bounds__(256) void k_edge_table_bwd_a(EdgeTableBwd a) {
+  const int f = a.f, C = a.classes;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n_w = 2 * (int64_t)f * f, n_b = 2 * (int64_t)f, n_c = (int64_t)C * f;
+  if (i < n_w) {
+    const int t = (int)(i / ((int64_t)f * f));
+    const int rem = (int)(i - (int64_t)t * f * f);
+    const int row = rem / f, j = rem - row * f;
+    const float *d = a.dr + t * f + row;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += d[(int64_t)c * (2 * f)] * a.cenc[(int64_t)c * f + j];
+    (t == 0 ? a.dwpre0 : a.dwpre1)[(int64_t)row * (3 * f) + 2 * f + j] = s;
+  } else if (i < n_w + n_b) {
+    const int k = (int)(i - n_w);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += a.dr[(int64_t)c * (2 * f) + k];
+    (k < f ? a.dbpre0 : a.dbpre1)[k < f ? k : k - f] = s;
+  } else if (i < n_w + n_b + n_c) {
+    const int64_t r = i - n_w - n_b;
+    const int c = (int)(r / f), j = (int)(r - (int64_t)c * f);
+    const float *d = a.dr + (int64_t)c * (2 * f);
+    float s = 0.f;
+    for (int k = 0; k < f; ++k) s += d[k] * a.wpre0[(int64_t)k * (3 * f) + 2 * f + j];
+    for (int k = 0; k < f; ++k) s += d[f + k] * a.wpre1[(int64_t)k * (3 * f) + 2 * f + j];
+    a.dcenc[r] = s;
+  }
+}
+// phase B: dW_e = dcenc^T cemb, db_e = column sums of dcenc, dcemb += dcenc W_e
+__global__ __launch_bounds__(256) void k_edge_table_bwd_b(EdgeTableBwd a) {
+  const int f = a.f, C = a.classes;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n_w = (int64_t)f * f, n_b = f, n_c = (int64_t)C * f;
+  if (i < n_w) {
+    const int j = (int)(i / f), col = (int)(i - (int64_t)j * f);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += a.dcenc[(int64_t)c * f + j] * a.cemb[(int64_t)c * f + col];
+    a.dwe[i] = s;
+  } else if (i < n_w + n_b) {
+    const int j = (int)(i - n_w);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += a.dcenc[(int64_t)c * f + j];
+    a.dbe[j] = s;
+  } else if (i < n_w + n_b + n_c) {
+    const int64_t r = i - n_w - n_b;
+    const int c = (int)(r / f), col = (int)(r - (int64_t)c * f);
+    const float *d = a.dcenc + (int64_t)c * f;
+    float s = 0.f;
+    for (int j = 0; j < f; ++j) s += d[j] * a.we[(int64_t)j * f + col];
+    a.dcemb[r] += s;
+  }
 }
 
 // bond tables: dtab_k[v, :] (+)= sum over combinations c with digit_k(c) == v of dcemb[c, :]
@@ -780,8 +874,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       float *outs[2] = {G(i_post0 + 1), G(i_post1 + 1)};
       GS_TRY(launch_colsum_blocks(du, h, n, 2, h / 2, outs, slabs, slab_bytes, sa));
     }
-    // update dgrad, x part: dx_in = (skip ? dx : 0) + du [N,F] x [W_x,0 ; W_x,1]
-    GS_TRY(dgrad(st, du, h, wxpqT_l, h5, dx_other, h, n, h, h, d->skip_connections ? dx : nullptr));
+    // (update dgrad, x part: merged with the message dgrad below -- one GEMM over [du | dPQ])
     // update dgrad, aggregate part (degree-tiled, scalers folded): dagg[i,t,:] = du_t[i] W_A,eff(d_i, t)
     {
       GS_TRY(await(st, ev_wta));
@@ -842,16 +935,22 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       hipLaunchKernelGGL(k_class_reduce, dim3((unsigned)gs_ceil_div(gs_ceil_div(p.ep, 32) * (h / 2), 256)),
                          dim3(256), 0, sa, rows_c, I(p.combo), dm, p.ep, (int)C, h, dr, gs_row_split(h / 2));
     }
-    {
-      float *blocks[2] = {G(i_pre0) + 2 * h, G(i_pre1) + 2 * h};
-      GS_TRY(launch_wgrad_plain_blocks(dr, 2 * (int64_t)h, cenc, h, C, 2, h, h, blocks, 3 * (int64_t)h, slabs, slab_bytes,
-                                       sa));
-    }
-    {
-      float *outs[2] = {G(i_pre0 + 1), G(i_pre1 + 1)};
-      GS_TRY(launch_colsum_blocks(dr, 2 * (int64_t)h, C, 2, h, outs, slabs, slab_bytes, sa));
-    }
-    {
+    if (class_gemm) {  // few classes: the six GEMM / column-sum launches below as two elementwise launches
+      EdgeTableBwd eb{dr, cenc, F(p.cemb), w.wpre[0][0], w.wpre[1][0], w.we, G(i_pre0), G(i_pre1), G(i_pre0 + 1),
+                      G(i_pre1 + 1), G(base + 1), G(base + 2), dcenc, dcemb, (int)C, h};
+      const int64_t na = 2 * (int64_t)h * h + 2 * h + C * h, nb2 = (int64_t)h * h + h + C * h;
+      hipLaunchKernelGGL(k_edge_table_bwd_a, dim3((unsigned)gs_ceil_div(na, 256)), dim3(256), 0, sa, eb);
+      hipLaunchKernelGGL(k_edge_table_bwd_b, dim3((unsigned)gs_ceil_div(nb2, 256)), dim3(256), 0, sa, eb);
+    } else {
+      {
+        float *blocks[2] = {G(i_pre0) + 2 * h, G(i_pre1) + 2 * h};
+        GS_TRY(launch_wgrad_plain_blocks(dr, 2 * (int64_t)h, cenc, h, C, 2, h, h, blocks, 3 * (int64_t)h, slabs,
+                                         slab_bytes, sa));
+      }
+      {
+        float *outs[2] = {G(i_pre0 + 1), G(i_pre1 + 1)};
+        GS_TRY(launch_colsum_blocks(dr, 2 * (int64_t)h, C, 2, h, outs, slabs, slab_bytes, sa));
+      }
       GemmBatchEntry e1{wcT_l, nullptr, dcenc, 0};
       LinearEpilogue epi1;
       GS_TRY(launch_linear(dr, 2 * (int64_t)h, 0, 1, &e1, 2 * (int64_t)h, h, C, h, 2 * h, epi1, sa));
@@ -864,14 +963,24 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     ev_csr = nullptr;
     hipLaunchKernelGGL(k_gather_rows_sum, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, rowptr_s,
                        rows_s, dm, dpq, n, h, gs_row_split(h / 2));
-    // message GEMMs: dx_in += [dP | dQ] W_pq (main) ; dW_dst,t / dW_src,t = dP_t^T x / dQ_t^T x (side)
+    // message weight gradients dW_dst,t / dW_src,t = dP_t^T x / dQ_t^T x (side)
     GS_TRY(order(st, sa));
     {  // dW_dst,t0 | dW_dst,t1 | dW_src,t0 | dW_src,t1 = dPQ^T x: one TN GEMM, four [F,F] blocks of two matrices
       float *blocks[4] = {G(i_pre0), G(i_pre1), G(i_pre0) + h, G(i_pre1) + h};
       GS_TRY(launch_wgrad_plain_blocks(dpq, 4 * (int64_t)h, x_l, h, n, 4, h, h, blocks, 3 * (int64_t)h, slabs,
                                        slab_bytes, sa));
     }
-    GS_TRY(dgrad(st, dpq, 4 * (int64_t)h, wxpqT_l + h, h5, dx, h, n, h, 4 * h, dx_other));
+    // dx_in = (skip ? dx : 0) + [du | dP | dQ] [W_x,0 ; W_x,1 | W_pq]^T : K = 5F in one pass
+    {
+      GemmBatchEntry e{wxpqT_l, nullptr, dx_other, 0};
+      LinearEpilogue epi;
+      epi.residual = d->skip_connections ? dx : nullptr;
+      epi.ldr = h;
+      GS_TRY(launch_linear_concat2(du, h, h, dpq, 4 * (int64_t)h, 4 * h, e, h5, h, n, h, epi, st));
+      float *tsw = dx;
+      dx = dx_other;
+      dx_other = tsw;
+    }
     // dx now holds dL/dx_l; dx_other is free again.  The layer's last gradient is written by the side stream (which
     // has waited for this layer's BatchNorm backward, the only main-stream writer of the segment).
     GS_TRY(segment_done(1 + (L - 1 - l), sa));

@@ -109,6 +109,10 @@ __device__ __forceinline__ f32x4 gs_relu4(f32x4 v) {
 int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const GemmBatchEntry *entries,
                   int64_t ldw, int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi,
                   hipStream_t stream, int cfg = -1 /* tile configuration, -1 = measured heuristic */);
+// out = [a0 | a1] W^T (+ residual): a0 [m,k0], a1 [m,k1], W [n_out, k0 + k1]; k0 a multiple of 32
+int launch_linear_concat2(const float *a0, int64_t lda0, int k0, const float *a1, int64_t lda1, int k1,
+                          const GemmBatchEntry &entry, int64_t ldw, int64_t ldo, int64_t m, int n_out,
+                          const LinearEpilogue &epi, hipStream_t stream);
 
 int launch_pna_update(const float *x, const float *agg, const float *log_amp, const float *log_att,
                       const float *avg_deg_log, int64_t n, int hidden, const GemmBatchEntry *entries /*2*/,

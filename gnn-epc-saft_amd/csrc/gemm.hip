@@ -152,6 +152,34 @@ struct EdgeA {
   }
 };
 
+// Two row-major matrices side by side, A = [A0 | A1] (the backward's merged input-gradient GEMM
+// dx = [du | dPQ] [W_x | W_pq]^T: one pass instead of two chained residual GEMMs).  k0 is a multiple of BK.
+struct Concat2A {
+  const float *a0;
+  const float *a1;
+  int64_t lda0, lda1, m;
+  int k0, k;
+  struct Row {
+    const float *p0;
+    const float *p1;
+  };
+  struct Raw {
+    f32x4 v;
+  };
+  __device__ __forceinline__ TileInfo tile(int bx, int bm) const { return gs_plain_tile(bx, bm, m); }
+  __device__ __forceinline__ int64_t out_row(const TileInfo &t, int lr) const { return t.row0 + lr; }
+  __device__ __forceinline__ Row row(int64_t r, int64_t) const { return Row{a0 + r * lda0, a1 + r * lda1 - k0}; }
+  __device__ __forceinline__ Raw load(const Row &r, int kt0, int c) const {
+    const int kk = kt0 + c;
+    const float *p = kt0 < k0 ? r.p0 : r.p1;  // wave-uniform
+    return Raw{gs_ld4(p + (kk < k ? kk : kt0))};
+  }
+  __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &, int kt0, int c) const {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    return (kt0 + c < k) ? w.v : zero;
+  }
+};
+
 // Degree-folded PNAConv update: rows are grouped by in-degree (tile table from csr.hip), so
 // the three degree scalers are folded into per-degree weights and K shrinks from 13F to 5F:
 //   u_t[i] = [W_x | W_id + amp(d) W_amp + att(d) W_att]_t(d_i)  .  cat[x_i, A_t[i]]
@@ -627,6 +655,25 @@ int launch_linear_degree_tiled(const float *a, int64_t lda, const int32_t *perm,
   EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
   return launch_cfg<PermPlainA, false, false, false>(ap, nbatch, b, ldw, ldo, n, n_out, k, ea, stream,
                                                      tiled_cfg_for(hidden), max_tiles);
+}
+
+int launch_linear_concat2(const float *a0, int64_t lda0, int k0, const float *a1, int64_t lda1, int k1,
+                          const GemmBatchEntry &entry, int64_t ldw, int64_t ldo, int64_t m, int n_out,
+                          const LinearEpilogue &epi, hipStream_t stream) {
+  GS_REQUIRE(a0 != nullptr && a1 != nullptr, GNNSAFT_ERR_NULL);
+  GS_REQUIRE((lda0 % 4) == 0 && (lda1 % 4) == 0 && k0 >= BK && (k0 % BK) == 0 && k1 >= 4 && (k1 % 4) == 0 &&
+                 (reinterpret_cast<uintptr_t>(a0) & 15) == 0 && (reinterpret_cast<uintptr_t>(a1) & 15) == 0,
+             GNNSAFT_ERR_SHAPE);
+  Concat2A ap{a0, a1, lda0, lda1, m, k0, k0 + k1};
+  GS_REQUIRE(epi.stats == nullptr && epi.scale == nullptr, GNNSAFT_ERR_UNSUPPORTED);
+  GS_REQUIRE(entry.w != nullptr && entry.out != nullptr && (ldw % 4) == 0 && m >= 0 && n_out >= 1, GNNSAFT_ERR_SHAPE);
+  if (m == 0) return GNNSAFT_OK;
+  GemmBatch b;
+  for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entry;
+  EpiArgs ea{nullptr, nullptr, epi.relu_out, epi.residual, epi.ldr, nullptr, epi.residual_is_mask};
+  if (epi.residual != nullptr)
+    return launch_cfg<Concat2A, false, false, true>(ap, 1, b, ldw, ldo, m, n_out, k0 + k1, ea, stream);
+  return launch_cfg<Concat2A, false, false, false>(ap, 1, b, ldw, ldo, m, n_out, k0 + k1, ea, stream);
 }
 
 }  // namespace gs

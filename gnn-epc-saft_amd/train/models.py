@@ -270,10 +270,16 @@ class PNAPCSAFT(nn.Module):
             raise NotImplementedError("dropout > 0 in training mode is not implemented (the reference always "
                                       "trains with dropout 0.0: train/utils.py:57-69, configs/default.py:41)")
 
-    def _needs_grad(self) -> bool:
-        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+    def _trainable(self, weights: List[torch.Tensor]) -> List[torch.Tensor]:
+        """Parameters of the weight table that require a gradient (every parameter of the module is in the table;
+        ``self.parameters()`` walks the module tree through ~90 generator frames, 0.25 ms per call)."""
+        return [t for t in weights if isinstance(t, nn.Parameter) and t.requires_grad]
 
-    def _launch(self, data, target: Optional[torch.Tensor], tape: bool):
+    def _needs_grad(self) -> bool:
+        return torch.is_grad_enabled() and any(isinstance(t, nn.Parameter) and t.requires_grad
+                                               for t in self._weight_tensors())
+
+    def _launch(self, data, target: Optional[torch.Tensor], tape: bool, weights: Optional[List[torch.Tensor]] = None):
         """One gnnsaft_forward call.  Returns (pred, loss3, ctx) where ctx holds what gnnsaft_backward needs
         when ``tape`` is set (the workspace doubles as the tape and is then private to this call)."""
         x = data.x
@@ -312,7 +318,8 @@ class PNAPCSAFT(nn.Module):
             raise ValueError("x / edge_attr column counts do not match the embedding tables")
         if self.training and (n < 2 or g < 2):
             raise ValueError("Expected more than 1 value per channel when training")  # torch BatchNorm1d
-        weights = self._weight_tensors()
+        if weights is None:
+            weights = self._weight_tensors()
         fdtype = weights[0].dtype
         for t in weights:
             if t.device != dev or not t.is_contiguous():
@@ -375,7 +382,7 @@ class PNAPCSAFT(nn.Module):
         check(rc, "gnnsaft_forward")
         ctx = None
         if tape:
-            ctx = dict(desc=desc, weights=weights, x=x, batch=batch, n=n, e=e, g=g, ws=ws, ws_ptr=ws_ptr,
+            ctx = dict(desc=desc, weights=weights, wtab=wtab, x=x, batch=batch, n=n, e=e, g=g, ws=ws, ws_ptr=ws_ptr,
                        ws_bytes=ws_bytes, dev=dev)
         return out, loss, ctx
 
@@ -446,14 +453,25 @@ class PNAPCSAFT(nn.Module):
         nw = len(weights)
         # one flat buffer, gradients are views into it (one allocation; also the layout a flat all-reduce wants);
         # zero-filled so that the alignment gaps hold no garbage for whoever consumes the buffer whole
-        sizes = [t.numel() if (t.dtype == torch.float32 and isinstance(t, nn.Parameter)) else 0 for t in weights]
-        flat = torch.zeros(sum((s + 63) // 64 * 64 for s in sizes), dtype=torch.float32, device=dev)
-        grads, off = [], 0
+        f32 = torch.float32
+        sizes = [t.numel() if (t.dtype == f32 and isinstance(t, nn.Parameter)) else 0 for t in weights]
+        total = 0
+        for s_ in sizes:
+            total += (s_ + 63) // 64 * 64
+        flat = torch.zeros(total, dtype=f32, device=dev)
+        base = flat.data_ptr()
+        grads, ptrs, off = [], [], 0
         for t, sz in zip(weights, sizes):
-            grads.append(flat[off:off + sz].view(t.shape) if sz else None)
-            off += (sz + 63) // 64 * 64
-        wtab = (ctypes.c_void_p * nw)(*[t.data_ptr() for t in weights])
-        gtab = (ctypes.c_void_p * nw)(*[None if g is None else g.data_ptr() for g in grads])
+            if sz:
+                # one op per view (slice + view would be two; ~70 views per step)
+                grads.append(flat.as_strided(t.shape, t.stride(), off))
+                ptrs.append(base + 4 * off)
+                off += (sz + 63) // 64 * 64
+            else:
+                grads.append(None)
+                ptrs.append(None)
+        wtab = ctx["wtab"]
+        gtab = (ctypes.c_void_p * nw)(*ptrs)
         need = lib.gnnsaft_backward_scratch_bytes(ctypes.byref(desc), ctx["n"], ctx["e"], ctx["g"])
         scratch = torch.empty(need + 256, dtype=torch.uint8, device=dev)
         sp = (scratch.data_ptr() + 255) // 256 * 256
@@ -539,9 +557,11 @@ class PNAPCSAFT(nn.Module):
     def forward(self, data) -> torch.Tensor:
         """models.py:105-135.  ``data``: anything with ``x``, ``edge_index``, ``edge_attr`` and optionally
         ``batch`` / ``num_graphs`` attributes (PyG ``Data`` / ``Batch``)."""
-        if self._needs_grad():
-            params = [p for p in self.parameters() if p.requires_grad]
-            return _PNAForwardFunction.apply(self, data, *params)
+        if torch.is_grad_enabled():
+            weights = self._weight_tensors()
+            params = self._trainable(weights)
+            if params:
+                return _PNAForwardFunction.apply(self, data, weights, *params)
         return self._launch(data, None, tape=False)[0]
 
     def input_error_flags(self) -> int:
@@ -566,8 +586,8 @@ class _PNAForwardFunction(torch.autograd.Function):
     """Autograd node of the whole network: forward = gnnsaft_forward (tape kept), backward = gnnsaft_backward."""
 
     @staticmethod
-    def forward(ctx, module, data, *params):
-        out, _, tape = module._launch(data, None, tape=True)
+    def forward(ctx, module, data, weights, *params):
+        out, _, tape = module._launch(data, None, tape=True, weights=weights)
         ctx.module, ctx.tape, ctx.params = module, tape, params
         return out
 
@@ -584,8 +604,8 @@ class _PNAForwardFunction(torch.autograd.Function):
             # AccumulateGrad clone each one (~50 copy launches) and scatter them over separate allocations.
             for p, g in zip(ctx.params, out):
                 p.grad = g
-            return (None, None) + (None,) * len(out)
-        return (None, None) + tuple(out)   # accumulate into existing .grad the autograd way
+            return (None, None, None) + (None,) * len(out)
+        return (None, None, None) + tuple(out)   # accumulate into existing .grad the autograd way
 
 
 class _MapeFunction(torch.autograd.Function):
