@@ -95,6 +95,9 @@ SIGNATURES = {
                                           P]),
     "gnnsaft_adamw_step": (c_int32, [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
                                      c_float, P]),
+    "gnnsaft_adamw_args_floats": (c_int32, []),
+    "gnnsaft_adamw_args": (c_int32, [c_float, c_float, c_float, c_float, c_float, c_int64, c_float, P]),
+    "gnnsaft_adamw_step_dev": (c_int32, [P, P, P, P, P, c_int64, P, P]),
     "gnnsaft_sgd_step": (c_int32, [P, P, P, c_int64, c_float, c_float, c_float, c_int32, c_float, P]),
     "gnnsaft_aux_create": (c_int32, [POINTER(c_void_p)]),
     "gnnsaft_aux_destroy": (None, [P]),
@@ -103,6 +106,8 @@ SIGNATURES = {
                                    c_int64, c_int64, P, P, c_size_t, P, c_size_t, POINTER(c_void_p), P, P]),
     "gnnsaft_mape_backward": (c_int32, [P, P, c_int64, c_int32, P, P, P]),
     "gnnsaft_wgrad_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "gnnsaft_debug_linear_wgrad": (c_int32, [P, c_int64, P, c_int64, c_int64, c_int32, c_int32, P, c_int64, P, c_size_t,
+                                             c_int32, c_int32, c_int64, P]),
     "gnnsaft_linear_wgrad": (c_int32, [P, c_int64, P, c_int64, c_int32, c_int64, c_int32, c_int32, P, c_int64, c_int32,
                                        P, P, c_size_t, P]),
     "gnnsaft_eval_pack_bytes": (c_size_t, [POINTER(ModelDesc), c_int32]),

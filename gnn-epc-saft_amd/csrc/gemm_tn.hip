@@ -172,6 +172,123 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dy, i
   }
 }
 
+// ---- wide variant: WN x WK waves, every wave owns a 64 x 64 block of the output (2 x 2 MFMA tiles, four independent
+// accumulators), so a workgroup covers 64 WN x 64 WK of dW and every staged operand element feeds 64 WK (dY) or
+// 64 WN (A) multiply-adds instead of 64: with 4 x 4 waves (the register file of a CU) a [256, 256] gradient is one
+// workgroup tile and both operands are read exactly once.  Measured (tools/tn_tune.py, MI355X): 4 x 4 wins where the
+// problem is large -- C3 (164 k rows): [256,256] 267 -> 229 us, [1024,256] 964 -> 788 us (94 / 109 TFLOP/s) -- and
+// every wide grid LOSES on the 10-20 k row problems of C2 / C5 (fewer, longer waves per CU hide less latency:
+// [128,128] 27 -> 33 us), so launch_tn uses it for large problems only.
+template <int WN, int WK, class AProv, bool Y_CLASS>
+__global__ __launch_bounds__(64 * WN * WK) void k_gemm_tn_wide(const float *__restrict__ dy, int64_t ldy, AProv ap,
+                                                               int64_t m, int n_out, int k, float *__restrict__ slabs,
+                                                               int64_t rows_per_z, TnDirect direct) {
+  constexpr int TN_ = 64 * WN, TK_ = 64 * WK;
+  constexpr int LDY = TN_ + 4, LDA = TK_ + 4;
+  constexpr int YL = 8 / WK, AL = 8 / WN;              // float4 loads per thread and stage
+  constexpr int STAGE = kTnBK * (LDY + LDA);
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][ dy 32 x LDY | a 32 x LDA ]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / WK, wk = wave % WK;
+  const int n0 = blockIdx.y * TN_, k0 = blockIdx.x * TK_;
+  const int64_t m_beg = (int64_t)blockIdx.z * rows_per_z;
+  int64_t m_end = m_beg + rows_per_z;
+  if (m_end > m) m_end = m;
+
+  const int yr = tid / (16 * WN), yc = (tid % (16 * WN)) * 4;   // + j * 4 WK rows
+  const int ar = tid / (16 * WK), ac = (tid % (16 * WK)) * 4;   // + j * 4 WN rows
+  f32x4 ry[YL], ra[AL];
+  auto fetch = [&](int64_t mrow0) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < YL; ++j) {
+      int64_t mm = mrow0 + yr + j * 4 * WK;
+      const bool ok = mm < m_end;
+      mm = ok ? mm : m_end - 1;
+      const int nn = n0 + yc;
+      f32x4 vy;
+      if (Y_CLASS) {
+        const int c = reinterpret_cast<const int32_t *>(dy)[mm] - nn;
+        vy = f32x4{c == 0 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, c == 2 ? 1.f : 0.f, c == 3 ? 1.f : 0.f};
+      } else {
+        vy = gs_ld4(dy + mm * ldy + (nn < n_out ? nn : 0));
+      }
+      ry[j] = (ok && nn < n_out) ? vy : zero;  // rows past the chunk contribute nothing
+    }
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+      int64_t mm = mrow0 + ar + j * 4 * WN;
+      const bool ok = mm < m_end;
+      mm = ok ? mm : m_end - 1;
+      const f32x4 va = ap.load(mm, k0 + ac);
+      ra[j] = ok ? va : zero;
+    }
+  };
+  auto stash = [&](int buf) {
+    float *ys = lds + buf * STAGE;
+    float *as = ys + kTnBK * LDY;
+#pragma unroll
+    for (int j = 0; j < YL; ++j) gs_st4(ys + (yr + j * 4 * WK) * LDY + yc, ry[j]);
+#pragma unroll
+    for (int j = 0; j < AL; ++j) gs_st4(as + (ar + j * 4 * WN) * LDA + ac, ra[j]);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int64_t steps = (m_end - m_beg + kTnBK - 1) / kTnBK;
+  fetch(m_beg);
+  stash(0);
+  __syncthreads();
+  for (int64_t s = 0; s < steps; ++s) {
+    fetch(m_beg + (s + 1) * kTnBK);  // unconditional: rows past the slab come back as zeros
+    const float *ys = lds + (s & 1) * STAGE + wn * 64 + (lane & 31);
+    const float *as = lds + (s & 1) * STAGE + kTnBK * LDY + wk * 64 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < kTnBK / 2; ++q) {
+      const int row = 2 * q + (lane >> 5);
+      const float y0 = ys[row * LDY], y1 = ys[row * LDY + 32];
+      const float a0 = as[row * LDA], a1 = as[row * LDA + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, a0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, a1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y1, a0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y1, a1, acc[1][1], 0, 0, 0);
+    }
+    stash((s + 1) & 1);
+    __syncthreads();
+  }
+  // C/D: col = lane & 31 (k), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (n)
+  float *slab = slabs + (int64_t)blockIdx.z * n_out * (int64_t)k;
+  const bool full = n0 + TN_ <= n_out && k0 + TK_ <= k;  // block-uniform: unguarded stores, issued back to back
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kc = k0 + wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nr = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (direct.on) {
+          if (nr < n_out && kc < k) {
+            const int64_t blk = nr / direct.so.rows_per_block;
+            float *o = direct.so.base[blk] + (nr - blk * direct.so.rows_per_block) * direct.ld_out + kc;
+            *o = direct.accumulate ? *o + acc[i][j][r] : acc[i][j][r];
+          }
+        } else if (full) {
+          slab[(int64_t)nr * k + kc] = acc[i][j][r];
+        } else if (nr < n_out && kc < k) {
+          slab[(int64_t)nr * k + kc] = acc[i][j][r];
+        }
+      }
+    }
+}
+
 // ---- post_nns weight gradient through the degree tiles (the backward twin of the degree-folded update).
 // dW_t = du_t^T cat[x, A_t, amp A_t, att A_t] has K = 13F, but amp / att are constant over a degree tile, so a
 // workgroup contracts only [x | A_t] (K = 5F) and, after every tile (rows of ONE in-degree), folds the tile's
@@ -450,29 +567,75 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float *__restrict__ 
   }
 }
 
+// wave grid for an [n_out, k] gradient over m rows: 4 x 4 waves of 64 x 64 for large problems (see above), else the
+// 64 x 64 four-wave kernel
+static inline int tn_waves(int64_t m, int n_out, int k) { return (m >= 32768 && n_out > 128 && k > 128) ? 4 : 1; }
+
+template <int WN, int WK, class AProv, bool Y_CLASS>
+static void launch_tn_wide(const float *dy, int64_t ldy, const AProv &ap, int64_t m, int n_out, int k, float *slabs,
+                           int64_t rows_per_z, int64_t chunks, const TnDirect &direct, hipStream_t st) {
+  constexpr int TN_ = 64 * WN, TK_ = 64 * WK;
+  constexpr size_t lds_bytes = 2 * (size_t)kTnBK * (TN_ + TK_ + 8) * 4;
+  static const bool attr = [] {   // > 64 KB of dynamic LDS has to be requested once per kernel
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_wide<WN, WK, AProv, Y_CLASS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+  }();
+  (void)attr;
+  const dim3 grid((unsigned)gs_ceil_div(k, TK_), (unsigned)gs_ceil_div(n_out, TN_), (unsigned)chunks);
+  hipLaunchKernelGGL((k_gemm_tn_wide<WN, WK, AProv, Y_CLASS>), grid, dim3(64 * WN * WK), lds_bytes, st, dy, ldy, ap, m,
+                     n_out, k, slabs, rows_per_z, direct);
+}
+
+// rows per slab and slab count: ~one resident set of workgroups, at least two 32-row stages each
+static inline void tn_chunking(int64_t m, int64_t tiles, int64_t resident, int64_t &rows_per_z, int64_t &chunks) {
+  chunks = gs_ceil_div(resident, tiles);
+  const int64_t max_chunks = gs_ceil_div(m, 2 * kTnBK);
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  rows_per_z = gs_ceil_div(gs_ceil_div(m, chunks), kTnBK) * kTnBK;
+  chunks = gs_ceil_div(m, rows_per_z);
+}
+
 template <class AProv, bool Y_CLASS = false>
 static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, int n_out, int k, float *out,
                      int64_t ld_out, int accumulate, float *slabs, size_t slab_bytes, hipStream_t st,
-                     const SlabOut *scatter = nullptr) {
+                     const SlabOut *scatter = nullptr, int force_wn = 0, int force_wk = 0, int64_t force_chunks = 0) {
   GS_REQUIRE(dy && (out || scatter) && slabs, GNNSAFT_ERR_NULL);
   GS_REQUIRE(m >= 1 && n_out >= 1 && k >= 4 && (k % 4) == 0 && (Y_CLASS || (ldy % 4) == 0) && (ld_out % 4) == 0,
              GNNSAFT_ERR_SHAPE);
-  // number of row slabs: enough workgroups to fill the chip (~1024), never finer than kTnChunk rows
-  const int64_t tiles = gs_ceil_div(k, kTnTile) * gs_ceil_div(n_out, kTnTile);
-  int64_t chunks = gs_ceil_div(1024, tiles);
-  const int64_t max_chunks = gs_ceil_div(m, kTnChunk);
-  if (chunks > max_chunks) chunks = max_chunks;
-  if (chunks < 1) chunks = 1;
-  int64_t rows_per_z = gs_ceil_div(gs_ceil_div(m, chunks), kTnBK) * kTnBK;
-  chunks = gs_ceil_div(m, rows_per_z);
+  int wn = force_wn > 0 ? force_wn : tn_waves(m, n_out, k), wk = force_wk > 0 ? force_wk : tn_waves(m, n_out, k);
+  GS_REQUIRE((wn == 1 && wk == 1) || (wn == 2 && wk == 2) || (wn == 4 && (wk == 2 || wk == 4)), GNNSAFT_ERR_UNSUPPORTED);
+  const bool wide = wn * wk > 1;
+  const int tn_ = wide ? 64 * wn : kTnTile, tk_ = wide ? 64 * wk : kTnTile;
+  const int64_t tiles = gs_ceil_div(k, tk_) * gs_ceil_div(n_out, tn_);
+  // workgroups one CU holds (LDS 160 KB; the 64 x 64 kernel: four)
+  const int64_t per_cu = wide ? (160 * 1024) / (2 * kTnBK * (tn_ + tk_ + 8) * 4) : 4;
+  int64_t rows_per_z, chunks;
+  tn_chunking(m, tiles, 256 * (per_cu > 4 ? 4 : per_cu), rows_per_z, chunks);
+  if (force_chunks > 0) {
+    rows_per_z = gs_ceil_div(gs_ceil_div(m, force_chunks), kTnBK) * kTnBK;
+    chunks = gs_ceil_div(m, rows_per_z);
+  }
   GS_REQUIRE(slab_bytes >= (size_t)chunks * n_out * k * 4, GNNSAFT_ERR_WORKSPACE);
-  const dim3 grid((unsigned)gs_ceil_div(k, kTnTile), (unsigned)gs_ceil_div(n_out, kTnTile), (unsigned)chunks);
   const int64_t per_slab = (int64_t)n_out * k;
   SlabOut so{{out, out, out, out}, (int64_t)1 << 40};
   if (scatter != nullptr) so = *scatter;
   TnDirect direct{so, ld_out, chunks == 1 ? 1 : 0, accumulate};
-  hipLaunchKernelGGL((k_gemm_tn<AProv, Y_CLASS>), grid, dim3(256), 0, st, dy, ldy, ap, m, n_out, k, slabs, rows_per_z,
-                     direct);
+  switch (wn * 8 + wk) {
+#define GS_TN_CASE(WN_, WK_)                                                                                  \
+  case WN_ * 8 + WK_:                                                                                         \
+    launch_tn_wide<WN_, WK_, AProv, Y_CLASS>(dy, ldy, ap, m, n_out, k, slabs, rows_per_z, chunks, direct, st); \
+    break;
+    GS_TN_CASE(2, 2)
+    GS_TN_CASE(4, 2)
+    GS_TN_CASE(4, 4)
+#undef GS_TN_CASE
+    default: {
+      const dim3 grid((unsigned)gs_ceil_div(k, kTnTile), (unsigned)gs_ceil_div(n_out, kTnTile), (unsigned)chunks);
+      hipLaunchKernelGGL((k_gemm_tn<AProv, Y_CLASS>), grid, dim3(256), 0, st, dy, ldy, ap, m, n_out, k, slabs,
+                         rows_per_z, direct);
+    }
+  }
   if (chunks == 1) {   // one slab: the GEMM wrote the result itself
     GS_CHECK_LAUNCH();
     return GNNSAFT_OK;
@@ -484,7 +647,10 @@ static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, i
 }
 
 size_t tn_slab_bytes(int64_t m, int n_out, int k) {
-  return (size_t)gs_ceil_div(m > 0 ? m : 1, kTnChunk) * (size_t)n_out * (size_t)k * 4;
+  // upper bound of launch_tn's slab count: at most 1024 workgroups' worth, never finer than 64 rows
+  int64_t chunks = gs_ceil_div(m > 0 ? m : 1, 2 * kTnBK);
+  if (chunks > 1024) chunks = 1024;
+  return (size_t)chunks * (size_t)n_out * (size_t)k * 4;
 }
 
 int launch_wgrad_plain(const float *dy, int64_t ldy, const float *a, int64_t lda, int relu_a, int64_t m, int n_out,
@@ -626,6 +792,18 @@ int launch_colsum_blocks(const float *a, int64_t lda, int64_t m, int num_blocks,
 }
 
 }  // namespace gs
+
+// tuning aid (tools/tn_tune.py): the weight-gradient GEMM with an explicit wave grid (wn x wk waves of 64 x 64 each;
+// 1 x 1 = the 64 x 64 four-wave kernel) and slab count; 0 = the library's own choice.  No global state.
+extern "C" int gnnsaft_debug_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t lda, int64_t m,
+                                          int32_t n_out, int32_t k, float *dw, int64_t ld_dw, void *scratch,
+                                          size_t scratch_bytes, int32_t wn, int32_t wk, int64_t chunks,
+                                          gnnsaft_stream_t stream) {
+  GS_REQUIRE(a != nullptr && (lda % 4) == 0, GNNSAFT_ERR_SHAPE);
+  gs::TnPlain ap{a, lda, 0, k};
+  return gs::launch_tn(dy, ldy, ap, m, n_out, k, dw, ld_dw, 0, static_cast<float *>(scratch), scratch_bytes,
+                       static_cast<hipStream_t>(stream), nullptr, wn, wk, chunks);
+}
 
 extern "C" size_t gnnsaft_wgrad_scratch_bytes(int64_t m, int32_t n_out, int32_t k) {
   return gs::tn_slab_bytes(m, n_out, k);

@@ -7,6 +7,7 @@
 // Arithmetic follows torch's single-tensor reference update op for op (same f32 rounding points),
 // -ffp-contract=off keeps hipcc from fusing what torch leaves unfused.
 #include <cmath>
+#include <cstring>
 
 #include "common.hpp"
 
@@ -35,9 +36,9 @@ __device__ __forceinline__ float adamw_one(float &p, float g, float &m, float &v
   return p;
 }
 
-__global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const float *__restrict__ g,
-                                               float *__restrict__ m, float *__restrict__ v,
-                                               float *__restrict__ vmax, int64_t count, AdamArgs a) {
+__device__ __forceinline__ void adamw_span(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                           float *__restrict__ v, float *__restrict__ vmax, int64_t count,
+                                           const AdamArgs &a) {
   const bool amsgrad = vmax != nullptr;
   const int64_t n4 = count >> 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -67,6 +68,22 @@ __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const floa
   }
 }
 
+__global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const float *__restrict__ g,
+                                               float *__restrict__ m, float *__restrict__ v,
+                                               float *__restrict__ vmax, int64_t count, AdamArgs a) {
+  adamw_span(p, g, m, v, vmax, count, a);
+}
+
+// the step's scalars (learning rate, bias corrections: they change every step) read from DEVICE memory, so that the
+// launch can sit in a captured hipGraph and be replayed with new values (gnnsaft_adamw_args writes them)
+__global__ __launch_bounds__(256) void k_adamw_dev(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v,
+                                                   float *__restrict__ vmax, int64_t count,
+                                                   const AdamArgs *__restrict__ ap) {
+  const AdamArgs a = *ap;
+  adamw_span(p, g, m, v, vmax, count, a);
+}
+
 // torch.optim.SGD(momentum, nesterov=True, dampening=0): g += wd p; buf = first ? g : mu buf + g; g += mu buf; p -= lr g
 __global__ __launch_bounds__(256) void k_sgd_nesterov(float *__restrict__ p, const float *__restrict__ g,
                                                       float *__restrict__ buf, int64_t count, float lr, float mu,
@@ -92,24 +109,60 @@ static unsigned optim_grid(int64_t items) {
 
 }  // namespace gs
 
-extern "C" int gnnsaft_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
-                                  float *max_exp_avg_sq, int64_t count, float lr, float beta1, float beta2, float eps,
-                                  float weight_decay, int64_t step, float grad_scale, gnnsaft_stream_t stream) {
+static gs::AdamArgs adam_args(float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                              float grad_scale) {
+  // bias corrections in double on the host, as torch computes them from the Python-float step count
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  return gs::AdamArgs{lr, beta1, beta2, eps, weight_decay, grad_scale, (float)((double)lr / bc1), (float)std::sqrt(bc2),
+                      (float)(1.0 - (double)lr * (double)weight_decay), (float)(1.0 - (double)beta1),
+                      (float)(1.0 - (double)beta2)};
+}
+
+static int adam_check(const float *param, const float *grad, const float *exp_avg, const float *exp_avg_sq,
+                      const float *max_exp_avg_sq, int64_t count) {
   GS_REQUIRE(param && grad && exp_avg && exp_avg_sq, GNNSAFT_ERR_NULL);
-  GS_REQUIRE(count >= 0 && step >= 1, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(count >= 0, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
                reinterpret_cast<uintptr_t>(exp_avg) | reinterpret_cast<uintptr_t>(exp_avg_sq) |
                reinterpret_cast<uintptr_t>(max_exp_avg_sq)) & 15) == 0,
              GNNSAFT_ERR_SHAPE);
+  return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                  float *max_exp_avg_sq, int64_t count, float lr, float beta1, float beta2, float eps,
+                                  float weight_decay, int64_t step, float grad_scale, gnnsaft_stream_t stream) {
+  if (const int rc = adam_check(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, count); rc != GNNSAFT_OK) return rc;
+  GS_REQUIRE(step >= 1, GNNSAFT_ERR_SHAPE);
   if (count == 0) return GNNSAFT_OK;
-  // bias corrections in double on the host, as torch computes them from the Python-float step count
-  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-  gs::AdamArgs a{lr, beta1, beta2, eps, weight_decay, grad_scale, (float)((double)lr / bc1), (float)std::sqrt(bc2),
-                 (float)(1.0 - (double)lr * (double)weight_decay), (float)(1.0 - (double)beta1),
-                 (float)(1.0 - (double)beta2)};
+  const gs::AdamArgs a = adam_args(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
   hipLaunchKernelGGL(gs::k_adamw, dim3(gs::optim_grid(count / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, count, a);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+extern "C" int32_t gnnsaft_adamw_args_floats(void) { return (int32_t)(sizeof(gs::AdamArgs) / sizeof(float)); }
+
+extern "C" int gnnsaft_adamw_args(float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                  float grad_scale, float *args_host) {
+  GS_REQUIRE(args_host != nullptr, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(step >= 1, GNNSAFT_ERR_SHAPE);
+  const gs::AdamArgs a = adam_args(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+  std::memcpy(args_host, &a, sizeof(a));
+  return GNNSAFT_OK;
+}
+
+extern "C" int gnnsaft_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                      float *max_exp_avg_sq, int64_t count, const float *args_dev,
+                                      gnnsaft_stream_t stream) {
+  if (const int rc = adam_check(param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, count); rc != GNNSAFT_OK) return rc;
+  GS_REQUIRE(args_dev != nullptr && (reinterpret_cast<uintptr_t>(args_dev) & 3) == 0, GNNSAFT_ERR_NULL);
+  if (count == 0) return GNNSAFT_OK;
+  hipLaunchKernelGGL(gs::k_adamw_dev, dim3(gs::optim_grid(count / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     param, grad, exp_avg, exp_avg_sq, max_exp_avg_sq, count,
+                     reinterpret_cast<const gs::AdamArgs *>(args_dev));
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }

@@ -148,6 +148,58 @@ def training_loop(lit: PNApcsaftL, batches: Iterable, max_steps: Optional[int] =
     return history
 
 
+class GraphedTrainingStep:
+    """One training step on a FIXED batch -- ``training_step`` (gnnsaft_forward with tape + MAPE), ``backward``
+    (gnnsaft_mape_backward + gnnsaft_backward on two streams), fused AdamW step -- captured once in a hipGraph and
+    replayed: ~140 launches and ~1.5 ms of host work per step become one graph launch.  Every replay trains on the
+    SAME batch object (same tensors; their contents may be overwritten in place between replays), so this serves
+    fixed-shape training and measurement, not a loader of ragged batches.
+
+    The optimizer must be a ``FusedAdamW`` (it is switched to ``capturable``: learning rate and bias corrections are
+    read from device memory that a captured copy refreshes from a pinned host buffer); ``scheduler.step()`` runs
+    after every replay, on the host, as Lightning's ``interval="step"`` does.  ``warmup`` eager steps run first, on a
+    side stream, as torch's whole-network capture recipe requires -- they are real training steps."""
+
+    def __init__(self, lit: PNApcsaftL, optimizer, batch, scheduler=None, warmup: int = 3):
+        from .optim import FusedAdamW
+        if not isinstance(optimizer, FusedAdamW):
+            raise TypeError("GraphedTrainingStep needs this package's FusedAdamW (optimizer='adam')")
+        self.lit, self.opt, self.sched, self.batch = lit, optimizer, scheduler, batch
+        optimizer.capturable = True
+        dev = next(lit.parameters()).device
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(max(1, int(warmup))):
+                self._eager()
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)      # the captured backward then owns one static flat gradient buffer
+        with torch.cuda.graph(self.graph):
+            self.loss = lit.training_step(batch)
+            self.loss.backward()
+            optimizer.step()                       # records copy + kernel; counts nothing (prepare_replay does)
+
+    def _eager(self):
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.lit.training_step(self.batch)
+        loss.backward()
+        self.opt.step()
+        if self.sched is not None:
+            self.sched.step()
+        return loss
+
+    def __call__(self) -> torch.Tensor:
+        """One replay = one optimizer step; returns the (static) loss tensor of that step."""
+        self.opt.prepare_replay()
+        self.graph.replay()
+        if self.sched is not None:
+            self.sched.step()
+        return self.loss
+
+
 def _get(cfg, name, default):
     try:
         return _cfg(cfg, name)

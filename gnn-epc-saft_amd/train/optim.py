@@ -59,6 +59,8 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.grad_scale = 1.0          # set to 1 / world_size by the data-parallel loop (SUM all-reduce)
         self.on_parameters_rewritten = None   # callable: the step kernel writes parameters behind torch's version counters
         self._step_tensor = None
+        self.capturable = False              # FusedAdamW: per-step scalars from device memory (hipGraph capture)
+        self._args_host = self._args_dev = None
         self._adopt()
 
     # ---- flat parameter buffer
@@ -183,6 +185,29 @@ class FusedAdamW(_FlatOptimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad),
                          layout=layout)
 
+    # ---- hipGraph capture (train/loop.py::GraphedTrainingStep): the step's scalars live in device memory, refreshed
+    # from a pinned host buffer by a copy that is part of the graph
+    def _arg_buffers(self):
+        if self._args_host is None or self._args_dev.device != self._flat.device:
+            n = int(lib.gnnsaft_adamw_args_floats())
+            self._args_host = torch.zeros(n, dtype=torch.float32).pin_memory()
+            self._args_dev = torch.zeros(n, dtype=torch.float32, device=self._flat.device)
+        return self._args_host, self._args_dev
+
+    def _write_args(self, step: int) -> None:
+        g = self.param_groups[0]
+        host, _ = self._arg_buffers()
+        check(lib.gnnsaft_adamw_args(float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                     float(g["weight_decay"]), step, float(self.grad_scale), host.data_ptr()),
+              "gnnsaft_adamw_args")
+
+    def prepare_replay(self) -> None:
+        """Before every replay of a graph that holds a captured ``step()``: advance the step count and publish this
+        step's learning rate / bias corrections where the captured copy + kernel read them."""
+        if not self.capturable:
+            raise RuntimeError("prepare_replay() belongs to a capturable optimizer (opt.capturable = True)")
+        self._write_args(self._tick())
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -195,8 +220,19 @@ class FusedAdamW(_FlatOptimizer):
         grad = self._step_gradient()
         m, v = self._state_buffer("exp_avg"), self._state_buffer("exp_avg_sq")
         vmax = self._state_buffer("max_exp_avg_sq") if g["amsgrad"] else None
-        step = self._tick()
         stream = torch.cuda.current_stream(self._flat.device).cuda_stream
+        if self.capturable:
+            host, dev = self._arg_buffers()
+            if not torch.cuda.is_current_stream_capturing():
+                self._write_args(self._tick())          # eager use of a capturable optimizer
+            # (while capturing nothing runs and nothing is counted: prepare_replay() does both per replay)
+            dev.copy_(host, non_blocking=True)
+            with torch.cuda.device(self._flat.device):
+                check(lib.gnnsaft_adamw_step_dev(self._flat.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                                 None if vmax is None else vmax.data_ptr(), self._total,
+                                                 dev.data_ptr(), stream), "gnnsaft_adamw_step_dev")
+            return loss
+        step = self._tick()
         with torch.cuda.device(self._flat.device):
             check(lib.gnnsaft_adamw_step(self._flat.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
                                          None if vmax is None else vmax.data_ptr(), self._total, float(g["lr"]),

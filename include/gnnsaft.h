@@ -401,6 +401,12 @@ int gnnsaft_backward(const gnnsaft_model_desc *desc, const void *const *weights_
 int gnnsaft_mape_backward(const float *pred, const float *target, int64_t num_graphs,
                           int32_t num_para, const float *dloss, float *dpred,
                           gnnsaft_stream_t stream);
+/* tuning aid: gnnsaft_linear_wgrad with an explicit wave grid (wn x wk waves of 64 x 64 outputs, 1 x 1 = the    */
+/* 64 x 64 four-wave kernel) and slab count (0 = the library's choice)                                          */
+int gnnsaft_debug_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t lda, int64_t m,
+                               int32_t n_out, int32_t k, float *dw, int64_t ld_dw, void *scratch,
+                               size_t scratch_bytes, int32_t wn, int32_t wk, int64_t chunks,
+                               gnnsaft_stream_t stream);
 /* dW[n_out,k] (+)= dY^T A (deterministic slab reduction), dbias (+)= column sums of dY  */
 size_t gnnsaft_wgrad_scratch_bytes(int64_t m, int32_t n_out, int32_t k);
 int gnnsaft_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t lda, int32_t relu_a,
@@ -465,6 +471,15 @@ int gnnsaft_adamw_step(float *param, const float *grad, float *exp_avg, float *e
                        float *max_exp_avg_sq, int64_t count, float lr, float beta1, float beta2,
                        float eps, float weight_decay, int64_t step, float grad_scale,
                        gnnsaft_stream_t stream);
+/* The same step with its per-step scalars (learning rate, bias corrections) read from DEVICE memory, for a     */
+/* launch that lives in a captured hipGraph: gnnsaft_adamw_args writes the gnnsaft_adamw_args_floats() floats  */
+/* of step `step` into HOST memory (pinned: a captured host-to-device copy re-reads it at every replay).       */
+int32_t gnnsaft_adamw_args_floats(void);
+int gnnsaft_adamw_args(float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                       float grad_scale, float *args_host);
+int gnnsaft_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                           float *max_exp_avg_sq, int64_t count, const float *args_dev,
+                           gnnsaft_stream_t stream);
 int gnnsaft_sgd_step(float *param, const float *grad, float *momentum_buf, int64_t count, float lr,
                      float momentum, float weight_decay, int32_t first_step, float grad_scale,
                      gnnsaft_stream_t stream);

@@ -25,7 +25,9 @@ def test_wgrad_tn_kernel_matches_f64():
     import ctypes
     from gnn_epc_saft_amd._native import check, lib
     torch.manual_seed(0)
-    for m, n_out, k in [(3000, 64, 128), (1025, 128, 832), (60, 128, 128), (500, 3, 32)]:
+    # the 40 000-row case takes the wide kernel (4 x 4 waves of 64 x 64: one workgroup tile = the whole gradient)
+    for m, n_out, k in [(3000, 64, 128), (1025, 128, 832), (60, 128, 128), (500, 3, 32), (4100, 128, 128),
+                        (2500, 512, 128), (40000, 256, 192), (777, 60, 256), (1500, 100, 64)]:
         ld = (n_out + 3) // 4 * 4
         dy = torch.zeros(m, ld)
         dy[:, :n_out] = torch.randn(m, n_out)

@@ -214,3 +214,44 @@ def test_c5_standin_default_model_training_loop():
         want = oracle.double().eval()(probe)
     print(f"C5 stand-in: loss {hist[0][1]:.4f} -> {hist[-1][1]:.4f}; eval predictions of the trained model:")
     check_population(got, want32, want)
+
+
+def test_graphed_training_step_equals_eager_steps():
+    """GraphedTrainingStep (forward + backward + fused AdamW in one captured hipGraph, learning rate and bias
+    corrections refreshed through the captured host-to-device copy) against the same number of eager steps on the
+    same batch: the kernels and their order are the same, so parameters, optimizer state and BatchNorm statistics
+    must agree bit for bit."""
+    import gnn_epc_saft_amd as G
+    lit_a, batches, _ = _setup()
+    lit_b, _, _ = _setup()
+    batch = batches[0]
+    steps, warm = 7, 2
+
+    conf = lit_a.configure_optimizers()
+    opt_a, sched_a = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    lit_a.train()
+    losses_a = []
+    for _ in range(steps):
+        opt_a.zero_grad(set_to_none=True)
+        loss = lit_a.training_step(batch)
+        loss.backward()
+        opt_a.step()
+        sched_a.step()
+        losses_a.append(float(loss))
+
+    conf = lit_b.configure_optimizers()
+    opt_b, sched_b = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    lit_b.train()
+    graphed = G.GraphedTrainingStep(lit_b, opt_b, batch, scheduler=sched_b, warmup=warm)
+    losses_b = [float(graphed()) for _ in range(steps - warm)]
+    torch.cuda.synchronize()
+    assert losses_b == losses_a[warm:]
+    assert losses_b[-1] < losses_a[0]
+    assert sched_b.last_epoch == sched_a.last_epoch == steps
+    for (ka, va), (kb, vb) in zip(lit_a.state_dict().items(), lit_b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    sa, sb = opt_a.state_dict()["state"], opt_b.state_dict()["state"]
+    for i in sa:
+        assert float(sa[i]["step"]) == float(sb[i]["step"]) == steps
+        for key in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+            assert torch.equal(sa[i][key], sb[i][key]), (i, key)
