@@ -387,11 +387,32 @@ def main() -> None:
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt[0])
-        return {"what": "forward + MAPE + backward (all parameter gradients)" +
-                         (" + flat gradient all-reduce (RCCL)" if world > 1 else "") +
-                         " + fused AdamW(amsgrad) step + LR schedule step, eager",
-                 "steps": args.train_steps, "ms_per_step": el / args.train_steps * 1e3,
-                 "graphs_per_s": cfg["graphs"] * world * args.train_steps / el}
+        out = {"what": "forward + MAPE + backward (all parameter gradients)" +
+                       (" + flat gradient all-reduce (RCCL)" if world > 1 else "") +
+                       " + fused AdamW(amsgrad) step + LR schedule step, eager",
+               "steps": args.train_steps, "ms_per_step": el / args.train_steps * 1e3,
+               "graphs_per_s": cfg["graphs"] * world * args.train_steps / el}
+        if world == 1:
+            # the same step captured in ONE hipGraph (train/loop.py::GraphedTrainingStep): the eager figure above is
+            # bound by the host (~140 launches, ~1.5 ms of enqueue per step at C2), this one by the GPU
+            try:
+                import gnn_epc_saft_amd as G
+                with torch.cuda.stream(stream):
+                    graphed = G.GraphedTrainingStep(model, opt, ddev, scheduler=sched, warmup=2)
+                    for _ in range(3):
+                        graphed()
+                    barrier()
+                    t3 = time.perf_counter()
+                    for _ in range(args.train_steps):
+                        graphed()
+                    barrier()
+                    eg = time.perf_counter() - t3
+                out["hipgraph"] = {"what": "the same step replayed from one captured hipGraph (fixed batch)",
+                                   "steps": args.train_steps, "ms_per_step": eg / args.train_steps * 1e3,
+                                   "graphs_per_s": cfg["graphs"] * args.train_steps / eg}
+            except Exception as exc:  # noqa: BLE001
+                out["hipgraph"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        return out
 
     train = None
     if args.train_steps > 0:
