@@ -167,9 +167,13 @@ class PNAPCSAFT(nn.Module):
         # hipGraph replay of the step is 0.490 ms with it and 0.491 ms without (C2), and the graph executor does
         # not reliably run the two branches concurrently (profiles/r01_c2_graph_replay_timeline.txt).
         self.use_side_stream = os.environ.get("GNNSAFT_SIDE_STREAM", "0") == "1"
-        # gnnsaft_backward runs weight / bias gradients, edge-class sums and the edge-table chain on a side stream
-        # (forked from and joined into the current stream inside the call); False = one stream
-        self.backward_side_stream = os.environ.get("GNNSAFT_BACKWARD_SIDE_STREAM", "1") == "1"
+        # gnnsaft_backward can run weight / bias gradients, edge-class sums and the edge-table chain on a side stream
+        # (forked from and joined into the current stream inside the call).  True / False / None = decide per batch:
+        # the ~10 event records + waits per layer cost the host more than the overlap gives the GPU on small batches
+        # (measured, MI355X: C5 stand-in, 10 k nodes x 64 channels: 1.82 ms one stream, 2.3 ms two; C2, 20 k x 128:
+        # 1.97 ms one stream, 1.82 ms two), so the side stream is used from ~2 M node-channels up.
+        env = os.environ.get("GNNSAFT_BACKWARD_SIDE_STREAM", "auto")
+        self.backward_side_stream = None if env == "auto" else env == "1"
         # backward fast path: set .grad to views of the one flat gradient buffer when every .grad is None
         self.direct_grads = True
         self._profile = None  # gnnsaft_profile* (bench.py attaches one to time kernels with HIP events)
@@ -484,8 +488,10 @@ class PNAPCSAFT(nn.Module):
                 raise ValueError("gradient_segment_events must hold num_layers + 2 events")
             events = (ctypes.c_void_p * len(evs))(*[e.cuda_event for e in evs])
         with torch.cuda.device(dev):
-            aux = aux_for(dev.index if dev.index is not None else torch.cuda.current_device()) \
-                if self.backward_side_stream else None
+            two = self.backward_side_stream
+            if two is None:
+                two = ctx["n"] * desc.hidden >= 2_000_000
+            aux = aux_for(dev.index if dev.index is not None else torch.cuda.current_device()) if two else None
             rc = lib.gnnsaft_backward(ctypes.byref(desc), wtab, gtab, nw, ctx["x"].data_ptr(),
                                       None if ctx["batch"] is None else ctx["batch"].data_ptr(), ctx["n"], ctx["e"],
                                       ctx["g"], grad_out.data_ptr(), ctx["ws_ptr"], ctx["ws_bytes"], sp,
