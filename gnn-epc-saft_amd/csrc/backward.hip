@@ -551,15 +551,18 @@ struct BwdSizes {
 static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
   const size_t h = d->hidden, nn = p.n > 0 ? p.n : 1, ee = p.ep > 0 ? p.ep : 1, gg = p.g > 0 ? p.g : 1;
   const size_t rows = nn > gg ? nn : gg;
-  size_t slab = wgrad_post_folded_slab_bytes(p.tile_cap, pna_fold_tile_rows((int)h), (int)h);  // dW_post, both towers
+  // the slab arena holds the partial results of ONE layer's five reductions side by side (SlabQueue): post_nns
+  // weights of both towers, lin weights, the message weights' four [F,F] blocks, per-class sums, bias column sums
+  const size_t s1 = wgrad_post_folded_slab_bytes(p.tile_cap, pna_fold_tile_rows((int)h), (int)h);
   const size_t s2 = tn_slab_bytes(p.n, (int)h, 176 + 16);                 // one-hot (atom vocabulary rows)
   size_t s3 = tn_slab_bytes(rows, (int)(4 * h), (int)h);                 // message weights: four [F,F] blocks at once
   const size_t s3e = d->pre_layers > 1 ? tn_slab_bytes(ee, (int)h, (int)h) : 0;  // edge-row wgrads of extra pre layers
   s3 = s3 > s3e ? s3 : s3e;
   const size_t s4 = (size_t)p.combos <= (size_t)kClassGemmMax ? tn_slab_bytes(p.ep, (int)p.combos, (int)(2 * h)) : 0;
+  const size_t s5 = tn_slab_bytes(rows, (int)h, (int)h);                 // lin
+  const size_t s6 = (rows / 256 + 2) * h * 4;                            // column-sum partials
+  size_t slab = s1 + s3 + s4 + s5 + s6 + 8 * 256;
   slab = slab > s2 ? slab : s2;
-  slab = slab > s3 ? slab : s3;
-  slab = slab > s4 ? slab : s4;
   size_t tot = 0;
   auto add = [&](size_t b) { tot += gs_align_up(b, 256); };
   add(slab);
@@ -708,6 +711,11 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   float *wt_readout = sc.take<float>((size_t)p.nb * h * h);
   GS_REQUIRE(det != nullptr && wt_layers != nullptr && wt_readout != nullptr, GNNSAFT_ERR_WORKSPACE);
   const size_t slab_bytes = bs.slab;
+  SlabQueue sq;   // one layer's reductions, summed by one launch (side stream)
+  sq.base = slabs;
+  sq.cap = slab_bytes / 4;
+  // extra pre / post layers reduce on the spot through the head of the same buffer: no queue for them
+  SlabQueue *dq = (pl == 1 && q == 1) ? &sq : nullptr;
 
   auto transpose1 = [&](const float *in, int64_t ld_in, float *out, int64_t ld_out, int rows, int cols) {
     const float *i1[1] = {in};
@@ -884,11 +892,12 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     const int64_t h5 = 5 * (int64_t)h;
     // x_{l+1} = relu(bn(y)) + x_l : dy through BN+ReLU; the skip gradient stays in dx
     GS_TRY(bn_relu_backward(y_l, dx, stat, w.bn.gamma, w.bn.beta, n, h, G(i_bn), G(i_bn + 1), dy, bnpart, st));
-    // lin: weight gradient (side), input gradient (main)
-    GS_TRY(order(st, sa));
-    GS_TRY(launch_wgrad_plain(dy, h, u_l, h, 0, n, h, h, G(i_lin), h, 0, slabs, slab_bytes, sa));
+    // lin: input gradient (main), then the fork for this layer's first side batch: weight gradient of lin (needs
+    // dy), of the update and its biases (need du)
     // (lin.bias sits in front of the BatchNorm: gradient exactly zero, written by the zero list)
     GS_TRY(dgrad(st, dy, h, wlinT_l, h, du, h, n, h, h, nullptr));
+    GS_TRY(order(st, sa));
+    GS_TRY(launch_wgrad_plain(dy, h, u_l, h, 0, n, h, h, G(i_lin), h, 0, slabs, slab_bytes, sa, dq));
     // extra post layers (Linear(F/2,F/2) after a ReLU, per tower), last to first: du_j -> du_{j-1}  (single stream)
     for (int j = q - 1; j >= 1; --j) {
       const float *u_prev = u_first + (int64_t)(j - 1) * n * h;  // pre-ReLU input of post layer j
@@ -912,13 +921,13 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       du = du_prev;
       dy = tsw;
     }
-    // update weight / bias gradients (side)
-    GS_TRY(order(st, sa));
+    // update weight / bias gradients (side; du is final: with extra post layers everything is on one stream)
     GS_TRY(launch_wgrad_post_folded(du, x_l, agg_l, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap,
-                                    pna_fold_tile_rows(h), w.avg, h, G(i_post0), G(i_post1), slabs, slab_bytes, sa));
+                                    pna_fold_tile_rows(h), w.avg, h, G(i_post0), G(i_post1), slabs, slab_bytes, sa,
+                                    dq));
     {  // both towers' bias gradients: column sums of du, halves to two tensors
       float *outs[2] = {G(i_post0 + 1), G(i_post1 + 1)};
-      GS_TRY(launch_colsum_blocks(du, h, n, 2, h / 2, outs, slabs, slab_bytes, sa));
+      GS_TRY(launch_colsum_blocks(du, h, n, 2, h / 2, outs, slabs, slab_bytes, sa, dq));
     }
     // (update dgrad, x part: merged with the message dgrad below -- one GEMM over [du | dPQ])
     // update dgrad, aggregate part (degree-tiled, scalers folded): dagg[i,t,:] = du_t[i] W_A,eff(d_i, t)
@@ -970,17 +979,29 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       hipLaunchKernelGGL(k_segment_sum, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, I(p.rowptr), dm,
                          dpq, n, h, gs_row_split(h / 2));
     }
-    // per-class sums of dm and the edge-class table chain (side):
-    //   rtab[c, tF:(t+1)F] = W_t[:,2F:3F] cenc[c] + b_t ; cenc = cemb W_e^T + b_e
+    // dQ by source (main; the transposed CSR comes from the side stream's preparation)
+    GS_TRY(await(st, ev_csr));
+    ev_csr = nullptr;
+    hipLaunchKernelGGL(k_gather_rows_sum, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, rowptr_s,
+                       rows_s, dm, dpq, n, h, gs_row_split(h / 2));
+    // side: per-class sums of dm, message weight gradients dW_dst,t / dW_src,t = dP_t^T x / dQ_t^T x, then ONE launch
+    // that reduces this layer's five slab sets (lin, post_nns, bias column sums, class sums, message weights), then
+    // the edge-class table chain  rtab[c, tF:(t+1)F] = W_t[:,2F:3F] cenc[c] + b_t ; cenc = cemb W_e^T + b_e
     GS_TRY(order(st, sa));
     if (class_gemm) {
       GS_TRY(launch_sum_rows_by_class(I(p.combo), (int)C, dm, 2 * (int64_t)h, p.ep, 2 * h, dr, 2 * (int64_t)h, slabs,
-                                      slab_bytes, sa));
+                                      slab_bytes, sa, dq));
     } else {
       hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div(C * 2 * h, 256)), dim3(256), 0, sa, dr, C * 2 * h);
       hipLaunchKernelGGL(k_class_reduce, dim3((unsigned)gs_ceil_div(gs_ceil_div(p.ep, 32) * (h / 2), 256)),
                          dim3(256), 0, sa, rows_c, I(p.combo), dm, p.ep, (int)C, h, dr, gs_row_split(h / 2));
     }
+    {  // dW_dst,t0 | dW_dst,t1 | dW_src,t0 | dW_src,t1 = dPQ^T x: one TN GEMM, four [F,F] blocks of two matrices
+      float *blocks[4] = {G(i_pre0), G(i_pre1), G(i_pre0) + h, G(i_pre1) + h};
+      GS_TRY(launch_wgrad_plain_blocks(dpq, 4 * (int64_t)h, x_l, h, n, 4, h, h, blocks, 3 * (int64_t)h, slabs,
+                                       slab_bytes, sa, dq));
+    }
+    if (dq != nullptr) GS_TRY(launch_slab_queue_flush(sq, sa));
     if (class_gemm) {  // few classes: the six GEMM / column-sum launches below as two elementwise launches
       EdgeTableBwd eb{dr, cenc, F(p.cemb), w.wpre[0][0], w.wpre[1][0], w.we, G(i_pre0), G(i_pre1), G(i_pre0 + 1),
                       G(i_pre1 + 1), G(base + 1), G(base + 2), dcenc, dcemb, (int)C, h};
@@ -1003,18 +1024,6 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       GS_TRY(launch_wgrad_plain(dcenc, h, F(p.cemb), h, 0, C, h, h, G(base + 1), h, 0, slabs, slab_bytes, sa));
       GS_TRY(launch_colsum(dcenc, h, C, h, G(base + 2), 0, slabs, slab_bytes, sa));
       GS_TRY(dgrad(sa, dcenc, h, weT_l, h, dcemb, h, C, h, h, dcemb));  // accumulate over layers (in place)
-    }
-    // dQ by source (main; the transposed CSR comes from the side stream's preparation)
-    GS_TRY(await(st, ev_csr));
-    ev_csr = nullptr;
-    hipLaunchKernelGGL(k_gather_rows_sum, dim3((unsigned)gs_ceil_div(n * (h / 2), 256)), dim3(256), 0, st, rowptr_s,
-                       rows_s, dm, dpq, n, h, gs_row_split(h / 2));
-    // message weight gradients dW_dst,t / dW_src,t = dP_t^T x / dQ_t^T x (side)
-    GS_TRY(order(st, sa));
-    {  // dW_dst,t0 | dW_dst,t1 | dW_src,t0 | dW_src,t1 = dPQ^T x: one TN GEMM, four [F,F] blocks of two matrices
-      float *blocks[4] = {G(i_pre0), G(i_pre1), G(i_pre0) + h, G(i_pre1) + h};
-      GS_TRY(launch_wgrad_plain_blocks(dpq, 4 * (int64_t)h, x_l, h, n, 4, h, h, blocks, 3 * (int64_t)h, slabs,
-                                       slab_bytes, sa));
     }
     // dx_in = (skip ? dx : 0) + [du | dP | dQ] [W_x,0 ; W_x,1 | W_pq]^T : K = 5F in one pass
     {

@@ -137,26 +137,57 @@ int launch_linear_degree_tiled(const float *a, int64_t lda, const int32_t *perm,
                                int hidden /* the tile table was built for */, hipStream_t stream);
 
 // ---- backward building blocks (gemm_tn.hip, csr.hip)
+// Row blocks of a dense [rows, cols] result go to separate matrices: block b = row / rows_per_block -> base[b]
+struct SlabOut {
+  float *base[4];
+  int64_t rows_per_block;
+};
+// Deferred slab reductions.  Every weight-gradient GEMM / column-sum pass leaves per-chunk partial results ("slabs")
+// that a second, tiny launch sums in chunk order.  A backward layer issues five of them: with a queue they write to
+// disjoint regions of one arena and ONE launch (launch_slab_queue_flush) reduces them all.
+constexpr int kMaxSlabJobs = 8;
+struct SlabJob {
+  const float *slabs;
+  int64_t per_slab, chunks, ld_out;
+  SlabOut so;
+  int cols, accumulate;
+};
+struct SlabQueue {
+  float *base = nullptr;
+  size_t cap = 0, off = 0;   // floats
+  int count = 0;
+  SlabJob jobs[kMaxSlabJobs];
+  float *take(size_t floats) {
+    const size_t o = off;
+    const size_t next = o + ((floats + 63) / 64) * 64;
+    if (next > cap) return nullptr;
+    off = next;
+    return base + o;
+  }
+  size_t left_bytes() const { return (cap - off) * 4; }
+};
+int launch_slab_queue_flush(SlabQueue &q, hipStream_t st);
 size_t tn_slab_bytes(int64_t m, int n_out, int k);
 int launch_wgrad_plain(const float *dy, int64_t ldy, const float *a, int64_t lda, int relu_a, int64_t m, int n_out,
                        int k, float *out, int64_t ld_out, int accumulate, float *slabs, size_t slab_bytes,
-                       hipStream_t st);
+                       hipStream_t st, SlabQueue *defer = nullptr /* slabs from its arena, reduction queued */);
 int launch_wgrad_onehot(const float *dx, int64_t ldx, const int64_t *idx, int ncol, const int32_t *dims_host, int64_t n,
                         int hidden, float *dtab_t, int total_rows_padded, float *slabs, size_t slab_bytes,
                         hipStream_t st);
 // dW blocks [rows_per_block, k] of one TN GEMM dy[:, b*rows_per_block ..]^T a, each written to its own matrix
 int launch_wgrad_plain_blocks(const float *dy, int64_t ldy, const float *a, int64_t lda, int64_t m, int num_blocks,
                               int rows_per_block, int k, float *const *out_blocks, int64_t ld_out, float *slabs,
-                              size_t slab_bytes, hipStream_t st);
+                              size_t slab_bytes, hipStream_t st, SlabQueue *defer = nullptr);
 // post_nns weight gradients of both towers through the degree tiles (K = 5F contraction, scalers folded per tile)
 int launch_wgrad_post_folded(const float *du, const float *x, const float *agg, const int32_t *perm,
                              const int32_t *tiles, const int32_t *num_tiles, int64_t tile_cap, int tile_rows,
                              const float *avg, int hidden, float *dw0, float *dw1, float *slabs, size_t slab_bytes,
-                             hipStream_t st);
+                             hipStream_t st, SlabQueue *defer = nullptr);
 size_t wgrad_post_folded_slab_bytes(int64_t tile_cap, int tile_rows, int hidden);
 // out[c, :] = sum of the rows of `a` whose class id is c (one-hot TN GEMM: deterministic, no atomics)
 int launch_sum_rows_by_class(const int32_t *cls, int num_classes, const float *a, int64_t lda, int64_t m, int k,
-                             float *out, int64_t ld_out, float *slabs, size_t slab_bytes, hipStream_t st);
+                             float *out, int64_t ld_out, float *slabs, size_t slab_bytes, hipStream_t st,
+                             SlabQueue *defer = nullptr);
 constexpr int kMaxTransposeBatch = 64;   // 48 B of kernel arguments per entry
 struct TransposeItem {
   const float *in;
@@ -171,7 +202,7 @@ int launch_transpose(int count, const float *const *in, float *const *out, const
 int launch_colsum(const float *a, int64_t lda, int64_t m, int cols, float *out, int accumulate, float *partial,
                   size_t partial_bytes, hipStream_t st);
 int launch_colsum_blocks(const float *a, int64_t lda, int64_t m, int num_blocks, int cols_per_block, float *const *outs,
-                         float *partial, size_t partial_bytes, hipStream_t st);
+                         float *partial, size_t partial_bytes, hipStream_t st, SlabQueue *defer = nullptr);
 size_t group_by_key_workspace_bytes(int64_t num_keys);
 int launch_group_by_key(const int32_t *keys, int64_t count, int64_t num_keys, int32_t *rowptr, int32_t *rows,
                         void *workspace, size_t workspace_bytes, int sort_segments, hipStream_t st);

@@ -65,10 +65,6 @@ struct TnOneHot {
 // the matrix cores, in the fixed summation order of the slab scheme (no atomics).
 // `direct` (single slab, i.e. few rows: edge classes, small batches): the tile goes straight to its destination
 // (SlabOut row blocks, leading dimension ld_out) -- no slab, no k_sum_slabs launch.
-struct SlabOut {
-  float *base[4];
-  int64_t rows_per_block;
-};
 struct TnDirect {
   SlabOut so;
   int64_t ld_out;
@@ -443,6 +439,31 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float *__restrict__ sla
   gs_st4(o, s);
 }
 
+// the same reduction for up to kMaxSlabJobs results in one launch (SlabQueue): blockIdx.y = job
+struct SlabJobs {
+  SlabJob j[kMaxSlabJobs];
+};
+__global__ __launch_bounds__(256) void k_sum_slabs_batched(SlabJobs jobs) {
+  __shared__ f32x4 red[8][32];
+  const SlabJob &jb = jobs.j[blockIdx.y];
+  const int il = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t i4 = ((int64_t)blockIdx.x * 32 + il) * 4;
+  if ((int64_t)blockIdx.x * 128 >= jb.per_slab) return;  // block-uniform: the grid is sized for the largest job
+  const bool ok = i4 < jb.per_slab;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (ok)
+    for (int64_t c = sl; c < jb.chunks; c += 8) s += gs_ld4(jb.slabs + c * jb.per_slab + i4);
+  red[sl][il] = s;
+  __syncthreads();
+  if (sl != 0 || !ok) return;
+  for (int o = 1; o < 8; ++o) s += red[o][il];
+  const int64_t r = i4 / jb.cols, cc = i4 - r * jb.cols;
+  const int64_t blk = r / jb.so.rows_per_block;
+  float *o = jb.so.base[blk] + (r - blk * jb.so.rows_per_block) * jb.ld_out + cc;
+  if (jb.accumulate) s += gs_ld4(o);
+  gs_st4(o, s);
+}
+
 // out[c][r] = in[r][c] for a batch of small matrices (weights): LDS-tiled 32x32
 struct TransposeBatch {
   const float *in[kMaxTransposeBatch];
@@ -599,8 +620,9 @@ static inline void tn_chunking(int64_t m, int64_t tiles, int64_t resident, int64
 template <class AProv, bool Y_CLASS = false>
 static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, int n_out, int k, float *out,
                      int64_t ld_out, int accumulate, float *slabs, size_t slab_bytes, hipStream_t st,
-                     const SlabOut *scatter = nullptr, int force_wn = 0, int force_wk = 0, int64_t force_chunks = 0) {
-  GS_REQUIRE(dy && (out || scatter) && slabs, GNNSAFT_ERR_NULL);
+                     const SlabOut *scatter = nullptr, int force_wn = 0, int force_wk = 0, int64_t force_chunks = 0,
+                     SlabQueue *defer = nullptr) {
+  GS_REQUIRE(dy && (out || scatter) && (slabs || defer), GNNSAFT_ERR_NULL);
   GS_REQUIRE(m >= 1 && n_out >= 1 && k >= 4 && (k % 4) == 0 && (Y_CLASS || (ldy % 4) == 0) && (ld_out % 4) == 0,
              GNNSAFT_ERR_SHAPE);
   int wn = force_wn > 0 ? force_wn : tn_waves(m, n_out, k), wk = force_wk > 0 ? force_wk : tn_waves(m, n_out, k);
@@ -616,7 +638,13 @@ static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, i
     rows_per_z = gs_ceil_div(gs_ceil_div(m, force_chunks), kTnBK) * kTnBK;
     chunks = gs_ceil_div(m, rows_per_z);
   }
-  GS_REQUIRE(slab_bytes >= (size_t)chunks * n_out * k * 4, GNNSAFT_ERR_WORKSPACE);
+  if (defer != nullptr) {
+    GS_REQUIRE(defer->count < kMaxSlabJobs, GNNSAFT_ERR_WORKSPACE);
+    slabs = defer->take((size_t)chunks * n_out * k);
+    GS_REQUIRE(slabs != nullptr, GNNSAFT_ERR_WORKSPACE);
+  } else {
+    GS_REQUIRE(slab_bytes >= (size_t)chunks * n_out * k * 4, GNNSAFT_ERR_WORKSPACE);
+  }
   const int64_t per_slab = (int64_t)n_out * k;
   SlabOut so{{out, out, out, out}, (int64_t)1 << 40};
   if (scatter != nullptr) so = *scatter;
@@ -640,9 +668,31 @@ static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, i
     GS_CHECK_LAUNCH();
     return GNNSAFT_OK;
   }
+  if (defer != nullptr) {
+    defer->jobs[defer->count++] = SlabJob{slabs, per_slab, chunks, ld_out, so, k, accumulate};
+    GS_CHECK_LAUNCH();
+    return GNNSAFT_OK;
+  }
   hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)gs_ceil_div(per_slab / 4, 32)), dim3(256), 0, st, slabs, per_slab,
                      chunks, so, ld_out, k, accumulate, per_slab);
   GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+int launch_slab_queue_flush(SlabQueue &q, hipStream_t st) {
+  if (q.count > 0) {
+    SlabJobs jobs;
+    int64_t blocks = 1;
+    for (int i = 0; i < kMaxSlabJobs; ++i) {
+      jobs.j[i] = q.jobs[i < q.count ? i : 0];
+      const int64_t b = gs_ceil_div(jobs.j[i].per_slab / 4, 32);
+      blocks = b > blocks ? b : blocks;
+    }
+    hipLaunchKernelGGL(k_sum_slabs_batched, dim3((unsigned)blocks, (unsigned)q.count), dim3(256), 0, st, jobs);
+    GS_CHECK_LAUNCH();
+  }
+  q.count = 0;
+  q.off = 0;
   return GNNSAFT_OK;
 }
 
@@ -655,29 +705,30 @@ size_t tn_slab_bytes(int64_t m, int n_out, int k) {
 
 int launch_wgrad_plain(const float *dy, int64_t ldy, const float *a, int64_t lda, int relu_a, int64_t m, int n_out,
                        int k, float *out, int64_t ld_out, int accumulate, float *slabs, size_t slab_bytes,
-                       hipStream_t st) {
+                       hipStream_t st, SlabQueue *defer) {
   GS_REQUIRE(a != nullptr && (lda % 4) == 0, GNNSAFT_ERR_SHAPE);
   TnPlain ap{a, lda, relu_a, k};
-  return launch_tn(dy, ldy, ap, m, n_out, k, out, ld_out, accumulate, slabs, slab_bytes, st);
+  return launch_tn(dy, ldy, ap, m, n_out, k, out, ld_out, accumulate, slabs, slab_bytes, st, nullptr, 0, 0, 0, defer);
 }
 
 int launch_wgrad_plain_blocks(const float *dy, int64_t ldy, const float *a, int64_t lda, int64_t m, int num_blocks,
                               int rows_per_block, int k, float *const *out_blocks, int64_t ld_out, float *slabs,
-                              size_t slab_bytes, hipStream_t st) {
+                              size_t slab_bytes, hipStream_t st, SlabQueue *defer) {
   GS_REQUIRE(a != nullptr && (lda % 4) == 0 && out_blocks != nullptr && num_blocks >= 1 && num_blocks <= 4,
              GNNSAFT_ERR_SHAPE);
   SlabOut so;
   for (int i = 0; i < 4; ++i) so.base[i] = out_blocks[i < num_blocks ? i : 0];
   so.rows_per_block = rows_per_block;
   TnPlain ap{a, lda, 0, k};
-  return launch_tn(dy, ldy, ap, m, num_blocks * rows_per_block, k, nullptr, ld_out, 0, slabs, slab_bytes, st, &so);
+  return launch_tn(dy, ldy, ap, m, num_blocks * rows_per_block, k, nullptr, ld_out, 0, slabs, slab_bytes, st, &so, 0, 0,
+                   0, defer);
 }
 
 int launch_wgrad_post_folded(const float *du, const float *x, const float *agg, const int32_t *perm,
                              const int32_t *tiles, const int32_t *num_tiles, int64_t tile_cap, int tile_rows,
                              const float *avg, int hidden, float *dw0, float *dw1 /* [F/2,13F] each */, float *slabs,
-                             size_t slab_bytes, hipStream_t st) {
-  GS_REQUIRE(du && x && agg && perm && tiles && num_tiles && avg && dw0 && dw1 && slabs, GNNSAFT_ERR_NULL);
+                             size_t slab_bytes, hipStream_t st, SlabQueue *defer) {
+  GS_REQUIRE(du && x && agg && perm && tiles && num_tiles && avg && dw0 && dw1 && (slabs || defer), GNNSAFT_ERR_NULL);
   GS_REQUIRE((hidden % 64) == 0 && tile_rows >= kTnBK && (tile_rows % kTnBK) == 0 && tile_cap >= 1,
              GNNSAFT_ERR_UNSUPPORTED);
   // ~256 rows per workgroup along the contraction, as launch_tn does
@@ -685,12 +736,23 @@ int launch_wgrad_post_folded(const float *du, const float *x, const float *agg, 
   const int64_t chunks = gs_ceil_div(tile_cap, (int64_t)tiles_per_z);
   const int n_out = hidden / 2;
   const int64_t per_slab = (int64_t)n_out * 13 * hidden;
-  GS_REQUIRE(slab_bytes >= (size_t)chunks * 2 * per_slab * 4, GNNSAFT_ERR_WORKSPACE);
+  if (defer != nullptr) {
+    GS_REQUIRE(defer->count < kMaxSlabJobs, GNNSAFT_ERR_WORKSPACE);
+    slabs = defer->take((size_t)chunks * 2 * per_slab);
+    GS_REQUIRE(slabs != nullptr, GNNSAFT_ERR_WORKSPACE);
+  } else {
+    GS_REQUIRE(slab_bytes >= (size_t)chunks * 2 * per_slab * 4, GNNSAFT_ERR_WORKSPACE);
+  }
   TnFoldArgs a{du, x, agg, perm, tiles, num_tiles, avg, hidden, tile_rows, tiles_per_z};
   const dim3 grid((unsigned)(5 * hidden / kTnTile), (unsigned)(2 * gs_ceil_div(n_out, kTnTile)), (unsigned)chunks);
   hipLaunchKernelGGL(k_gemm_tn_postfold, grid, dim3(256), 0, st, a, slabs);
   // both towers in one pass: the slab pair is a dense [2 * F/2, 13F] matrix whose row blocks go to dw0 / dw1
   SlabOut so{{dw0, dw1, dw1, dw1}, (int64_t)n_out};
+  if (defer != nullptr) {
+    defer->jobs[defer->count++] = SlabJob{slabs, 2 * per_slab, chunks, 13 * (int64_t)hidden, so, 13 * hidden, 0};
+    GS_CHECK_LAUNCH();
+    return GNNSAFT_OK;
+  }
   hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)gs_ceil_div(2 * per_slab / 4, 32)), dim3(256), 0, st, slabs,
                      2 * per_slab, chunks, so, 13 * (int64_t)hidden, 13 * hidden, 0, 2 * per_slab);
   GS_CHECK_LAUNCH();
@@ -721,11 +783,11 @@ int launch_wgrad_onehot(const float *dx, int64_t ldx, const int64_t *idx, int nc
 
 int launch_sum_rows_by_class(const int32_t *cls, int num_classes, const float *a, int64_t lda, int64_t m, int k,
                              float *out /* [num_classes, k] */, int64_t ld_out, float *slabs, size_t slab_bytes,
-                             hipStream_t st) {
+                             hipStream_t st, SlabQueue *defer) {
   GS_REQUIRE(cls != nullptr && a != nullptr && (lda % 4) == 0 && num_classes >= 1, GNNSAFT_ERR_SHAPE);
   TnPlain ap{a, lda, 0, k};
   return launch_tn<TnPlain, true>(reinterpret_cast<const float *>(cls), 0, ap, m, num_classes, k, out, ld_out, 0, slabs,
-                                  slab_bytes, st);
+                                  slab_bytes, st, nullptr, 0, 0, 0, defer);
 }
 
 int launch_transpose_list(int count, const TransposeItem *items, hipStream_t st) {
@@ -760,11 +822,26 @@ int launch_transpose(int count, const float *const *in, float *const *out, const
 }
 
 static int colsum_impl(const float *a, int64_t lda, int64_t m, int cols, const ColsumOut &co, int accumulate,
-                       float *partial, size_t partial_bytes, hipStream_t st) {
-  GS_REQUIRE(a && partial, GNNSAFT_ERR_NULL);
+                       float *partial, size_t partial_bytes, hipStream_t st, SlabQueue *defer = nullptr) {
+  GS_REQUIRE(a && (partial || defer), GNNSAFT_ERR_NULL);
   const int64_t chunks = gs_ceil_div(m > 0 ? m : 1, kColChunk);
-  GS_REQUIRE(partial_bytes >= (size_t)chunks * cols * 4, GNNSAFT_ERR_WORKSPACE);
   const int direct = chunks == 1;
+  if (defer != nullptr && !direct && (cols % 4) == 0 && (co.cols_per_block % 4) == 0) {
+    // queued: the per-chunk partials [chunks][cols] are one more slab set (dense [num_blocks, cols_per_block] result,
+    // row b -> bias tensor b)
+    GS_REQUIRE(defer->count < kMaxSlabJobs, GNNSAFT_ERR_WORKSPACE);
+    partial = defer->take((size_t)chunks * cols);
+    GS_REQUIRE(partial != nullptr, GNNSAFT_ERR_WORKSPACE);
+    hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)gs_ceil_div(cols, 32), (unsigned)chunks), dim3(256), 0, st, a,
+                       lda, m, cols, partial, co, 0, accumulate);
+    const bool one = co.cols_per_block >= cols;
+    SlabOut so{{co.base[0], co.base[1], co.base[2], co.base[3]}, 1};
+    defer->jobs[defer->count++] = SlabJob{partial, cols, chunks, one ? cols : co.cols_per_block, so,
+                                          one ? cols : co.cols_per_block, accumulate};
+    GS_CHECK_LAUNCH();
+    return GNNSAFT_OK;
+  }
+  GS_REQUIRE(partial != nullptr && partial_bytes >= (size_t)chunks * cols * 4, GNNSAFT_ERR_WORKSPACE);
   hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)gs_ceil_div(cols, 32), (unsigned)chunks), dim3(256), 0, st, a,
                      lda, m, cols, partial, co, direct, accumulate);
   if (!direct)
@@ -783,12 +860,12 @@ int launch_colsum(const float *a, int64_t lda, int64_t m, int cols, float *out, 
 
 // column sums of [m, num_blocks * cols_per_block], block b written to outs[b] (several bias gradients in one pass)
 int launch_colsum_blocks(const float *a, int64_t lda, int64_t m, int num_blocks, int cols_per_block, float *const *outs,
-                         float *partial, size_t partial_bytes, hipStream_t st) {
+                         float *partial, size_t partial_bytes, hipStream_t st, SlabQueue *defer) {
   GS_REQUIRE(outs != nullptr && num_blocks >= 1 && num_blocks <= 4 && cols_per_block >= 1, GNNSAFT_ERR_SHAPE);
   ColsumOut co;
   for (int i = 0; i < 4; ++i) co.base[i] = outs[i < num_blocks ? i : 0];
   co.cols_per_block = cols_per_block;
-  return colsum_impl(a, lda, m, num_blocks * cols_per_block, co, 0, partial, partial_bytes, st);
+  return colsum_impl(a, lda, m, num_blocks * cols_per_block, co, 0, partial, partial_bytes, st, defer);
 }
 
 }  // namespace gs
