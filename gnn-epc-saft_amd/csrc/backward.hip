@@ -352,17 +352,24 @@ __global__ __launch_bounds__(256) void k_class_reduce(const int32_t *__restrict_
 }
 
 // WTA[d][t][c][o] = W_t[o][F+c] + amp(d) W_t[o][5F+c] + att(d) W_t[o][9F+c]   (c < 4F, o < F/2)
+// for every layer in one launch: blockIdx.z = (layer, degree, tower)
+constexpr int kMaxFoldLayers = 16;
 struct PostPair {
   const float *w0, *w1;
 };
-__global__ __launch_bounds__(256) void k_fold_post_weights_t(PostPair pp, const float *__restrict__ avg,
-                                                             const int32_t *__restrict__ hist, int f,
-                                                             float *__restrict__ wta) {
+struct FoldLayers {
+  PostPair pp[kMaxFoldLayers];
+  const float *avg[kMaxFoldLayers];
+};
+__global__ __launch_bounds__(256) void k_fold_post_weights_t(FoldLayers fl, const int32_t *__restrict__ hist, int f,
+                                                             float *__restrict__ wta_all, int64_t wta_per_layer) {
   __shared__ float tl[32][33];
-  const int d = blockIdx.z / 2, t = blockIdx.z % 2;
+  const int layer = blockIdx.z / (kDegreeBuckets * 2);
+  const int dz = blockIdx.z - layer * (kDegreeBuckets * 2);
+  const int d = dz / 2, t = dz % 2;
   if (hist[d] == 0) return;
-  const float *w = t == 0 ? pp.w0 : pp.w1;
-  const float avgv = avg[0];
+  const float *w = t == 0 ? fl.pp[layer].w0 : fl.pp[layer].w1;
+  const float avgv = fl.avg[layer][0];
   const float amp = logf((float)d + 1.f) / avgv;
   const float att = avgv / logf(fmaxf((float)d, 1.f) + 1.f);
   const int o0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(256) void k_fold_post_weights_t(PostPair pp, const 
     tl[ty + 8 * j][tx] = wr[0] + wr[4 * f] * amp + wr[8 * f] * att;
   }
   __syncthreads();
-  float *out = wta + (((int64_t)d * 2 + t) * (4 * f)) * (f / 2);
+  float *out = wta_all + layer * wta_per_layer + (((int64_t)d * 2 + t) * (4 * f)) * (f / 2);
 #pragma unroll
   for (int j = 0; j < 4; ++j) out[(int64_t)(c0 + ty + 8 * j) * (f / 2) + o0 + tx] = tl[tx][ty + 8 * j];
 }
@@ -734,11 +741,18 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   // =========================== side branch: one-off preparation ===========================
   GS_TRY(order(st, sa));  // fork: the tape and the scratch buffer belong to the caller's stream
   hipEvent_t ev_wta = nullptr, ev_csr = nullptr;
-  for (int l = 0; l < L; ++l) {  // transposed, degree-folded update weights of every layer (weights only)
-    const LayerW &w = pw.layers[l];
-    PostPair pp{w.wpost[0][0], w.wpost[1][0]};
-    hipLaunchKernelGGL(k_fold_post_weights_t, dim3((unsigned)(4 * h / 32), (unsigned)(h / 2 / 32), kDegreeBuckets * 2),
-                       dim3(256), 0, sa, pp, w.avg, I(p.hist3), h, wta_all + (size_t)l * wta_per_layer);
+  for (int l0 = 0; l0 < L; l0 += kMaxFoldLayers) {  // transposed, degree-folded update weights (weights only)
+    FoldLayers fl;
+    const int cnt = L - l0 < kMaxFoldLayers ? L - l0 : kMaxFoldLayers;
+    for (int i = 0; i < kMaxFoldLayers; ++i) {
+      const LayerW &w = pw.layers[l0 + (i < cnt ? i : 0)];
+      fl.pp[i] = PostPair{w.wpost[0][0], w.wpost[1][0]};
+      fl.avg[i] = w.avg;
+    }
+    hipLaunchKernelGGL(k_fold_post_weights_t,
+                       dim3((unsigned)(4 * h / 32), (unsigned)(h / 2 / 32), (unsigned)(cnt * kDegreeBuckets * 2)),
+                       dim3(256), 0, sa, fl, I(p.hist3), h, wta_all + (size_t)l0 * wta_per_layer,
+                       (int64_t)wta_per_layer);
   }
   GS_TRY(mark(sa, ev_wta));
   // transposed CSR (rows grouped by source) ... and, with many edge classes, rows grouped by class.  Few classes
@@ -780,6 +794,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       push(G(i_lin + 1), h);
     }
     for (int bi = 0; bi < nb; ++bi) push(G(pw.readout_base[bi] + 1), pw.readout[bi].n_out);
+    push(w3T, h * 8);   // zero padding of the final Linear's transposed weight (filled by the batched transpose)
     flush();
   }
   {  // every weight transpose the dgrads of this backward need, in one launch (64 matrices per launch)
@@ -816,6 +831,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       const ReadoutW &rw = pw.readout[bi];
       GS_TRY(push({rw.w, wt_readout + (size_t)bi * h * h, rw.n_in, rw.n_out, rw.n_out, rw.n_in}));  // [n_in][n_out]
     }
+    GS_TRY(push({pw.readout[nb].w, w3T, pw.readout[nb].n_in, 8, P, pw.readout[nb].n_in}));  // W3^T, 8 columns
     GS_TRY(flush());
   }
   {
@@ -826,10 +842,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     const float *in = F(p.ro) + (nb - 1) * rs;  // output of the last BN block, width H/4
     GS_TRY(launch_wgrad_plain(dout_pad, 8, in, fin.n_in, 0, g, P, fin.n_in, G(ib), fin.n_in, 0, slabs, slab_bytes, st));
     GS_TRY(launch_colsum(dout_pad, 8, g, P, G(ib + 1), 0, slabs, slab_bytes, st));
-    // dIn = dOut W3: W'[n_out = H/4][k = 8] = W3^T zero-padded
-    hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)gs_ceil_div((int64_t)h * 8, 256)), dim3(256), 0, st, w3T,
-                       (int64_t)h * 8);
-    GS_TRY(transpose1(fin.w, fin.n_in, w3T, 8, P, fin.n_in));
+    // dIn = dOut W3: W'[n_out = H/4][k = 8] = W3^T zero-padded (zero list + batched transpose above)
     GS_TRY(dgrad(st, dout_pad, 8, w3T, 8, dcur, fin.n_in, g, fin.n_in, 8, nullptr));
   }
   for (int bi = nb - 1; bi >= 0; --bi) {
