@@ -11,6 +11,7 @@
 // table (edge_encoder, bond embeddings).  Supported: pre_layers == post_layers == 1 (the shipped
 // default, configs/default.py:39-40), hidden % 64 == 0.
 #include "plan.hpp"
+#include "readout.hpp"
 
 namespace gs {
 
@@ -570,6 +571,9 @@ static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
   const size_t s6 = (rows / 256 + 2) * h * 4;                            // column-sum partials
   size_t slab = s1 + s3 + s4 + s5 + s6 + 8 * 256;
   slab = slab > s2 ? slab : s2;
+  const bool rb_fused = !d->unfused_readout && readout_bwd_fused_supported(p.g, (int)h, d->num_para, p.nb);
+  const size_t s7 = rb_fused ? readout_bwd_slab_floats(p.g, (int)h, d->num_para, p.nb) * 4 : 0;
+  slab = slab > s7 ? slab : s7;
   size_t tot = 0;
   auto add = [&](size_t b) { tot += gs_align_up(b, 256); };
   add(slab);
@@ -602,6 +606,8 @@ static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
   add(gg * 8 * 4);                                       // padded dout
   add(h * 8 * 4);                                        // padded W3^T
   add(h * (size_t)(176 + 16) * 4);                       // one-hot result
+  add(readout_bwd_scratch_floats(p.g, (int)h, p.nb) * 4); // fused readout backward: BatchNorm / bias partials
+  add(kRdSyncInts * 4);                                   //   ... and its barrier counters
   return BwdSizes{slab, tot + 65536};
 }
 
@@ -716,7 +722,12 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   const size_t per_layer_t = 9 * (size_t)h * h;      // wlinT [H][H] | wxpqT [H][5H] = [wxT | wpqT] | wcT [H][2H] | weT [H][H]
   float *wt_layers = sc.take<float>((size_t)Ln * per_layer_t);
   float *wt_readout = sc.take<float>((size_t)p.nb * h * h);
-  GS_REQUIRE(det != nullptr && wt_layers != nullptr && wt_readout != nullptr, GNNSAFT_ERR_WORKSPACE);
+  float *rb_scratch = sc.take<float>(readout_bwd_scratch_floats(g, h, p.nb));
+  int32_t *rb_sync = sc.take<int32_t>(kRdSyncInts);
+  GS_REQUIRE(det != nullptr && wt_layers != nullptr && wt_readout != nullptr && rb_scratch != nullptr &&
+                 rb_sync != nullptr,
+             GNNSAFT_ERR_WORKSPACE);
+  const bool rb_fused = !d->unfused_readout && readout_bwd_fused_supported(g, h, P, p.nb);
   const size_t slab_bytes = bs.slab;
   SlabQueue sq;   // one layer's reductions, summed by one launch (side stream)
   sq.base = slabs;
@@ -795,6 +806,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     }
     for (int bi = 0; bi < nb; ++bi) push(G(pw.readout_base[bi] + 1), pw.readout[bi].n_out);
     push(w3T, h * 8);   // zero padding of the final Linear's transposed weight (filled by the batched transpose)
+    push(reinterpret_cast<float *>(rb_sync), kRdSyncInts);   // barrier counters of the fused readout backward
     flush();
   }
   {  // every weight transpose the dgrads of this backward need, in one launch (64 matrices per launch)
@@ -834,32 +846,67 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     GS_TRY(push({pw.readout[nb].w, w3T, pw.readout[nb].n_in, 8, P, pw.readout[nb].n_in}));  // W3^T, 8 columns
     GS_TRY(flush());
   }
-  {
-    // final Linear(H/4 -> P): pad dOut to 8 columns so that the GEMMs can use 16-byte loads
-    hipLaunchKernelGGL(k_pad_cols, dim3((unsigned)gs_ceil_div(g * 8, 256)), dim3(256), 0, st, grad_out, g, P, 8, dout_pad);
-    const ReadoutW &fin = pw.readout[nb];
-    const int ib = pw.readout_base[nb];
-    const float *in = F(p.ro) + (nb - 1) * rs;  // output of the last BN block, width H/4
-    GS_TRY(launch_wgrad_plain(dout_pad, 8, in, fin.n_in, 0, g, P, fin.n_in, G(ib), fin.n_in, 0, slabs, slab_bytes, st));
-    GS_TRY(launch_colsum(dout_pad, 8, g, P, G(ib + 1), 0, slabs, slab_bytes, st));
-    // dIn = dOut W3: W'[n_out = H/4][k = 8] = W3^T zero-padded (zero list + batched transpose above)
-    GS_TRY(dgrad(st, dout_pad, 8, w3T, 8, dcur, fin.n_in, g, fin.n_in, 8, nullptr));
-  }
-  for (int bi = nb - 1; bi >= 0; --bi) {
-    const ReadoutW &rw = pw.readout[bi];
-    const int ib = pw.readout_base[bi];
-    const float *yb = F(p.ry) + bi * rs;
-    const float *in = bi == 0 ? F(p.pooled) : F(p.ro) + (bi - 1) * rs;
-    const float *stat = F(p.rstat) + (int64_t)bi * 2 * h;
-    GS_TRY(bn_relu_backward(yb, dcur, stat, rw.bn.gamma, rw.bn.beta, g, rw.n_out, G(ib + 2), G(ib + 3), dyr, bnpart, st));
-    GS_TRY(launch_wgrad_plain(dyr, rw.n_out, in, rw.n_in, 0, g, rw.n_out, rw.n_in, G(ib), rw.n_in, 0, slabs, slab_bytes,
-                              st));
-    // (bias gradient: exactly zero, written above)
-    GS_TRY(dgrad(st, dyr, rw.n_out, wt_readout + (size_t)bi * h * h, rw.n_out, dnext, rw.n_in, g, rw.n_in, rw.n_out,
-                 nullptr));
-    float *t = dcur;
-    dcur = dnext;
-    dnext = t;
+  if (rb_fused) {
+    // one launch for the whole readout (readout.hip: k_readout_bwd_fused) + one reduction of its per-workgroup partial
+    // weight gradients
+    ReadoutBwdParams rp;
+    rp.g = g;
+    rp.h = h;
+    rp.num_para = P;
+    rp.nblocks = nb;
+    rp.grad_out = grad_out;
+    for (int i = 0; i <= kRdMaxBlocks; ++i) {
+      const bool live = i <= nb;
+      rp.w[i] = live ? pw.readout[i].w : nullptr;
+      rp.dw[i] = live ? G(pw.readout_base[i]) : nullptr;
+      if (i < kRdMaxBlocks) {
+        const bool bl = i < nb;
+        rp.wt[i] = bl ? wt_readout + (size_t)i * h * h : nullptr;
+        rp.gamma[i] = bl ? pw.readout[i].bn.gamma : nullptr;
+        rp.beta[i] = bl ? pw.readout[i].bn.beta : nullptr;
+        rp.dgamma[i] = bl ? G(pw.readout_base[i] + 2) : nullptr;
+        rp.dbeta[i] = bl ? G(pw.readout_base[i] + 3) : nullptr;
+      }
+    }
+    rp.db_final = G(pw.readout_base[nb] + 1);
+    rp.pooled = F(p.pooled);
+    rp.ry = F(p.ry);
+    rp.ro = F(p.ro);
+    rp.rstat = F(p.rstat);
+    rp.dpooled = dcur;
+    rp.scratch = rb_scratch;
+    rp.sync = rb_sync;
+    rp.err = nullptr;
+    GS_TRY(launch_readout_bwd_fused(rp, sq, st));
+    GS_TRY(launch_slab_queue_flush(sq, st));
+  } else {
+    {
+      // final Linear(H/4 -> P): pad dOut to 8 columns so that the GEMMs can use 16-byte loads
+      hipLaunchKernelGGL(k_pad_cols, dim3((unsigned)gs_ceil_div(g * 8, 256)), dim3(256), 0, st, grad_out, g, P, 8, dout_pad);
+      const ReadoutW &fin = pw.readout[nb];
+      const int ib = pw.readout_base[nb];
+      const float *in = F(p.ro) + (nb - 1) * rs;  // output of the last BN block, width H/4
+      GS_TRY(launch_wgrad_plain(dout_pad, 8, in, fin.n_in, 0, g, P, fin.n_in, G(ib), fin.n_in, 0, slabs, slab_bytes, st));
+      GS_TRY(launch_colsum(dout_pad, 8, g, P, G(ib + 1), 0, slabs, slab_bytes, st));
+      // dIn = dOut W3: W'[n_out = H/4][k = 8] = W3^T zero-padded (zero list + batched transpose above)
+      GS_TRY(dgrad(st, dout_pad, 8, w3T, 8, dcur, fin.n_in, g, fin.n_in, 8, nullptr));
+    }
+    for (int bi = nb - 1; bi >= 0; --bi) {
+      const ReadoutW &rw = pw.readout[bi];
+      const int ib = pw.readout_base[bi];
+      const float *yb = F(p.ry) + bi * rs;
+      const float *in = bi == 0 ? F(p.pooled) : F(p.ro) + (bi - 1) * rs;
+      const float *stat = F(p.rstat) + (int64_t)bi * 2 * h;
+      GS_TRY(bn_relu_backward(yb, dcur, stat, rw.bn.gamma, rw.bn.beta, g, rw.n_out, G(ib + 2), G(ib + 3), dyr, bnpart, st));
+      GS_TRY(launch_wgrad_plain(dyr, rw.n_out, in, rw.n_in, 0, g, rw.n_out, rw.n_in, G(ib), rw.n_in, 0, slabs, slab_bytes,
+                                st));
+      // (bias gradient: exactly zero, written above)
+      GS_TRY(dgrad(st, dyr, rw.n_out, wt_readout + (size_t)bi * h * h, rw.n_out, dnext, rw.n_in, g, rw.n_in, rw.n_out,
+                   nullptr));
+      float *t = dcur;
+      dcur = dnext;
+      dnext = t;
+    }
   }
   // gradient segments complete in the order readout, layer L-1 .. 0, embeddings: an event per segment lets the
   // data-parallel exchange of a finished segment run under the rest of the backward (parallel.py).  A layer's

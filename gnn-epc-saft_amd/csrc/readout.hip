@@ -316,6 +316,250 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_fused(ReadoutArgs a) {
   RD_STAMP(60);
 }
 
+// --------------------------------------------------------------------------------------------------------------
+// Backward of the readout in ONE launch (+ the batched slab reduction of backward.hip): what 23 launches did over
+// [G, H] matrices -- per block BatchNorm+ReLU backward (2), weight-gradient TN GEMM + slab sum (2), input-gradient
+// GEMM (1), plus the final Linear's -- for < 1 % of the backward's FLOPs and ~10 % of its time at BASELINE config 2.
+// Same decomposition as the forward kernel: a workgroup owns 64 graphs, keeps the gradient tile in LDS through all
+// blocks, meets the grid once per BatchNorm block (the column sums of dz and dz*yhat run over ALL graphs) and leaves
+// per-workgroup partial weight gradients [W][n_out][n_in] for the reduction launch (fixed order: reproducible).
+struct ReadoutBwdArgs {
+  int64_t g;
+  int h, num_para, nblocks;
+  const float *grad_out;                       // [G, P]
+  const float *w_final;                        // [P, H/4]
+  const float *wt[kRdMaxBlocks];               // transposed block weights [n_in][n_out]
+  const float *gamma[kRdMaxBlocks], *beta[kRdMaxBlocks];
+  int n_in[kRdMaxBlocks + 1], n_out[kRdMaxBlocks + 1];
+  const float *pooled, *ry, *ro, *rstat;       // tape of the forward
+  float *dgamma[kRdMaxBlocks], *dbeta[kRdMaxBlocks];
+  float *slab_w[kRdMaxBlocks + 1];             // [W][n_out][n_in] per layer (final Linear last)
+  float *bias_part;                            // [W][8] column sums of dOut per workgroup
+  float *dbias_final;                          // [P]
+  float *part;                                 // [nb][W][2][H] per-workgroup (sum dz, sum dz yhat)
+  float *dpooled;                              // [G, H]
+  int32_t *sync;                               // [nb + 1] counters, zero at launch
+  int32_t *err;
+};
+
+// slab[n][k] = sum over this workgroup's 64 rows of dy[r][n] * in[r][k]: 32 x 32 output tiles round-robin over the
+// waves, contraction in row pairs (lane half = row parity) exactly as k_gemm_tn; dy from the LDS tile, `in` rows
+// straight from L2 (the forward's tape).
+__device__ __forceinline__ void rd_wgrad(const float *dy, int ld, const float *__restrict__ in, int64_t row0, int rows,
+                                         int n_out, int n_in, float *__restrict__ slab) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int nt_n = (n_out + 31) >> 5, nt_k = (n_in + 31) >> 5;
+  for (int t = wave; t < nt_n * nt_k; t += kRdThreads / 64) {
+    const int nt = t / nt_k, kt = t - nt * nt_k;
+    const int ncol = nt * 32 + l31, kcol = kt * 32 + l31;
+    const bool n_ok = ncol < n_out, k_ok = kcol < n_in;
+    const float *bp = in + (k_ok ? kcol : 0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int q0 = 0; q0 < kRdRows / 2; q0 += 8) {
+      float av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = 2 * (q0 + u) + half;
+        const int rc = row < rows ? row : rows - 1;       // rows past the end: dy is zero there, any valid address
+        av[u] = dy[row * ld + (n_ok ? ncol : 0)];
+        bv[u] = bp[(row0 + rc) * n_in];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(n_ok ? av[u] : 0.f, k_ok ? bv[u] : 0.f, acc, 0, 0, 0);
+    }
+    if (k_ok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nr = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (nr < n_out) slab[(int64_t)nr * n_in + kcol] = acc[r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kRdThreads) void k_readout_bwd_fused(ReadoutBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rd_lds[];
+  const int tid = threadIdx.x;
+  const int h = a.h, ld = h + kRdPad;
+  float *dt = rd_lds;                  // [64][ld] gradient w.r.t. the current block's output, then its input
+  float *yt = dt + kRdRows * ld;       // [64][ld] yhat, then dy
+  float *s_a = yt + kRdRows * ld;      // [H] gamma rstd
+  float *s_b = s_a + h;                // [H] gamma rstd mean(dz)
+  float *s_c = s_b + h;                // [H] gamma rstd mean(dz yhat)
+  float *s_do = s_c + h;               // [64][8] dOut rows
+  double *s_d = reinterpret_cast<double *>(s_do + kRdRows * 8);   // [2][kRdThreads]
+  const int64_t row0 = (int64_t)blockIdx.x * kRdRows;
+  const int rows = a.g - row0 < kRdRows ? (int)(a.g - row0) : kRdRows;   // >= 1
+  const int nwg = gridDim.x, nb = a.nblocks, P = a.num_para;
+  const int64_t rs = a.g * (int64_t)h;
+
+  // ---- final Linear(H/4 -> P): dW_f = dOut^T x, db_f = column sums of dOut, dx = dOut W_f
+  {
+    const int n_in = a.n_in[nb];
+    for (int idx = tid; idx < kRdRows * 8; idx += kRdThreads) {
+      const int r = idx >> 3, c = idx & 7;
+      s_do[idx] = (r < rows && c < P) ? a.grad_out[(row0 + r) * P + c] : 0.f;
+    }
+    __syncthreads();
+    const float *in = a.ro + (int64_t)(nb - 1) * rs;     // output of the last BatchNorm block, row stride n_in
+    // staged through LDS: 64 dependent-address row loads per thread straight from L2 were most of this phase
+    for (int idx = tid; idx < kRdRows * (n_in / 4); idx += kRdThreads) {
+      const int r = idx / (n_in / 4), c4 = (idx - r * (n_in / 4)) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rows) v = gs_ld4(in + (row0 + r) * n_in + c4);
+      gs_st4(yt + r * ld + c4, v);
+    }
+    __syncthreads();
+    float *slab = a.slab_w[nb] + (int64_t)blockIdx.x * P * n_in;
+    for (int idx = tid; idx < P * n_in; idx += kRdThreads) {
+      const int pp = idx / n_in, j = idx - pp * n_in;
+      float s = 0.f;
+      for (int r = 0; r < rows; ++r) s += s_do[r * 8 + pp] * yt[r * ld + j];
+      slab[idx] = s;
+    }
+    if (tid < 8) {
+      float s = 0.f;
+      for (int r = 0; r < rows; ++r) s += s_do[r * 8 + tid];
+      s_a[tid] = s;     // published by thread 0 below (one writer in front of the ticket)
+    }
+    for (int idx = tid; idx < kRdRows * n_in; idx += kRdThreads) {
+      const int r = idx / n_in, j = idx - r * n_in;
+      float s = 0.f;
+      for (int pp = 0; pp < P; ++pp) s += s_do[r * 8 + pp] * a.w_final[pp * n_in + j];
+      dt[r * ld + j] = s;                                  // rows past the end: dOut is zero there
+    }
+    __syncthreads();
+    if (tid == 0) {   // the last workgroup to arrive adds the bias partials in workgroup order
+      for (int pp = 0; pp < 8; ++pp) a.bias_part[(int64_t)blockIdx.x * 8 + pp] = s_a[pp];
+      const int ticket = __hip_atomic_fetch_add(a.sync + nb, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == nwg - 1)
+        for (int pp = 0; pp < P; ++pp) {
+          float tot = 0.f;
+          for (int w = 0; w < nwg; ++w) tot += __builtin_nontemporal_load(a.bias_part + (int64_t)w * 8 + pp);
+          a.dbias_final[pp] = tot;
+        }
+    }
+  }
+
+  for (int b = nb - 1; b >= 0; --b) {
+    const int n_in = a.n_in[b], n_out = a.n_out[b];
+    const int q = n_out >> 2;
+    const float *stat = a.rstat + (int64_t)b * 2 * h;
+    // ---- yhat and dz = dOut masked by the ReLU (z = yhat gamma + beta > 0), in place
+    for (int idx = tid; idx < kRdRows * q; idx += kRdThreads) {
+      const int r = idx / q, c4 = (idx - r * q) * 4;
+      f32x4 yh = {0.f, 0.f, 0.f, 0.f}, dz = {0.f, 0.f, 0.f, 0.f};
+      if (r < rows) {
+        const f32x4 y = gs_ld4(a.ry + b * rs + (row0 + r) * n_out + c4);
+        const f32x4 mean = gs_ld4(stat + c4), rstd = gs_ld4(stat + n_out + c4);
+        const f32x4 gm = gs_ld4(a.gamma[b] + c4), bt = gs_ld4(a.beta[b] + c4);
+        const f32x4 dv = gs_ld4(dt + r * ld + c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          yh[j] = (y[j] - mean[j]) * rstd[j];
+          dz[j] = (yh[j] * gm[j] + bt[j]) > 0.f ? dv[j] : 0.f;
+        }
+      }
+      gs_st4(yt + r * ld + c4, yh);
+      gs_st4(dt + r * ld + c4, dz);
+    }
+    __syncthreads();
+    // ---- per-workgroup column sums, published for the grid
+    int np2 = 8;
+    while (np2 < n_out) np2 <<= 1;
+    const int tpc = kRdThreads / np2;
+    const int c = tid & (np2 - 1), part = tid / np2;
+    const bool col_ok = c < n_out;
+    {
+      double s1 = 0.0, s2 = 0.0;
+      if (col_ok)
+        for (int r = part; r < rows; r += tpc) {
+          const float dz = dt[r * ld + c];
+          s1 += (double)dz;
+          s2 += (double)dz * (double)yt[r * ld + c];
+        }
+      s_d[tid] = s1;
+      s_d[kRdThreads + tid] = s2;
+      __syncthreads();
+      if (part == 0 && col_ok) {
+        for (int o = 1; o < tpc; ++o) {
+          s1 += s_d[o * np2 + c];
+          s2 += s_d[kRdThreads + o * np2 + c];
+        }
+        float *pp = a.part + ((int64_t)b * nwg + blockIdx.x) * 2 * h;
+        pp[c] = (float)s1;
+        pp[h + c] = (float)s2;
+      }
+    }
+    grid_barrier(a.sync + b, nwg, a.err);
+    {
+      const float *pp = a.part + (int64_t)b * nwg * 2 * h;
+      const int cc = col_ok ? c : 0;
+      double s1 = 0.0, s2 = 0.0;
+      for (int w0 = part; w0 < nwg; w0 += 8 * tpc) {
+        float g1[8], g2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int w = w0 + u * tpc < nwg ? w0 + u * tpc : nwg - 1;
+          g1[u] = __builtin_nontemporal_load(pp + (int64_t)w * 2 * h + cc);
+          g2[u] = __builtin_nontemporal_load(pp + (int64_t)w * 2 * h + h + cc);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (w0 + u * tpc < nwg) {
+            s1 += (double)g1[u];
+            s2 += (double)g2[u];
+          }
+      }
+      __syncthreads();
+      s_d[tid] = s1;
+      s_d[kRdThreads + tid] = s2;
+      __syncthreads();
+      if (part == 0 && col_ok) {
+        for (int o = 1; o < tpc; ++o) {
+          s1 += s_d[o * np2 + c];
+          s2 += s_d[kRdThreads + o * np2 + c];
+        }
+        // dy = gamma rstd (dz - s1/G - yhat s2/G) = a dz - b - c yhat
+        const float gr = a.gamma[b][c] * stat[n_out + c];
+        s_a[c] = gr;
+        s_b[c] = gr * (float)(s1 / (double)a.g);
+        s_c[c] = gr * (float)(s2 / (double)a.g);
+        if (blockIdx.x == 0) {
+          if (a.dgamma[b] != nullptr) a.dgamma[b][c] = (float)s2;
+          if (a.dbeta[b] != nullptr) a.dbeta[b][c] = (float)s1;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- dy (rows past the end stay zero: they must not reach the weight gradient)
+    for (int idx = tid; idx < kRdRows * q; idx += kRdThreads) {
+      const int r = idx / q, c4 = (idx - r * q) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rows) {
+        const f32x4 dz = gs_ld4(dt + r * ld + c4), yh = gs_ld4(yt + r * ld + c4);
+        v = gs_ld4(s_a + c4) * dz - gs_ld4(s_b + c4) - gs_ld4(s_c + c4) * yh;
+      }
+      gs_st4(yt + r * ld + c4, v);
+    }
+    __syncthreads();
+    // ---- dW_b partial = dy^T in_b ; dIn = dy W_b
+    const float *in = b == 0 ? a.pooled : a.ro + (int64_t)(b - 1) * rs;
+    rd_wgrad(yt, ld, in, row0, rows, n_out, n_in, a.slab_w[b] + (int64_t)blockIdx.x * n_out * n_in);
+    rd_gemm(yt, ld, a.wt[b], nullptr, n_out, n_in, dt, ld);
+    __syncthreads();
+  }
+  // ---- gradient of the pooled rows
+  for (int idx = tid; idx < rows * (h / 4); idx += kRdThreads) {
+    const int r = idx / (h / 4), c4 = (idx - r * (h / 4)) * 4;
+    gs_st4(a.dpooled + (row0 + r) * h + c4, gs_ld4(dt + r * ld + c4));
+  }
+}
+
 #ifdef GS_GF_TIMING
 extern "C" int gnnsaft_debug_readout_stamps(long long *host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_rd_stamp), sizeof(long long) * 64);
@@ -392,6 +636,93 @@ int launch_readout_fused(const ReadoutFusedParams &p, hipStream_t st) {
     attr_set = true;
   }
   hipLaunchKernelGGL(k_readout_fused, dim3((unsigned)wgs), dim3(kRdThreads), lds, st, a);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+size_t readout_bwd_scratch_floats(int64_t g, int h, int nblocks) {
+  const int64_t wgs = gs_ceil_div(g > 0 ? g : 1, (int64_t)kRdRows);
+  return (size_t)nblocks * wgs * 2 * h + (size_t)wgs * 8 + 64;
+}
+
+size_t readout_bwd_slab_floats(int64_t g, int h, int num_para, int nblocks) {
+  const int64_t wgs = gs_ceil_div(g > 0 ? g : 1, (int64_t)kRdRows);
+  size_t per_wg = (size_t)num_para * (h / 4) + 64;
+  int width = h;
+  for (int i = 0; i < nblocks; ++i) {
+    int n_out = h;
+    if (i == nblocks - 2) n_out = h / 2;
+    if (i == nblocks - 1) n_out = h / 4;
+    per_wg += (size_t)n_out * width + 64;
+    width = n_out;
+  }
+  return per_wg * (size_t)wgs;
+}
+
+bool readout_bwd_fused_supported(int64_t g, int h, int num_para, int nblocks) {
+  return readout_fused_supported(g, h, num_para, nblocks) && num_para <= 8 && (h % 64) == 0 && g >= 2 &&
+         nblocks + 1 <= kMaxSlabJobs;
+}
+
+int launch_readout_bwd_fused(const ReadoutBwdParams &p, SlabQueue &q, hipStream_t st) {
+  GS_REQUIRE(readout_bwd_fused_supported(p.g, p.h, p.num_para, p.nblocks), GNNSAFT_ERR_UNSUPPORTED);
+  GS_REQUIRE(p.grad_out && p.pooled && p.ry && p.ro && p.rstat && p.scratch && p.sync && p.dpooled, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(q.count + p.nblocks + 1 <= kMaxSlabJobs, GNNSAFT_ERR_WORKSPACE);
+  const int64_t wgs = gs_ceil_div(p.g, (int64_t)kRdRows);
+  ReadoutBwdArgs a;
+  a.g = p.g;
+  a.h = p.h;
+  a.num_para = p.num_para;
+  a.nblocks = p.nblocks;
+  a.grad_out = p.grad_out;
+  a.w_final = p.w[p.nblocks];
+  a.pooled = p.pooled;
+  a.ry = p.ry;
+  a.ro = p.ro;
+  a.rstat = p.rstat;
+  a.dpooled = p.dpooled;
+  a.dbias_final = p.db_final;
+  a.sync = p.sync;
+  a.err = p.err;
+  a.part = p.scratch;
+  a.bias_part = p.scratch + (size_t)p.nblocks * wgs * 2 * p.h;
+  GS_REQUIRE(a.w_final != nullptr && a.dbias_final != nullptr, GNNSAFT_ERR_NULL);
+  int width = p.h;
+  for (int i = 0; i <= kRdMaxBlocks; ++i) {
+    const bool live = i <= p.nblocks;
+    int n_out = p.h;
+    if (i == p.nblocks - 2) n_out = p.h / 2;
+    if (i == p.nblocks - 1) n_out = p.h / 4;
+    if (i == p.nblocks) n_out = p.num_para;
+    a.n_in[i] = width;
+    a.n_out[i] = n_out;
+    a.slab_w[i] = nullptr;
+    if (live) {
+      GS_REQUIRE(p.dw[i] != nullptr, GNNSAFT_ERR_NULL);
+      a.slab_w[i] = q.take((size_t)wgs * n_out * width);
+      GS_REQUIRE(a.slab_w[i] != nullptr, GNNSAFT_ERR_WORKSPACE);
+      SlabOut so{{p.dw[i], p.dw[i], p.dw[i], p.dw[i]}, (int64_t)1 << 40};
+      q.jobs[q.count++] = SlabJob{a.slab_w[i], (int64_t)n_out * width, wgs, width, so, width, 0};
+    }
+    width = n_out;
+    if (i < kRdMaxBlocks) {
+      const bool bl = i < p.nblocks;
+      a.wt[i] = bl ? p.wt[i] : nullptr;
+      a.gamma[i] = bl ? p.gamma[i] : nullptr;
+      a.beta[i] = bl ? p.beta[i] : nullptr;
+      a.dgamma[i] = bl ? p.dgamma[i] : nullptr;
+      a.dbeta[i] = bl ? p.dbeta[i] : nullptr;
+      GS_REQUIRE(!bl || (a.wt[i] && a.gamma[i] && a.beta[i]), GNNSAFT_ERR_NULL);
+    }
+  }
+  const size_t lds = ((size_t)2 * kRdRows * (p.h + kRdPad) + 3 * (size_t)p.h + kRdRows * 8) * sizeof(float) +
+                     2 * (size_t)kRdThreads * sizeof(double);
+  static const bool attr = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_readout_bwd_fused),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+  }();
+  (void)attr;
+  hipLaunchKernelGGL(k_readout_bwd_fused, dim3((unsigned)wgs), dim3(kRdThreads), lds, st, a);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }

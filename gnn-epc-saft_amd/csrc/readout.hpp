@@ -24,6 +24,29 @@ struct ReadoutFusedParams {
   int32_t *err;
 };
 
+// Backward of the readout in one launch (k_readout_bwd_fused): per-workgroup partial weight gradients go to `q`'s
+// arena and are reduced by its flush (launch_slab_queue_flush); BatchNorm and final-bias gradients are written directly.
+struct ReadoutBwdParams {
+  int64_t g;
+  int h, num_para, nblocks;
+  const float *grad_out;                     // [G, P]
+  const float *w[kRdMaxBlocks + 1];          // only the final Linear's [P, H/4] is read
+  const float *wt[kRdMaxBlocks];             // transposed block weights [n_in][n_out]
+  const float *gamma[kRdMaxBlocks], *beta[kRdMaxBlocks];
+  float *dw[kRdMaxBlocks + 1];               // weight gradients (final Linear last)
+  float *dgamma[kRdMaxBlocks], *dbeta[kRdMaxBlocks];
+  float *db_final;                           // [P]
+  const float *pooled, *ry, *ro, *rstat;     // the forward's tape
+  float *dpooled;                            // [G, H] out
+  float *scratch;                            // readout_bwd_scratch_floats
+  int32_t *sync;                             // kRdSyncInts ints, zero at launch
+  int32_t *err;                              // or null
+};
+size_t readout_bwd_scratch_floats(int64_t g, int h, int nblocks);
+size_t readout_bwd_slab_floats(int64_t g, int h, int num_para, int nblocks);
+bool readout_bwd_fused_supported(int64_t g, int h, int num_para, int nblocks);
+int launch_readout_bwd_fused(const ReadoutBwdParams &p, SlabQueue &q, hipStream_t st);
+
 size_t readout_fused_scratch_bytes(int64_t g, int h, int nblocks);
 bool readout_fused_supported(int64_t g, int h, int num_para, int nblocks);
 int launch_readout_fused(const ReadoutFusedParams &p, hipStream_t st);
