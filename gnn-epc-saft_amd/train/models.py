@@ -280,8 +280,12 @@ class PNAPCSAFT(nn.Module):
         return [t for t in weights if isinstance(t, nn.Parameter) and t.requires_grad]
 
     def _needs_grad(self) -> bool:
-        return torch.is_grad_enabled() and any(isinstance(t, nn.Parameter) and t.requires_grad
-                                               for t in self._weight_tensors())
+        if not torch.is_grad_enabled():
+            return False
+        first = next(iter(self._modules["node_embed"].parameters()), None)   # the usual case: everything trains
+        if first is not None and first.requires_grad:
+            return True
+        return any(isinstance(t, nn.Parameter) and t.requires_grad for t in self._weight_tensors())
 
     def _launch(self, data, target: Optional[torch.Tensor], tape: bool, weights: Optional[List[torch.Tensor]] = None):
         """One gnnsaft_forward call.  Returns (pred, loss3, ctx) where ctx holds what gnnsaft_backward needs

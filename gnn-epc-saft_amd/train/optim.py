@@ -75,6 +75,18 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self._flat = flat
 
     def _adopted(self) -> bool:
+        """Are the parameters still views of the flat buffer?  What breaks the adoption (``module.to()``, a loader that
+        assigns ``p.data``) replaces EVERY parameter's storage, so three probes per step stand for the full walk
+        (~110 tensors at L = 6: 0.08 ms per step); the full walk runs when a probe fails and before checkpoints."""
+        base = self._flat.data_ptr()
+        n = len(self._params)
+        for i in (0, n // 2, n - 1):
+            p = self._params[i]
+            if p.data_ptr() != base + 4 * self._offsets[i] or not p.is_contiguous():
+                return False
+        return True
+
+    def _adopted_all(self) -> bool:
         base = self._flat.data_ptr()
         return all(p.data_ptr() == base + 4 * off and p.is_contiguous() for p, off in zip(self._params, self._offsets))
 
@@ -97,11 +109,13 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 and owner.dtype == torch.float32:
             # views of ONE flat buffer in this optimizer's layout (what PNAPCSAFT's backward hands over)?
             zero_copy = True
-            for p, off in zip(self._params, self._offsets):
+            for p in self._params:      # (a view of `owner` with the parameter's shape: offsets were fixed at creation)
                 g = p.grad
-                if g is None or g._base is not owner or g.storage_offset() != off or not g.is_contiguous():
+                if g is None or g._base is not owner:
                     zero_copy = False
                     break
+            last = self._params[-1].grad
+            zero_copy = zero_copy and last.storage_offset() == self._offsets[-1] and last.is_contiguous()
             if zero_copy:
                 return owner
         if self._gather is None:
@@ -130,11 +144,15 @@ class _FlatOptimizer(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         self._reduced = None
-        super().zero_grad(set_to_none=set_to_none)
+        if set_to_none:                       # torch's loop carries profiler / foreach bookkeeping (0.09 ms at L = 6)
+            for p in self._params:
+                p.grad = None
+            return
+        super().zero_grad(set_to_none=False)
 
     def flat_parameters(self) -> torch.Tensor:
         """The one flat f32 buffer every parameter is a view of (broadcast / checksum it as a whole)."""
-        if not self._adopted():
+        if not self._adopted_all():
             self._adopt()
         return self._flat
 
