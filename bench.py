@@ -552,11 +552,7 @@ def bench_training_loop(args, dev, rank: int, world: int) -> None:
     opt, sched = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
     broadcast_training_state(lit, opt, sched, 0)
 
-    def batches():
-        while True:
-            yield from loader
-
-    it = batches()
+    it = loader.forever()     # epochs back to back, batches prefetched by the loader's background thread
     seen = [0]
 
     def train_step():
