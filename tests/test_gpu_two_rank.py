@@ -86,3 +86,31 @@ def test_two_processes_on_one_gpu_match_a_single_process_replay(tmp_path, overla
             for b in GraphLoader(graphs, 24, shuffle=False, device=DEV, rank=r, world_size=2):
                 parts += reps[r].model.run(b, target=b.para.view(-1, 3))[1][1:].double().cpu()
     assert abs(got[0]["global_mape"] - float(parts[0] / parts[1])) <= 1e-6 * want
+
+
+@pytest.mark.parametrize("config", [2, 5], ids=["C2-forward", "C5-training-loop"])
+def test_bench_two_rank_rehearsal_prints_one_whole_job_line(config):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), but with
+    both ranks on cuda:0 over gloo (GNNSAFT_BENCH_REHEARSAL=1): argument / environment handling, shard-by-rank
+    workloads, the loss / gradient exchange, barrier + max-over-ranks timing and the single rank-0 JSON line.  The
+    numbers mean nothing (two ranks share one GPU); the RCCL backend itself is the driver's to exercise."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GNNSAFT_BENCH_REHEARSAL="1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "2", "--config", str(config), "--train-steps", "2", "--no-cpu-baseline", "--no-c3"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]          # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is True and d["data"] == "synthetic"
+    per_step = 512 if config == 5 else 1024          # graphs per rank and step (C5: the last batch of a rank's epoch
+    ratio = d["value"] * d["ms_per_step"] * 1e-3 / (2 * per_step)     # is short: 1000 graphs = 512 + 488)
+    assert (0.9 < ratio <= 1.001) if config == 5 else abs(ratio - 1.0) < 0.02   # whole-job graphs / max-rank time
+    if config == 2:
+        assert "error" not in (d.get("train_step") or {}), d.get("train_step")
