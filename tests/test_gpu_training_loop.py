@@ -255,3 +255,41 @@ def test_graphed_training_step_equals_eager_steps():
         assert float(sa[i]["step"]) == float(sb[i]["step"]) == steps
         for key in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
             assert torch.equal(sa[i][key], sb[i][key]), (i, key)
+
+
+def test_loader_prefetch_thread_yields_the_same_batches_and_stops_cleanly():
+    """GraphLoader(prefetch=2) -- batches collated, staged and copied by a background thread -- against prefetch=0
+    (caller's thread): identical batches in identical order over two reshuffled epochs; forever() continues across
+    the epoch boundary with the same sequence; abandoning an iteration leaves no producer thread behind."""
+    import threading
+    from gnn_epc_saft_amd.data.loader import GraphLoader
+    from gnn_epc_saft_amd.data.synthetic import synthetic_dataset
+    graphs = synthetic_dataset(300, 77, num_para=3)
+
+    def same(x, y):
+        assert x.num_graphs == y.num_graphs
+        for name in ("x", "edge_index", "edge_attr", "batch", "ptr", "para"):
+            assert torch.equal(getattr(x, name), getattr(y, name)), name
+
+    a = GraphLoader(graphs, 64, shuffle=True, device=DEV, seed=3, prefetch=0)
+    b = GraphLoader(graphs, 64, shuffle=True, device=DEV, seed=3, prefetch=2)
+    expected = []
+    for _ in range(2):
+        ea, eb = list(a), list(b)
+        assert len(ea) == len(eb) == 5
+        for x, y in zip(ea, eb):
+            same(x, y)
+        expected.extend(ea)
+    c = GraphLoader(graphs, 64, shuffle=True, device=DEV, seed=3, prefetch=2)
+    it = c.forever()
+    for want in expected:
+        same(next(it), want)
+    it.close()                                   # generator abandoned mid-stream
+    for x in GraphLoader(graphs, 64, shuffle=False, device=DEV, prefetch=2):
+        break                                    # ... and a plain epoch left after its first batch
+    torch.cuda.synchronize()
+    import time
+    deadline = time.time() + 5.0
+    while any(t.name == "gnnsaft-loader" and t.is_alive() for t in threading.enumerate()) and time.time() < deadline:
+        time.sleep(0.05)
+    assert not any(t.name == "gnnsaft-loader" and t.is_alive() for t in threading.enumerate())
