@@ -173,6 +173,44 @@ def test_backward_is_reproducible_and_optimizer_step_reduces_loss():
     assert losses[-1] < losses[0]
 
 
+def test_backward_schedules_agree():
+    """The backward's alternative schedules against each other on one batch (1 024 graphs: 16 readout workgroups, ~80
+    TN slabs): (a) side stream on / off runs the SAME kernels on the same data -- bit-equal gradients (an ordering
+    bug between the two streams would show as garbage in a weight gradient); (b) the one-launch readout backward
+    (k_readout_bwd_fused) against the per-op chain (BatchNorm backward, TN GEMM + slab sum, dgrad per block) -- other
+    summation orders, so equal to f32 rounding of the gradient's own scale."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    from gnn_epc_saft_amd.train.models import mape_loss
+    data = make_synthetic_batch(1024, 77)
+    oracle = oracle_model(128, 3, 1, 1, 1, 3, True, True, degree_histogram(data), seed=5).train()
+    hip = hip_twin(oracle)
+    dd = data.to(DEV)
+    tgt = dd.para.view(-1, 3)
+    sd = copy.deepcopy(hip.state_dict())
+
+    def run(side_stream, fused_readout):
+        hip.load_state_dict(sd)
+        hip.backward_side_stream, hip.fused_readout = side_stream, fused_readout
+        hip.zero_grad()
+        loss = mape_loss(hip(dd), tgt)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.clone() for k, p in hip.named_parameters()}
+
+    l_two, g_two = run(True, True)
+    l_one, g_one = run(False, True)
+    assert l_two == l_one
+    for k in g_two:
+        assert torch.equal(g_two[k], g_one[k]), k
+    l_chain, g_chain = run(False, False)           # per-op readout, forward and backward
+    assert abs(l_chain - l_one) <= 2e-6 * abs(l_one)
+    scale = max(float(g.abs().max()) for g in g_one.values())
+    for k in g_one:
+        err = float((g_chain[k] - g_one[k]).abs().max())
+        # (+ an absolute floor: post_nns biases sit in front of lin -> BatchNorm, their gradient is rounding noise)
+        assert err <= 2e-5 * float(g_one[k].abs().max()) + 2e-7 * scale, (k, err)
+
+
 def test_unsupported_shapes_fail_loudly_in_grad_mode():
     from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
     data = make_synthetic_batch(8, 3)
