@@ -216,7 +216,8 @@ def test_c5_standin_default_model_training_loop():
     check_population(got, want32, want)
 
 
-def test_graphed_training_step_equals_eager_steps():
+@pytest.mark.parametrize("two_streams", [False, True], ids=["one-stream", "two-stream-capture"])
+def test_graphed_training_step_equals_eager_steps(two_streams):
     """GraphedTrainingStep (forward + backward + fused AdamW in one captured hipGraph, learning rate and bias
     corrections refreshed through the captured host-to-device copy) against the same number of eager steps on the
     same batch: the kernels and their order are the same, so parameters, optimizer state and BatchNorm statistics
@@ -224,6 +225,9 @@ def test_graphed_training_step_equals_eager_steps():
     import gnn_epc_saft_amd as G
     lit_a, batches, _ = _setup()
     lit_b, _, _ = _setup()
+    # the backward's side stream forks from and joins the capturing stream inside the capture (both modules alike:
+    # the two schedules give the same bits, test_backward_schedules_agree)
+    lit_a.model.backward_side_stream = lit_b.model.backward_side_stream = two_streams
     batch = batches[0]
     steps, warm = 7, 2
 
