@@ -82,6 +82,10 @@ struct LinearEpilogue {
   int64_t ldr = 0;
   float *stats = nullptr;         // [groups, 2, n_out] (mean, M2) partials
   int residual_is_mask = 0;       // out = residual > 0 ? v : 0 (ReLU backward) instead of v + residual
+  // eval-mode BatchNorm straight from its parameters: with bn_var set, `scale` / `shift` hold gamma / beta and the
+  // epilogue forms scale = gamma / sqrt(var + eps), shift = beta - mean scale itself (no finalize launch)
+  const float *bn_mean = nullptr, *bn_var = nullptr;
+  float bn_eps = 0.f;
 };
 
 struct GemmBatch {
@@ -96,6 +100,8 @@ struct EpiArgs {
   int64_t ldr;
   float *stats;
   int residual_is_mask;  // 1: out = residual > 0 ? v : 0 (ReLU backward) instead of v + residual
+  const float *bn_mean, *bn_var;   // eval-mode BatchNorm parameters (scale / shift then hold gamma / beta), or null
+  float bn_eps;
 };
 
 __device__ __forceinline__ f32x4 gs_relu4(f32x4 v) {

@@ -80,8 +80,6 @@ static int linear_bn_relu(const float *a, int64_t lda, const float *w, const flo
                           const BnPtrs &bn, const gnnsaft_model_desc *d, char *ws, const Plan &p, float *y_tmp,
                           const float *residual, float *out, hipStream_t st, gnnsaft_profile *prof = nullptr,
                           float *save_stat = nullptr) {
-  float *scale = reinterpret_cast<float *>(ws + p.scale);
-  float *shift = reinterpret_cast<float *>(ws + p.shift);
   float *stats = reinterpret_cast<float *>(ws + p.stats);
   GemmBatchEntry ent{w, b, nullptr, 0};
   if (d->training) {
@@ -96,12 +94,14 @@ static int linear_bn_relu(const float *a, int64_t lda, const float *w, const flo
     GS_TRY(gnnsaft_bn_train_apply(stats, y_tmp, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt,
                                   d->bn_momentum, d->bn_eps, residual, out, save_stat, ws + p.bnseg, p.bnseg_bytes, st));
   } else {
-    GS_TRY(gnnsaft_bn_finalize(nullptr, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, nullptr, d->bn_momentum,
-                               d->bn_eps, 0, scale, shift, st));
+    // running statistics: the GEMM epilogue forms scale / shift from (gamma, beta, mean, var) itself
     ent.out = out;
     LinearEpilogue epi;
-    epi.scale = scale;
-    epi.shift = shift;
+    epi.scale = bn.gamma;
+    epi.shift = bn.beta;
+    epi.bn_mean = bn.rmean;
+    epi.bn_var = bn.rvar;
+    epi.bn_eps = d->bn_eps;
     epi.relu_out = 1;
     epi.residual = residual;
     epi.ldr = n_out;

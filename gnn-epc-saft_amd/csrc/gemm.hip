@@ -448,6 +448,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
     if (AFFINE) {
       sc = epi.scale[colc];
       sh = epi.shift[colc];
+      if (epi.bn_var != nullptr) {   // the arithmetic of k_bn_finalize, eval branch (same rounding points)
+        const float rstd = 1.f / sqrtf(epi.bn_var[colc] + epi.bn_eps);
+        sc = rstd * sc;
+        sh = sh - epi.bn_mean[colc] * sc;
+      }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -562,7 +567,10 @@ static int dispatch(const AProv &ap, int nbatch, const GemmBatchEntry *entries, 
     GS_REQUIRE(entries[i].w != nullptr && entries[i].out != nullptr, GNNSAFT_ERR_NULL);
     GS_REQUIRE((reinterpret_cast<uintptr_t>(entries[i].w) & 15) == 0, GNNSAFT_ERR_SHAPE);
   }
-  EpiArgs ea{epi.scale, epi.shift, epi.relu_out, epi.residual, epi.ldr, epi.stats, epi.residual_is_mask};
+  EpiArgs ea{epi.scale, epi.shift, epi.relu_out, epi.residual, epi.ldr, epi.stats, epi.residual_is_mask,
+             epi.bn_mean, epi.bn_var, epi.bn_eps};
+  GS_REQUIRE((epi.bn_var == nullptr) == (epi.bn_mean == nullptr) && (epi.bn_var == nullptr || epi.scale != nullptr),
+             GNNSAFT_ERR_NULL);
   GS_REQUIRE((epi.scale == nullptr) == (epi.shift == nullptr), GNNSAFT_ERR_NULL);
   GS_REQUIRE(epi.stats == nullptr || nbatch == 1, GNNSAFT_ERR_SHAPE);
   const bool st = epi.stats != nullptr, af = epi.scale != nullptr, rs = epi.residual != nullptr;
@@ -636,7 +644,7 @@ int launch_pna_update_folded(const float *x, const float *agg, const int32_t *pe
   b.e[0] = GemmBatchEntry{w_eff, b_post0, u, 0};
   b.e[1] = GemmBatchEntry{w_eff + per_tower, b_post1, u + hidden / 2, 4 * (int64_t)hidden};
   for (int i = 2; i < kMaxGemmBatch; ++i) b.e[i] = b.e[0];
-  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
+  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0.f};
   return launch_cfg<PostFoldA, false, false, false>(ap, 2, b, 5 * (int64_t)hidden, hidden, n, hidden / 2, 5 * hidden,
                                                     ea, stream, tiled_cfg_for(hidden), max_tiles);
 }
@@ -652,7 +660,7 @@ int launch_linear_degree_tiled(const float *a, int64_t lda, const int32_t *perm,
   PermPlainA ap{a, lda, perm, tiles, num_tiles, w_stride, k};
   GemmBatch b;
   for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entries[i < nbatch ? i : 0];
-  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0};
+  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0.f};
   return launch_cfg<PermPlainA, false, false, false>(ap, nbatch, b, ldw, ldo, n, n_out, k, ea, stream,
                                                      tiled_cfg_for(hidden), max_tiles);
 }
@@ -670,7 +678,8 @@ int launch_linear_concat2(const float *a0, int64_t lda0, int k0, const float *a1
   if (m == 0) return GNNSAFT_OK;
   GemmBatch b;
   for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entry;
-  EpiArgs ea{nullptr, nullptr, epi.relu_out, epi.residual, epi.ldr, nullptr, epi.residual_is_mask};
+  EpiArgs ea{nullptr, nullptr, epi.relu_out, epi.residual, epi.ldr, nullptr, epi.residual_is_mask, nullptr, nullptr,
+             0.f};
   if (epi.residual != nullptr)
     return launch_cfg<Concat2A, false, false, true>(ap, 1, b, ldw, ldo, m, n_out, k0 + k1, ea, stream);
   return launch_cfg<Concat2A, false, false, false>(ap, 1, b, ldw, ldo, m, n_out, k0 + k1, ea, stream);
