@@ -338,7 +338,9 @@ static int pack_impl(const gnnsaft_model_desc *d, const EvalShape &s, const Eval
 }
 
 // ------------------------------------------------------------------------------------------ the graph kernel
-constexpr int kGfThreads = 1024;
+constexpr int kGfThreads = 1024;       // 16 waves: R <= 8 (float32) / 4 (float64) accumulator rows per thread
+constexpr int kGfThreadsWide = 512;    // 8 waves, twice the registers per thread: 16 / 8 rows -- a 9-16 atom molecule
+                                       // is ONE node tile (every tile re-streams the layer's weights)
 constexpr int kGfLdsNodes = 64;    // in-kernel CSR (single small graph): at most this many nodes ...
 constexpr int kGfLdsEdges = 256;   // ... and directed edges
 
@@ -371,13 +373,14 @@ __device__ long long g_gf_stamp[256];
 #define GF_STAMP(i) do {} while (0)
 #endif
 
-template <typename T, int R, class Accum, class Epi>
+template <typename T, int R, int NT, class Accum, class Epi>
 __device__ __forceinline__ void wg_gemm(int n_out, int K, GS_LDS(T) *red, Accum accum, Epi epi) {
+  constexpr int kWaves = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kl = lane >> 4, cl = lane & 15;
   int np2 = 16;
-  while (np2 < n_out && np2 < 256) np2 <<= 1;  // columns per pass
+  while (np2 < n_out && np2 < 16 * kWaves) np2 <<= 1;  // columns per pass
   const int groups = np2 >> 4;                 // waves side by side over the columns
-  const int ksw = 16 / groups;                 // waves stacked over K
+  const int ksw = kWaves / groups;             // waves stacked over K
   const int cg = wave % groups, ks = wave / groups;
   constexpr int KSTEP = 4 * 16 / (int)sizeof(T);   // k covered by one wave step (4 k-lanes x 16 B)
   const int kper = (((K + ksw - 1) / ksw) + KSTEP - 1) / KSTEP * KSTEP;
@@ -406,7 +409,7 @@ __device__ __forceinline__ void wg_gemm(int n_out, int K, GS_LDS(T) *red, Accum 
         for (int r = 0; r < R; ++r) red[(ks * R + r) * np2 + cg * 16 + cl] = acc[r];
       }
       __syncthreads();
-      for (int idx = tid; idx < R * np2; idx += kGfThreads) {
+      for (int idx = tid; idx < R * np2; idx += NT) {
         const int r = idx / np2, cc = idx - r * np2;
         if (c0 + cc < n_out) {
           T v = (T)0;
@@ -469,15 +472,16 @@ __device__ __forceinline__ void dot_range(T (&acc)[R], const GS_LDS(T) *a, int l
   }
 }
 
-template <typename T, int R>
-__global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
+template <typename T, int R, int NT>
+__global__ __launch_bounds__(NT) void k_graph_forward(GraphArgs<T> a) {
+  constexpr int kRed = 16 * (NT / 64) * R;   // wg_gemm's cross-wave reduction buffer
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const EvalShape &s = a.s;
   const EvalLayout &lay = a.lay;
   const int h = s.h, f = s.h, tid = threadIdx.x;
   // ---- LDS carve-up
-  GS_LDS(T) *red = (GS_LDS(T) *)smem;          // [256 R]
-  GS_LDS(T) *xt = red + 256 * R;               // [R][F]   x tile (update) / scratch
+  GS_LDS(T) *red = (GS_LDS(T) *)smem;          // [kRed]
+  GS_LDS(T) *xt = red + kRed;                  // [R][F]   x tile (update) / scratch
   GS_LDS(T) *zt = xt + R * f;                  // [R][2][13F] update operand cat[x, A, A amp, A att] per tower
                                                //             (also: edge-row tiles of the extra pre layers)
   GS_LDS(T) *ut = zt + R * 26 * f;             // [R][H]   update output
@@ -509,9 +513,9 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
     int32_t *l_rp = l_int, *l_cnt = l_int + (kGfLdsNodes + 1), *l_src = l_cnt + kGfLdsNodes,
             *l_combo = l_src + (kGfLdsEdges + kGfLdsNodes);
     const int e = (int)a.e;
-    for (int i = tid; i < n; i += kGfThreads) l_cnt[i] = 0;
+    for (int i = tid; i < n; i += NT) l_cnt[i] = 0;
     __syncthreads();
-    for (int i = tid; i < e; i += kGfThreads) {
+    for (int i = tid; i < e; i += NT) {
       const int64_t sv = a.edge_index[i], dv = a.edge_index[e + i];
       if (sv < 0 || sv >= n || dv < 0 || dv >= n) {
         if (a.err) atomicOr(a.err, GNNSAFT_FLAG_BAD_EDGE);
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
       l_rp[n] = run;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += kGfThreads) {  // thread per destination: edges in edge_index order
+    for (int i = tid; i < n; i += NT) {  // thread per destination: edges in edge_index order
       int pos = l_rp[i];
       for (int ed = 0; ed < e; ++ed) {
         const int64_t sv = a.edge_index[ed], dv = a.edge_index[e + ed];
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
   // ---- AtomEncoder: x[i, c] = sum_k tab_k[idx[i, k], c]  (left to right)
   {
     const T *atoms = a.pack + lay.atoms;
-    for (int idx = tid; idx < n * h; idx += kGfThreads) {
+    for (int idx = tid; idx < n * h; idx += NT) {
       const int i = idx / h, c = idx - i * h;
       T acc = (T)0;
       for (int k = 0; k < s.n_atom_cols; ++k) {
@@ -600,13 +604,13 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
     // ---- P | Q for every node of the graph
     for (int t0 = 0; t0 < n; t0 += R) {
       const int rows = n - t0 < R ? n - t0 : R;
-      for (int idx = tid; idx < rows * f; idx += kGfThreads) {
+      for (int idx = tid; idx < rows * f; idx += NT) {
         const int r = idx / f, c = idx - r * f;
         xt[r * f + c] = x_cur[(int64_t)(t0 + r) * h + c];
       }
       __syncthreads();
       const T *w = lw + lay.wpq;
-      wg_gemm<T, R>(
+      wg_gemm<T, R, NT>(
           4 * f, h, red,
           [&](T(&acc)[R], int col, int kb, int ke, int kl) { dot_range<T, R, false>(acc, xt, f, w, 4 * (int64_t)h, col, kb, ke, kl); },
           [&](int r, int col, T v) {
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
       for (int e0 = row_lo; e0 < row_hi; e0 += R) {
         const int rows = row_hi - e0 < R ? row_hi - e0 : R;
         // h1 = P[dst] + Q[src] + rtab[class]   (pre-activation of the first pre layer)
-        for (int idx = tid; idx < rows * 2 * f; idx += kGfThreads) {
+        for (int idx = tid; idx < rows * 2 * f; idx += NT) {
           const int r = idx / (2 * f), c = idx - r * 2 * f;
           const int row = e0 + r;
           // destination of a CSR row: binary search in rp
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
           const T *px = lw + lay.prex + (int64_t)(j - 1) * lay.prex_stride;
           const T *bx = px + 2 * (int64_t)h * h;
           const bool last = j == s.pre - 1;
-          wg_gemm<T, R>(
+          wg_gemm<T, R, NT>(
               2 * f, f, red,
               [&](T(&acc)[R], int col, int kb, int ke, int kl) {
                 dot_range<T, R, true>(acc, cur + (col / f) * f, 2 * f, px, 2 * (int64_t)h, col, kb, ke, kl);
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
     // ---- node tiles: aggregate -> update -> lin (+BN) -> ReLU -> (+x)
     for (int t0 = 0; t0 < n; t0 += R) {
       const int rows = n - t0 < R ? n - t0 : R;
-      for (int idx = tid; idx < rows * f; idx += kGfThreads) {
+      for (int idx = tid; idx < rows * f; idx += NT) {
         const int r = idx / f, c = idx - r * f;
         const T xv = x_cur[(int64_t)(t0 + r) * h + c];
         xt[r * f + c] = xv;
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
         zt[(r * 2 + 1) * 13 * f + c] = xv;
       }
       // mean | min | max | std over the in-edges (sums of m - m_first: no cancellation in the variance)
-      for (int idx = tid; idx < rows * 2 * f; idx += kGfThreads) {
+      for (int idx = tid; idx < rows * 2 * f; idx += NT) {
         const int r = idx / (2 * f), c = idx - r * 2 * f;
         const int i = t0 + r;
         const int beg = rp[i], end = rp[i + 1];
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
       // update: u[r, t F/2 + o] = W_t[o, :] . cat[x, A_t, amp A_t, att A_t] + b   (K = 13 F, one weight stream)
       {
         const T *w = lw + lay.wpost, *b = lw + lay.bpost;
-        wg_gemm<T, R>(
+        wg_gemm<T, R, NT>(
             f, 13 * f, red,
             [&](T(&acc)[R], int col, int kb, int ke, int kl) {
               dot_range<T, R, false>(acc, zt + (col / (f / 2)) * 13 * f, 26 * f, w, (int64_t)h, col, kb, ke, kl);
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
       for (int j = 1; j < s.post; ++j) {
         const T *px = lw + lay.postx + (int64_t)(j - 1) * lay.postx_stride;
         const T *bx = px + (int64_t)(h / 2) * h;
-        wg_gemm<T, R>(
+        wg_gemm<T, R, NT>(
             h, h / 2, red,
             [&](T(&acc)[R], int col, int kb, int ke, int kl) {
               dot_range<T, R, true>(acc, ucur + (col / (h / 2)) * (h / 2), h, px, (int64_t)h, col, kb, ke, kl);
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
       // lin with the eval-mode BatchNorm folded in, ReLU, residual
       {
         const T *w = lw + lay.wlin, *sc = lw + lay.slin, *b = lw + lay.blin;
-        wg_gemm<T, R>(
+        wg_gemm<T, R, NT>(
             h, h, red,
             [&](T(&acc)[R], int col, int kb, int ke, int kl) { dot_range<T, R, false>(acc, ucur, h, w, (int64_t)h, col, kb, ke, kl); },
             [&](int r, int col, T v) {
@@ -777,7 +781,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
   }
 
   // ---- global_add_pool + readout MLP (BatchNorm folded), one row
-  for (int c = tid; c < h; c += kGfThreads) {
+  for (int c = tid; c < h; c += NT) {
     T acc = (T)0;
     for (int i = 0; i < n; ++i) acc += x_cur[(int64_t)i * h + c];
     ut[c] = acc;
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
     readout_block(s, lay, i, wo, bo, n_in, n_out);
     const T *w = a.pack + wo, *b = a.pack + bo, *sc = b - up4(n_out);
     const bool last = i == s.mlp + 2;
-    wg_gemm<T, R>(
+    wg_gemm<T, R, NT>(
         n_out, n_in, red,
         [&](T(&acc)[R], int col, int kb, int ke, int kl) {   // lda = 0: every accumulator row sees the one pooled row
           dot_range<T, R, false>(acc, cur, 0, w, (int64_t)n_out, col, kb, ke, kl);
@@ -809,17 +813,28 @@ __global__ __launch_bounds__(kGfThreads) void k_graph_forward(GraphArgs<T> a) {
   GF_STAMP(251);
 }
 
-static size_t gf_fixed_lds_elems(int h, int r) { return (size_t)256 * r + (size_t)r * h + (size_t)r * 26 * h + 2 * (size_t)r * h + 2 * (size_t)r; }
+static size_t gf_fixed_lds_elems(int h, int r, int threads = kGfThreads) {
+  return (size_t)16 * (threads / 64) * r + (size_t)r * h + (size_t)r * 26 * h + 2 * (size_t)r * h + 2 * (size_t)r;
+}
 static size_t gf_csr_lds_bytes() { return (size_t)(kGfLdsNodes + 1 + kGfLdsNodes + 2 * (kGfLdsEdges + kGfLdsNodes)) * 4 + 16; }
 constexpr size_t kGfLdsBudget = 150 * 1024;  // of the 160 KB of a gfx950 CU
 
 // rows per node tile = accumulators per thread: at most 8 in float32 / 4 in float64 (128 VGPRs at 1024 threads), and
 // what the [R][2][13F] operand tile leaves of the LDS; halved for a single molecule that would leave the tile half empty
-static int gf_tile_rows(int h, size_t elem, int64_t n, int64_t g) {
+static int gf_tile_rows(int h, size_t elem, int64_t n, int64_t g, int &threads) {
+  threads = kGfThreads;
   int r = elem == 4 ? 8 : 4;
   while (r > 2 && gf_fixed_lds_elems(h, r) * elem + gf_csr_lds_bytes() > kGfLdsBudget - 16 * 1024) r /= 2;
   const int floor_r = elem == 4 ? 4 : 2;
   if (g == 1 && n <= r / 2 && r / 2 >= floor_r) r /= 2;
+  // a single molecule with more atoms than one tile holds: 512 threads with twice the accumulator rows, when the
+  // wider operand tile still fits (hidden_dim 64, the reference's default model)
+  const int wide_r = elem == 4 ? 16 : 8;
+  if (g == 1 && n > r && r == wide_r / 2 &&
+      gf_fixed_lds_elems(h, wide_r, kGfThreadsWide) * elem + gf_csr_lds_bytes() <= kGfLdsBudget - 16 * 1024) {
+    r = wide_r;
+    threads = kGfThreadsWide;
+  }
   return r;
 }
 
@@ -856,15 +871,15 @@ static int gf_plan(const gnnsaft_model_desc *d, size_t elem, int64_t n, int64_t 
   return GNNSAFT_OK;
 }
 
-template <typename T, int R>
+template <typename T, int R, int NT = kGfThreads>
 static int gf_launch(const GraphArgs<T> &a, int64_t g, size_t lds_bytes, hipStream_t st) {
   static bool attr_set = false;  // idempotent: the attribute is a property of the kernel, set once per process
   if (!attr_set) {
-    GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_graph_forward<T, R>),
+    GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_graph_forward<T, R, NT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGfLdsBudget));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_graph_forward<T, R>), dim3((unsigned)g), dim3(kGfThreads), lds_bytes, st, a);
+  hipLaunchKernelGGL((k_graph_forward<T, R, NT>), dim3((unsigned)g), dim3(NT), lds_bytes, st, a);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }
@@ -909,8 +924,9 @@ static int graph_forward_impl(const gnnsaft_model_desc *d, const void *pack, con
     a.combo = I(p.combo);
     a.graph_ptr = I(p.graph_ptr);
   }
-  const int r = gf_tile_rows(s.h, sizeof(T), n, g);
-  const size_t fixed = gf_fixed_lds_elems(s.h, r) * sizeof(T);
+  int threads = kGfThreads;
+  const int r = gf_tile_rows(s.h, sizeof(T), n, g, threads);
+  const size_t fixed = gf_fixed_lds_elems(s.h, r, threads) * sizeof(T);
   const size_t csr_b = gf_csr_lds_bytes();
   GS_REQUIRE(fixed + csr_b <= kGfLdsBudget, GNNSAFT_ERR_UNSUPPORTED);
   size_t state_elems = (kGfLdsBudget - fixed - csr_b) / sizeof(T);
@@ -922,8 +938,10 @@ static int graph_forward_impl(const gnnsaft_model_desc *d, const void *pack, con
   a.lds_state_elems = (int)state_elems;
   const size_t lds_bytes = fixed + state_elems * sizeof(T) + csr_b;
   if constexpr (sizeof(T) == 4) {
+    if (threads == kGfThreadsWide) return gf_launch<T, 16, kGfThreadsWide>(a, g, lds_bytes, st);
     return r == 8 ? gf_launch<T, 8>(a, g, lds_bytes, st) : gf_launch<T, 4>(a, g, lds_bytes, st);
   } else {
+    if (threads == kGfThreadsWide) return gf_launch<T, 8, kGfThreadsWide>(a, g, lds_bytes, st);
     return r == 4 ? gf_launch<T, 4>(a, g, lds_bytes, st) : gf_launch<T, 2>(a, g, lds_bytes, st);
   }
 }
