@@ -164,6 +164,15 @@ template <typename T>
 __device__ __forceinline__ T t_max(T a, T b) { return a > b ? a : b; }
 template <typename T>
 __device__ __forceinline__ T t_min(T a, T b) { return a < b ? a : b; }
+// fused multiply-add of the dot products.  The library is built with -ffp-contract=off (the batched pipeline keeps
+// torch's rounding points), which would make every multiply-add of this VALU-bound kernel two instructions; a GEMM's
+// summation order is free anyway (the oracle's BLAS uses FMA too), so the dots contract explicitly.
+template <typename T>
+__device__ __forceinline__ T t_fma(T a, T b, T c);
+template <>
+__device__ __forceinline__ float t_fma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <>
+__device__ __forceinline__ double t_fma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // dst[k * ldd + c0 + j] = src[j * lds + k] * s_j,  s_j = gamma_j / sqrt(var_j + eps) (eval-mode BatchNorm) or 1
 template <typename T>
@@ -463,7 +472,7 @@ __device__ __forceinline__ void dot_range(T (&acc)[R], const GS_LDS(T) *a, int l
         for (int j2 = 0; j2 < V; ++j2) {
           T x = av[j2];
           if (RELU) x = t_max<T>(x, (T)0);
-          acc[r] += x * (live ? wv[st * V + j2] : (T)0);
+          acc[r] = t_fma<T>(x, live ? wv[st * V + j2] : (T)0, acc[r]);
         }
       }
     }
