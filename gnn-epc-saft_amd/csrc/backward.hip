@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
                                                       const float *__restrict__ beta, int64_t rows, int ch,
                                                       int64_t rows_per_chunk, const float *__restrict__ partial,
                                                       int64_t chunks, float *__restrict__ dgamma,
-                                                      float *__restrict__ dbeta, float *__restrict__ dy) {
+                                                      float *__restrict__ dbeta, float *__restrict__ dy, int eval_bn) {
   __shared__ double s1s[8][kBwdCols], s2s[8][kBwdCols];
   __shared__ float s_a[kBwdCols], s_b[kBwdCols], s_c[kBwdCols], s_mean[kBwdCols], s_rstd[kBwdCols], s_g[kBwdCols],
       s_bt[kBwdCols];
@@ -158,10 +158,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
       s2 += s2s[o][cl];
     }
     const float gm = gamma[colc], rstd = stat[ch + colc];
-    // dy = gamma*rstd*(dz - s1/N - yhat*s2/N) = a*dz - b - c*yhat
+    // dy = gamma*rstd*(dz - s1/N - yhat*s2/N) = a*dz - b - c*yhat   (running statistics: a constant affine map,
+    // the two batch-mean terms vanish)
     s_a[cl] = gm * rstd;
-    s_b[cl] = gm * rstd * (float)(s1 / (double)rows);
-    s_c[cl] = gm * rstd * (float)(s2 / (double)rows);
+    s_b[cl] = eval_bn ? 0.f : gm * rstd * (float)(s1 / (double)rows);
+    s_c[cl] = eval_bn ? 0.f : gm * rstd * (float)(s2 / (double)rows);
     s_mean[cl] = stat[colc];
     s_rstd[cl] = rstd;
     s_g[cl] = gm;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
 
 static int bn_relu_backward(const float *y, const float *dout, const float *stat, const float *gamma,
                             const float *beta, int64_t rows, int ch, float *dgamma, float *dbeta, float *dy,
-                            float *partial, hipStream_t st) {
+                            float *partial, hipStream_t st, int eval_bn = 0) {
   GS_REQUIRE(ch >= 4 && (ch % 4) == 0, GNNSAFT_ERR_UNSUPPORTED);
   const int slabs = (ch + kBwdCols - 1) / kBwdCols;
   int64_t chunks = 512 / slabs;
@@ -207,7 +208,7 @@ static int bn_relu_backward(const float *y, const float *dout, const float *stat
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3((unsigned)slabs, (unsigned)chunks), dim3(256), 0, st, y, dout, stat, gamma,
                      beta, rows, ch, rpc, partial);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)slabs, (unsigned)chunks), dim3(256), 0, st, y, dout, stat, gamma,
-                     beta, rows, ch, rpc, partial, chunks, dgamma, dbeta, dy);
+                     beta, rows, ch, rpc, partial, chunks, dgamma, dbeta, dy, eval_bn);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }
@@ -569,9 +570,9 @@ static BwdSizes backward_sizes(const gnnsaft_model_desc *d, const Plan &p) {
   const size_t s4 = (size_t)p.combos <= (size_t)kClassGemmMax ? tn_slab_bytes(p.ep, (int)p.combos, (int)(2 * h)) : 0;
   const size_t s5 = tn_slab_bytes(rows, (int)h, (int)h);                 // lin
   const size_t s6 = (rows / 256 + 2) * h * 4;                            // column-sum partials
-  size_t slab = s1 + s3 + s4 + s5 + s6 + 8 * 256;
+  size_t slab = s1 + s3 + s4 + s5 + 2 * s6 + 8 * 256;   // (two column-sum sets with an eval-mode BatchNorm)
   slab = slab > s2 ? slab : s2;
-  const bool rb_fused = !d->unfused_readout && readout_bwd_fused_supported(p.g, (int)h, d->num_para, p.nb);
+  const bool rb_fused = !d->unfused_readout && d->training && readout_bwd_fused_supported(p.g, (int)h, d->num_para, p.nb);
   const size_t s7 = rb_fused ? readout_bwd_slab_floats(p.g, (int)h, d->num_para, p.nb) * 4 : 0;
   slab = slab > s7 ? slab : s7;
   size_t tot = 0;
@@ -640,7 +641,10 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
                                 gnnsaft_stream_t stream) {
   (void)batch;
   GS_REQUIRE(d && weights_host && grads_host && grad_out && tape && scratch && x_idx, GNNSAFT_ERR_NULL);
-  GS_REQUIRE(d->save_tape && d->training, GNNSAFT_ERR_UNSUPPORTED);
+  GS_REQUIRE(d->save_tape, GNNSAFT_ERR_UNSUPPORTED);
+  // eval-mode BatchNorm (running statistics; fine-tuning with frozen statistics): BatchNorm is a constant affine map,
+  // and the biases in front of it have real gradients again
+  const int eval_bn = d->training ? 0 : 1;
   GS_REQUIRE(d->pre_layers >= 1 && d->pre_layers <= 8 && d->post_layers >= 1 && d->post_layers <= 8 &&
                  (d->hidden % 64) == 0 && d->fold_degree_scalers && !d->fold_dst_term,
              GNNSAFT_ERR_UNSUPPORTED);
@@ -727,7 +731,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   GS_REQUIRE(det != nullptr && wt_layers != nullptr && wt_readout != nullptr && rb_scratch != nullptr &&
                  rb_sync != nullptr,
              GNNSAFT_ERR_WORKSPACE);
-  const bool rb_fused = !d->unfused_readout && readout_bwd_fused_supported(g, h, P, p.nb);
+  const bool rb_fused = !d->unfused_readout && d->training && readout_bwd_fused_supported(g, h, P, p.nb);
   const size_t slab_bytes = bs.slab;
   SlabQueue sq;   // one layer's reductions, summed by one launch (side stream)
   sq.base = slabs;
@@ -800,11 +804,13 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       z.n[cnt] = count;
       if (++cnt == kMaxZeroList) flush();
     };
-    for (int l = 0; l < L; ++l) {
-      const int i_lin = pw.layer_base[l] + 3 + 4 * d->pre_layers + 4 * d->post_layers;
-      push(G(i_lin + 1), h);
+    if (!eval_bn) {
+      for (int l = 0; l < L; ++l) {
+        const int i_lin = pw.layer_base[l] + 3 + 4 * d->pre_layers + 4 * d->post_layers;
+        push(G(i_lin + 1), h);
+      }
+      for (int bi = 0; bi < nb; ++bi) push(G(pw.readout_base[bi] + 1), pw.readout[bi].n_out);
     }
-    for (int bi = 0; bi < nb; ++bi) push(G(pw.readout_base[bi] + 1), pw.readout[bi].n_out);
     push(w3T, h * 8);   // zero padding of the final Linear's transposed weight (filled by the batched transpose)
     push(reinterpret_cast<float *>(rb_sync), kRdSyncInts);   // barrier counters of the fused readout backward
     flush();
@@ -897,7 +903,9 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
       const float *yb = F(p.ry) + bi * rs;
       const float *in = bi == 0 ? F(p.pooled) : F(p.ro) + (bi - 1) * rs;
       const float *stat = F(p.rstat) + (int64_t)bi * 2 * h;
-      GS_TRY(bn_relu_backward(yb, dcur, stat, rw.bn.gamma, rw.bn.beta, g, rw.n_out, G(ib + 2), G(ib + 3), dyr, bnpart, st));
+      GS_TRY(bn_relu_backward(yb, dcur, stat, rw.bn.gamma, rw.bn.beta, g, rw.n_out, G(ib + 2), G(ib + 3), dyr, bnpart, st,
+                              eval_bn));
+      if (eval_bn) GS_TRY(launch_colsum(dyr, rw.n_out, g, rw.n_out, G(ib + 1), 0, slabs, slab_bytes, st));
       GS_TRY(launch_wgrad_plain(dyr, rw.n_out, in, rw.n_in, 0, g, rw.n_out, rw.n_in, G(ib), rw.n_in, 0, slabs, slab_bytes,
                                 st));
       // (bias gradient: exactly zero, written above)
@@ -951,13 +959,17 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     float *wlinT_l = wl, *wxpqT_l = wl + (size_t)h * h, *wcT_l = wl + 6 * (size_t)h * h, *weT_l = wl + 8 * (size_t)h * h;
     const int64_t h5 = 5 * (int64_t)h;
     // x_{l+1} = relu(bn(y)) + x_l : dy through BN+ReLU; the skip gradient stays in dx
-    GS_TRY(bn_relu_backward(y_l, dx, stat, w.bn.gamma, w.bn.beta, n, h, G(i_bn), G(i_bn + 1), dy, bnpart, st));
+    GS_TRY(bn_relu_backward(y_l, dx, stat, w.bn.gamma, w.bn.beta, n, h, G(i_bn), G(i_bn + 1), dy, bnpart, st, eval_bn));
     // lin: input gradient (main), then the fork for this layer's first side batch: weight gradient of lin (needs
     // dy), of the update and its biases (need du)
     // (lin.bias sits in front of the BatchNorm: gradient exactly zero, written by the zero list)
     GS_TRY(dgrad(st, dy, h, wlinT_l, h, du, h, n, h, h, nullptr));
     GS_TRY(order(st, sa));
     GS_TRY(launch_wgrad_plain(dy, h, u_l, h, 0, n, h, h, G(i_lin), h, 0, slabs, slab_bytes, sa, dq));
+    if (eval_bn) {   // lin.bias: a real gradient behind a frozen BatchNorm
+      float *outs[1] = {G(i_lin + 1)};
+      GS_TRY(launch_colsum_blocks(dy, h, n, 1, h, outs, slabs, slab_bytes, sa, dq));
+    }
     // extra post layers (Linear(F/2,F/2) after a ReLU, per tower), last to first: du_j -> du_{j-1}  (single stream)
     for (int j = q - 1; j >= 1; --j) {
       const float *u_prev = u_first + (int64_t)(j - 1) * n * h;  // pre-ReLU input of post layer j

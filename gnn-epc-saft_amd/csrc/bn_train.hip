@@ -177,6 +177,46 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
   }
 }
 
+// eval-mode BatchNorm (+ ReLU, + residual) of a kept pre-activation tensor: out = relu(y scale + shift) (+ residual)
+// with scale = gamma / sqrt(running_var + eps), shift = beta - running_mean scale formed per thread; (running_mean, rstd)
+// go to `save_stat` in the layout k_bn_train_apply keeps its batch statistics in, so that the backward reads either.
+__global__ __launch_bounds__(256) void k_bn_eval_apply(const float *__restrict__ y, int64_t rows, int ch,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       const float *__restrict__ rmean, const float *__restrict__ rvar,
+                                                       float eps, const float *__restrict__ residual,
+                                                       float *__restrict__ out, float *__restrict__ save_stat) {
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= rows * ch) return;
+  const int c = (int)(i4 % ch);
+  const f32x4 yv = gs_ld4(y + i4), gm = gs_ld4(gamma + c), bt = gs_ld4(beta + c), mn = gs_ld4(rmean + c),
+              vr = gs_ld4(rvar + c);
+  f32x4 o, rs;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float rstd = 1.f / sqrtf(vr[j] + eps);
+    const float sc = rstd * gm[j];
+    rs[j] = rstd;
+    o[j] = fmaxf(yv[j] * sc + (bt[j] - mn[j] * sc), 0.f);
+  }
+  if (residual != nullptr) o += gs_ld4(residual + i4);
+  gs_st4(out + i4, o);
+  if (save_stat != nullptr && i4 < ch) {   // the first row's threads cover every channel once
+    gs_st4(save_stat + c, mn);
+    gs_st4(save_stat + ch + c, rs);
+  }
+}
+
+int launch_bn_eval_apply(const float *y, int64_t rows, int ch, const float *gamma, const float *beta,
+                         const float *rmean, const float *rvar, float eps, const float *residual, float *out,
+                         float *save_stat, hipStream_t st) {
+  GS_REQUIRE(y && out && gamma && beta && rmean && rvar, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(rows >= 1 && ch >= 4 && (ch % 4) == 0, GNNSAFT_ERR_SHAPE);
+  hipLaunchKernelGGL(k_bn_eval_apply, dim3((unsigned)gs_ceil_div(rows * ch / 4, 256)), dim3(256), 0, st, y, rows, ch,
+                     gamma, beta, rmean, rvar, eps, residual, out, save_stat);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
 }  // namespace gs
 
 extern "C" size_t gnnsaft_bn_train_scratch_bytes(int64_t num_rows, int32_t channels) {

@@ -142,6 +142,12 @@ int launch_linear_degree_tiled(const float *a, int64_t lda, const int32_t *perm,
                                const GemmBatchEntry *entries, int64_t ldw, int64_t ldo, int64_t n, int n_out, int k,
                                int hidden /* the tile table was built for */, hipStream_t stream);
 
+// eval-mode BatchNorm + ReLU (+ residual) of a kept pre-activation tensor (bn_train.hip); `save_stat` [2][ch] receives
+// (running_mean, rstd) for the backward
+int launch_bn_eval_apply(const float *y, int64_t rows, int ch, const float *gamma, const float *beta,
+                         const float *rmean, const float *rvar, float eps, const float *residual, float *out,
+                         float *save_stat, hipStream_t st);
+
 // ---- backward building blocks (gemm_tn.hip, csr.hip)
 // Row blocks of a dense [rows, cols] result go to separate matrices: block b = row / rows_per_block -> base[b]
 struct SlabOut {

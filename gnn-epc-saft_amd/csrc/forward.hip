@@ -93,6 +93,16 @@ static int linear_bn_relu(const float *a, int64_t lda, const float *w, const flo
     }
     GS_TRY(gnnsaft_bn_train_apply(stats, y_tmp, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt,
                                   d->bn_momentum, d->bn_eps, residual, out, save_stat, ws + p.bnseg, p.bnseg_bytes, st));
+  } else if (d->save_tape) {
+    // eval mode WITH a tape (fine-tuning with frozen statistics): the pre-activation is kept, as in training
+    ent.out = y_tmp;
+    LinearEpilogue epi;
+    {
+      ProfScope ps(prof, GNNSAFT_PROF_LIN, st);
+      GS_TRY(launch_linear(a, lda, 0, 1, &ent, k, n_out, rows, n_out, k, epi, st));
+    }
+    GS_TRY(launch_bn_eval_apply(y_tmp, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, d->bn_eps, residual, out,
+                                save_stat, st));
   } else {
     // running statistics: the GEMM epilogue forms scale / shift from (gamma, beta, mean, var) itself
     ent.out = out;
@@ -640,7 +650,8 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
   }
 
   // ---- readout: one launch (readout.hip) while its workgroups are co-resident, the per-op path beyond
-  if (readout_fused_supported(g, h, d->num_para, p.nb) && !d->unfused_readout) {
+  // (an eval-mode tape keeps the readout's pre-activations through the per-op path)
+  if (readout_fused_supported(g, h, d->num_para, p.nb) && !d->unfused_readout && !(d->save_tape && !d->training)) {
     GS_TRY(gnnsaft_add_pool(xc, I(p.graph_ptr), g, n, h, F(p.pooled), st));
     ReadoutFusedParams rp{};
     rp.x = xc;

@@ -312,8 +312,6 @@ class PNAPCSAFT(nn.Module):
             g = int(g)
         desc = self._model_desc()
         if tape:
-            if not self.training:
-                raise NotImplementedError("backward is implemented for train-mode BatchNorm only (model.train())")
             if desc.hidden % 64 != 0 or desc.num_para > 8:
                 raise NotImplementedError("backward needs hidden_dim % 64 == 0 and num_para <= 8 (the reference's "
                                           "envelope: 64 / 128 / 256, 3 or 5); run other shapes under torch.no_grad()")

@@ -371,8 +371,10 @@ int gnnsaft_structure_build(const gnnsaft_model_desc *desc, const int64_t *edge_
 /* ------------------------------------------------------------------------ */
 /* Backward of the path (what autograd does when Lightning calls               */
 /* loss.backward() after training_step, models.py:191-202).  Run               */
-/* gnnsaft_forward with desc->save_tape = 1, training = 1, fold_degree_scalers  */
-/* = 1, fold_dst_term = 0 and keep its workspace (`tape`) untouched; then      */
+/* gnnsaft_forward with desc->save_tape = 1, fold_degree_scalers = 1,           */
+/* fold_dst_term = 0 (training = 1: batch statistics; training = 0: running     */
+/* statistics, i.e. fine-tuning behind frozen BatchNorm -- the same value in     */
+/* both calls) and keep its workspace (`tape`) untouched; then                  */
 /* gnnsaft_backward writes dL/dparam for EVERY parameter into `grads_host`      */
 /* (HOST array of device pointers, same order and shapes as `weights_host`;     */
 /* entries of buffers -- avg_deg_log, running statistics, counters -- are       */

@@ -45,8 +45,8 @@ def test_wgrad_tn_kernel_matches_f64():
         assert rel_err(db.cpu(), dy[:, :n_out].double().sum(0)) < 3e-6
 
 
-def grads_of(model, data, num_para, dtype):
-    m = copy.deepcopy(model).to(dtype).train()
+def grads_of(model, data, num_para, dtype, train=True):
+    m = copy.deepcopy(model).to(dtype).train(train)
     for p in m.parameters():
         p.grad = None
     loss = mape(m(data), data.para.view(-1, num_para).to(dtype))
@@ -171,6 +171,59 @@ def test_backward_is_reproducible_and_optimizer_step_reduces_loss():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0]
+
+
+def test_eval_mode_gradients_match_oracle_autograd():
+    """Fine-tuning with frozen statistics: ``model.eval()`` in grad mode.  BatchNorm is then a constant affine map
+    (no batch-mean terms in its backward) and the biases in front of it -- exactly-zero gradients in train mode --
+    have real gradients; the taped forward keeps the pre-activations through the per-op path.  Same comparison as in
+    train mode: f64 oracle autograd, on a batch where all discrete decisions agree, 3x the f32 oracle's own error."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    from gnn_epc_saft_amd.train.models import mape_loss
+    hidden, depth, mlp, num_para, skip, loops, graphs = 64, 2, 1, 3, True, True, 48
+    for attempt in range(32):
+        data = make_synthetic_batch(graphs, 4100 + 1000 * attempt, num_para=num_para)
+        oracle = oracle_model(hidden, depth, 1, 1, mlp, num_para, skip, loops, degree_histogram(data), seed=3)
+        gen = torch.Generator().manual_seed(11)
+        for mod in oracle.modules():          # running statistics that are not the identity
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=gen) * 0.3)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=gen) * 1.5 + 0.5)
+        oracle.eval()
+        st64, dec64 = oracle_decisions(copy.deepcopy(oracle).double(), data, skip)
+        st32, dec32 = oracle_decisions(copy.deepcopy(oracle), data, skip)
+        hip = hip_twin(copy.deepcopy(oracle)).eval()
+        dd = data.to(DEV)
+        pred = hip(dd)
+        assert pred.requires_grad and not hip.training
+        if not (decisions_agree(dec32, dec64) and decisions_agree(tape_decisions(pred, skip), dec64)):
+            continue
+        route64 = oracle_routing(st64, data, loops)
+        if decisions_agree(oracle_routing(st32, data, loops), route64) and decisions_agree(tape_routing(pred), route64):
+            break
+    else:
+        pytest.skip("no batch on which all three evaluations take the same discrete decisions")
+    loss64, g64 = grads_of(oracle, data, num_para, torch.float64, train=False)
+    loss32, g32 = grads_of(oracle, data, num_para, torch.float32, train=False)
+    before = {k: v.clone() for k, v in hip.state_dict().items() if "running" in k or "num_batches" in k}
+    loss = mape_loss(pred, dd.para.view(-1, num_para))
+    loss.backward()
+    assert abs(float(loss) - loss64) < 2e-5 * abs(loss64)
+    for k, v in hip.state_dict().items():
+        if k in before:
+            assert torch.equal(v, before[k]), k          # eval mode: statistics untouched
+    global_scale = max(float(g.abs().max()) for g in g64.values())
+    bad = []
+    for name, p in hip.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        scale = max(float(g64[name].abs().max()), 1e-4 * global_scale)
+        e_hip = float((p.grad.detach().double().cpu() - g64[name]).abs().max()) / scale
+        e_f32 = float((g32[name].double() - g64[name]).abs().max()) / scale
+        if e_hip > max(3 * e_f32, 2e-5):
+            bad.append((name, e_hip, e_f32))
+    assert not bad, bad[:5]
+    lin_bias = [n for n, _ in hip.named_parameters() if n.endswith("lin.bias")][0]
+    assert float(hip.get_parameter(lin_bias).grad.abs().max()) > 1e-4 * global_scale   # no longer exactly zero
 
 
 def test_backward_schedules_agree():

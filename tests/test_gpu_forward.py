@@ -196,15 +196,19 @@ def test_train_mode_single_row_raises_like_batchnorm():
             hip(ethanol_heavy().to(DEV))
 
 
-def test_cpu_tensors_and_autograd_fail_loudly():
+def test_cpu_tensors_fail_loudly_and_eval_mode_builds_a_graph():
     from gnn_epc_saft_amd.data.synthetic import ethanol_heavy
     oracle = oracle_model(64, 1, 1, 1, 0, 3, False, True, torch.tensor([0, 2, 1])).eval()
     hip = hip_twin(oracle)
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             hip(ethanol_heavy())                 # CPU batch: no fallback
-    with pytest.raises(NotImplementedError):
-        hip(ethanol_heavy().to(DEV))             # grad mode in eval(): only train-mode BatchNorm has a backward
+    # grad mode in eval(): a graph over frozen BatchNorm statistics (one un-batched molecule: a single pooled row,
+    # which train-mode BatchNorm would refuse)
+    pred = hip(ethanol_heavy().to(DEV))
+    assert pred.requires_grad and pred.shape == (1, 3)
+    pred.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in hip.parameters())
 
 
 @pytest.mark.parametrize("config_id", [2, 3])
