@@ -271,7 +271,9 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
                             int32_t *zero_ptr, int64_t zero_count, int32_t fold_layers,
                             const float *const *w_post0_host, const float *const *w_post1_host,
                             const float *const *w_pre0_host, const float *const *w_pre1_host, float *g_all,
-                            int32_t *err_flag, hipStream_t st, int32_t *zero2_ptr = nullptr, int zero2_count = 0);
+                            int32_t *err_flag, hipStream_t st, int32_t *zero2_ptr = nullptr, int zero2_count = 0,
+                            const struct EdgeTableLayers *tables = nullptr /* fold.hpp */, int32_t table_layers = 0,
+                            float *cenc = nullptr, float *rtab = nullptr);
 void csr_zero_region(void *workspace, int64_t num_nodes, int32_t **ptr, int64_t *count);
 int launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_t num_nodes, int64_t num_edges,
                      int32_t num_bond_cols, const int32_t *bond_dims_host, int32_t self_loops, int32_t *rowptr,

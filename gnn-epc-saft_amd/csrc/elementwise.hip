@@ -101,7 +101,66 @@ struct PrologueArgs {
   int h;
   unsigned dst_blocks;             // workgroups [0, dst_blocks): destination fold
   unsigned end_embed, end_combo;   // then embedding sum [0, end_embed), class table [.., end_combo), zero fill
+  // edge-class tables of every layer (tab_layers == 0: off): workgroup (layer, class) after the zero fill
+  EdgeTableLayers et;
+  float *cenc, *rtab;              // [L][C][H], [L][C][2H]
+  unsigned end_zero;               // zero fill [end_combo, end_zero), then tab_layers * combos table workgroups
+  int tab_layers;
 };
+
+// Edge-class tables of one (layer, class): cenc[c] = W_e emb_c + b_e, rtab[c, tF + f] = W_pre,t[f, 2F:3F] cenc[c] + b_pre,t[f]
+// (models.py:65-66 + the edge part of PNAConv's pre_nns; the class embedding emb_c = sum of its bond-table rows is
+// formed here, so the job depends on weights only).  60 classes x L layers: two [60, H] x [H, H | 2H] GEMM launches at
+// the head of every forward (6.5 us each at C2) become workgroups of the prologue launch.  One thread per output,
+// 16 weight loads in flight, operand vector in LDS.
+__device__ __forceinline__ void edge_table_body(const PrologueArgs &a, unsigned wg) {
+  __shared__ __attribute__((aligned(16))) float s_in[256], s_cenc[256];
+  const int h = a.h;
+  const int layer = (int)(wg / (unsigned)a.combos);
+  const int64_t cid = wg - (unsigned)layer * (unsigned)a.combos;
+  const int tid = threadIdx.x;
+  if (tid < h) {
+    int64_t rem = cid;
+    int digit[GNNSAFT_MAX_TABLES];
+    for (int k = a.bonds.n - 1; k >= 0; --k) {
+      digit[k] = (int)(rem % a.bonds.dims[k]);
+      rem /= a.bonds.dims[k];
+    }
+    float acc = 0.f;
+    for (int k = 0; k < a.bonds.n; ++k) acc += a.bonds.tab[k][(int64_t)digit[k] * h + tid];   // left to right, as ogb
+    s_in[tid] = acc;
+  }
+  __syncthreads();
+  auto dot = [&](const float *__restrict__ wrow, const float *vec) {   // wrow: h contiguous floats (16-B aligned)
+    float s = 0.f;
+    for (int i = 0; i < h; i += 16) {
+      f32x4 w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w[u] = gs_ld4(wrow + i + 4 * u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(vec + i + 4 * u);
+        s += w[u].x * v.x;
+        s += w[u].y * v.y;
+        s += w[u].z * v.z;
+        s += w[u].w * v.w;
+      }
+    }
+    return s;
+  };
+  if (tid < h) {
+    const float v = dot(a.et.we[layer] + (int64_t)tid * h, s_in) + a.et.be[layer][tid];
+    s_cenc[tid] = v;
+    a.cenc[((int64_t)layer * a.combos + cid) * h + tid] = v;
+  }
+  __syncthreads();
+  for (int o = tid; o < 2 * h; o += 256) {
+    const int t = o >= h ? 1 : 0, f = o - t * h;
+    const float *w = (t == 0 ? a.et.wpre0[layer] : a.et.wpre1[layer]) + (int64_t)f * (3 * h) + 2 * h;
+    const float *b = t == 0 ? a.et.bpre0[layer] : a.et.bpre1[layer];
+    a.rtab[((int64_t)layer * a.combos + cid) * (2 * h) + o] = dot(w, s_cenc) + b[f];
+  }
+}
 
 template <int MAXT>
 __global__ __launch_bounds__(256) void k_forward_prologue(PrologueArgs a) {
@@ -119,10 +178,12 @@ __global__ __launch_bounds__(256) void k_forward_prologue(PrologueArgs a) {
     embed_sum_body<MAXT>((int64_t)b * 256 + threadIdx.x, a.x_idx, a.rows, a.atoms, a.h, a.x_out, a.err, a.rs);
   } else if (b < a.end_combo) {
     combo_embed_body((int64_t)(b - a.end_embed) * 256 + threadIdx.x, a.bonds, a.combos, a.h, a.cemb);
-  } else {
+  } else if (b < a.end_zero) {
     const int64_t i = (int64_t)(b - a.end_combo) * 256 + threadIdx.x;
     if (i < a.zero_count) a.zero_ptr[i] = 0;
     if (b == a.end_combo && (int)threadIdx.x < a.zero2_count) a.zero2_ptr[threadIdx.x] = 0;
+  } else {
+    edge_table_body(a, b - a.end_zero);
   }
 }
 
@@ -274,7 +335,8 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
                             int32_t *zero_ptr, int64_t zero_count, int32_t fold_layers,
                             const float *const *w_post0_host, const float *const *w_post1_host,
                             const float *const *w_pre0_host, const float *const *w_pre1_host, float *g_all,
-                            int32_t *err_flag, hipStream_t st, int32_t *zero2_ptr, int zero2_count) {
+                            int32_t *err_flag, hipStream_t st, int32_t *zero2_ptr, int zero2_count,
+                            const EdgeTableLayers *tables, int32_t table_layers, float *cenc, float *rtab) {
   GS_REQUIRE(x_idx && x_out && cemb && num_rows >= 1, GNNSAFT_ERR_NULL);
   GS_REQUIRE(zero2_count >= 0 && zero2_count <= 256, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(hidden >= 4 && (hidden % 4) == 0, GNNSAFT_ERR_SHAPE);
@@ -318,7 +380,24 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
   a.dst_blocks = (unsigned)bd;
   a.end_embed = (unsigned)be;
   a.end_combo = (unsigned)(be + bc);
-  const dim3 grid((unsigned)(be + bc + bz + bd));
+  a.end_zero = (unsigned)(be + bc + bz);
+  a.tab_layers = 0;
+  a.cenc = cenc;
+  a.rtab = rtab;
+  int64_t bt = 0;
+  if (tables != nullptr && table_layers > 0) {
+    GS_REQUIRE(table_layers <= GNNSAFT_MAX_FOLD_LAYERS && cenc != nullptr && rtab != nullptr && hidden <= 256 &&
+                   (hidden % 16) == 0,
+               GNNSAFT_ERR_SHAPE);
+    a.et = *tables;
+    a.tab_layers = table_layers;
+    bt = (int64_t)table_layers * a.combos;
+  } else {
+    for (int i = 0; i < GNNSAFT_MAX_FOLD_LAYERS; ++i)
+      a.et.we[i] = a.et.be[i] = a.et.wpre0[i] = a.et.wpre1[i] = a.et.bpre0[i] = a.et.bpre1[i] = nullptr;
+  }
+  GS_REQUIRE(be + bc + bz + bd + bt < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);
+  const dim3 grid((unsigned)(be + bc + bz + bd + bt));
   if (num_atom_cols <= 9)
     hipLaunchKernelGGL(k_forward_prologue<9>, grid, dim3(256), 0, st, a);
   else

@@ -13,6 +13,13 @@ struct FoldLayers {
   const float *pre1[GNNSAFT_MAX_FOLD_LAYERS];
 };
 
+// per-layer operands of the edge-class tables (edge_encoder, the edge columns of pre_nns[t][0]); elementwise.hip
+struct EdgeTableLayers {
+  const float *we[GNNSAFT_MAX_FOLD_LAYERS], *be[GNNSAFT_MAX_FOLD_LAYERS];          // [H,H], [H]
+  const float *wpre0[GNNSAFT_MAX_FOLD_LAYERS], *wpre1[GNNSAFT_MAX_FOLD_LAYERS];    // [F,3F] each
+  const float *bpre0[GNNSAFT_MAX_FOLD_LAYERS], *bpre1[GNNSAFT_MAX_FOLD_LAYERS];    // [F]
+};
+
 // Destination-term fold.  msg = P_i + m~ with P_i = W_dst x_i constant over a node's in-edges, so
 // mean/min/max(msg) = P_i + mean/min/max(m~) and std(msg) = std(m~).  The update's aggregate block
 // then contributes  sum_s scale_s(d) (W_s,mean + W_s,min + W_s,max) P_i, i.e. an extra x-block

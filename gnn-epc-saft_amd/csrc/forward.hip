@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "fold.hpp"
 #include "plan.hpp"
 #include "readout.hpp"
 
@@ -454,6 +455,9 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
   // The four independent first jobs (atom embedding sum, bond-class embedding table, zeroing of the CSR
   // histogram, destination-term weight fold) share ONE launch on the caller's stream; then the chains fork.
   const bool dst_in_prologue = fold_dst && d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS;
+  // the edge-class tables (cenc, rtab: weights only) as workgroups of the same launch instead of two small GEMMs
+  const bool tables_in_prologue = d->num_layers >= 1 && d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS && h <= 256 &&
+                                  (h % 16) == 0 && p.combos <= 4096;
   {
     const float *w0[GNNSAFT_MAX_FOLD_LAYERS], *w1[GNNSAFT_MAX_FOLD_LAYERS];
     const float *p0[GNNSAFT_MAX_FOLD_LAYERS], *p1[GNNSAFT_MAX_FOLD_LAYERS];
@@ -466,10 +470,23 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     int32_t *zero_ptr = nullptr;
     int64_t zero_count = 0;
     if (structure_in == nullptr) csr_zero_region(ws + p.csr_ws, n, &zero_ptr, &zero_count);
+    EdgeTableLayers et;
+    for (int i = 0; i < GNNSAFT_MAX_FOLD_LAYERS; ++i) {
+      et.we[i] = et.be[i] = et.wpre0[i] = et.wpre1[i] = et.bpre0[i] = et.bpre1[i] = nullptr;
+      if (!tables_in_prologue) continue;
+      const LayerW &lwi = lw[i < d->num_layers ? i : 0];
+      et.we[i] = lwi.we;
+      et.be[i] = lwi.be;
+      et.wpre0[i] = lwi.wpre[0][0];
+      et.wpre1[i] = lwi.wpre[1][0];
+      et.bpre0[i] = lwi.bpre[0][0];
+      et.bpre1[i] = lwi.bpre[1][0];
+    }
     GS_TRY(launch_forward_prologue(x_idx, n, d->num_atom_cols, atom_tab, d->atom_dims, d->num_bond_cols, bond_tab,
                                    d->bond_dims, h, F(p.x0), F(p.cemb), zero_ptr, zero_count,
                                    dst_in_prologue ? d->num_layers : 0, w0, w1, p0, p1, F(p.gfold), err_flag, st,
-                                   I(p.rd_sync), kRdSyncInts));
+                                   I(p.rd_sync), kRdSyncInts, &et, tables_in_prologue ? d->num_layers : 0, F(p.cenc),
+                                   F(p.rtab)));
   }
   hipStream_t sa = st;
   if (aux != nullptr) {
@@ -527,16 +544,15 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     }
   }
   }  // structure built in place
-  // ---- the edge-class tables of all layers, on the caller's stream
-
-  for (int l0 = 0; l0 < d->num_layers; l0 += kMaxGemmBatch) {
+  // ---- the edge-class tables of all layers, on the caller's stream (unless the prologue made them)
+  for (int l0 = 0; !tables_in_prologue && l0 < d->num_layers; l0 += kMaxGemmBatch) {
     const int nl = d->num_layers - l0 < kMaxGemmBatch ? d->num_layers - l0 : kMaxGemmBatch;
     GemmBatchEntry e[kMaxGemmBatch];
     for (int i = 0; i < nl; ++i) e[i] = GemmBatchEntry{lw[l0 + i].we, lw[l0 + i].be, F(p.cenc) + (l0 + i) * cstride, 0};
     LinearEpilogue epi;
     GS_TRY(launch_linear(F(p.cemb), h, 0, nl, e, h, h, p.combos, h, h, epi, st));
   }
-  for (int i0 = 0; i0 < 2 * d->num_layers; i0 += kMaxGemmBatch) {
+  for (int i0 = 0; !tables_in_prologue && i0 < 2 * d->num_layers; i0 += kMaxGemmBatch) {
     const int ne = 2 * d->num_layers - i0 < kMaxGemmBatch ? 2 * d->num_layers - i0 : kMaxGemmBatch;
     GemmBatchEntry e[kMaxGemmBatch];
     for (int i = 0; i < ne; ++i) {
