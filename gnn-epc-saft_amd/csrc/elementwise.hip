@@ -101,10 +101,10 @@ struct PrologueArgs {
   int h;
   unsigned dst_blocks;             // workgroups [0, dst_blocks): destination fold
   unsigned end_embed, end_combo;   // then embedding sum [0, end_embed), class table [.., end_combo), zero fill
-  // edge-class tables of every layer (tab_layers == 0: off): workgroup (layer, class) after the zero fill
+  // edge-class tables of every layer (tab_layers == 0: off): workgroup (layer, class)
   EdgeTableLayers et;
   float *cenc, *rtab;              // [L][C][H], [L][C][2H]
-  unsigned end_zero;               // zero fill [end_combo, end_zero), then tab_layers * combos table workgroups
+  unsigned tab_blocks;             // tab_layers * combos workgroups at the very front of the grid
   int tab_layers;
 };
 
@@ -131,7 +131,9 @@ __device__ __forceinline__ void edge_table_body(const PrologueArgs &a, unsigned 
     s_in[tid] = acc;
   }
   __syncthreads();
-  auto dot = [&](const float *__restrict__ wrow, const float *vec) {   // wrow: h contiguous floats (16-B aligned)
+  // wrow: h contiguous floats (16-B aligned); sequential sum in k order (the 4-row BatchNorm fixtures of
+  // tests/golden are sensitive to the summation order of these tables at the 1e-5 level: keep the plain order)
+  auto dot = [&](const float *__restrict__ wrow, const float *vec) {
     float s = 0.f;
     for (int i = 0; i < h; i += 16) {
       f32x4 w[4];
@@ -166,24 +168,27 @@ template <int MAXT>
 __global__ __launch_bounds__(256) void k_forward_prologue(PrologueArgs a) {
   // the destination fold goes FIRST in the grid: its workgroups are the long-latency ones (a k-loop with
   // barriers), so they should be resident from the start while the streaming jobs fill the remaining CUs
-  if (blockIdx.x < a.dst_blocks) {
-    const unsigned d = blockIdx.x;
+  // ... and in front of them the edge-table workgroups (two dependent rounds of L2 latency each)
+  if (blockIdx.x < a.tab_blocks) {
+    edge_table_body(a, blockIdx.x);
+    return;
+  }
+  if (blockIdx.x < a.tab_blocks + a.dst_blocks) {
+    const unsigned d = blockIdx.x - a.tab_blocks;
     const int per_z = a.dst_gx * a.dst_gy;
     const int bz = d / per_z, r = d - bz * per_z;
     dst_fold_body(a.fl, a.h, a.g_all, r % a.dst_gx, r / a.dst_gx, bz);
     return;
   }
-  const unsigned b = blockIdx.x - a.dst_blocks;
+  const unsigned b = blockIdx.x - a.tab_blocks - a.dst_blocks;
   if (b < a.end_embed) {
     embed_sum_body<MAXT>((int64_t)b * 256 + threadIdx.x, a.x_idx, a.rows, a.atoms, a.h, a.x_out, a.err, a.rs);
   } else if (b < a.end_combo) {
     combo_embed_body((int64_t)(b - a.end_embed) * 256 + threadIdx.x, a.bonds, a.combos, a.h, a.cemb);
-  } else if (b < a.end_zero) {
+  } else {
     const int64_t i = (int64_t)(b - a.end_combo) * 256 + threadIdx.x;
     if (i < a.zero_count) a.zero_ptr[i] = 0;
     if (b == a.end_combo && (int)threadIdx.x < a.zero2_count) a.zero2_ptr[threadIdx.x] = 0;
-  } else {
-    edge_table_body(a, b - a.end_zero);
   }
 }
 
@@ -380,7 +385,7 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
   a.dst_blocks = (unsigned)bd;
   a.end_embed = (unsigned)be;
   a.end_combo = (unsigned)(be + bc);
-  a.end_zero = (unsigned)(be + bc + bz);
+  a.tab_blocks = 0;
   a.tab_layers = 0;
   a.cenc = cenc;
   a.rtab = rtab;
@@ -392,6 +397,7 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
     a.et = *tables;
     a.tab_layers = table_layers;
     bt = (int64_t)table_layers * a.combos;
+    a.tab_blocks = (unsigned)bt;
   } else {
     for (int i = 0; i < GNNSAFT_MAX_FOLD_LAYERS; ++i)
       a.et.we[i] = a.et.be[i] = a.et.wpre0[i] = a.et.wpre1[i] = a.et.bpre0[i] = a.et.bpre1[i] = nullptr;
