@@ -164,6 +164,24 @@ def test_shape_envelope_vs_oracle(cfg, mode):
                 assert int(sd_h[k]) == int(sd_o[k]) == 1
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_nine_layers_take_the_chunked_weight_paths(mode):
+    """More layers than one fused launch carries (GNNSAFT_MAX_FOLD_LAYERS = 8): the destination-term fold, the
+    update-weight fold and the edge-class tables then run as their own chunked launches / GEMMs instead of riding in
+    the prologue -- same bar as the rest of the envelope."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    data = make_synthetic_batch(64, 97, num_para=3)
+    oracle = oracle_model(64, 9, 1, 1, 1, 3, True, True, degree_histogram(data), seed=9)
+    oracle.train(mode == "train")
+    hip = hip_twin(copy.deepcopy(oracle))
+    with torch.no_grad():
+        out = hip(data.to(DEV)).cpu()
+        want32 = copy.deepcopy(oracle)(data)
+        want64 = copy.deepcopy(oracle).double()(data)
+    assert hip.input_error_flags() == 0
+    check_population(out, want32, want64)
+
+
 def test_single_graph_unbatched_and_one_node_graphs():
     from gnn_epc_saft_amd.data.synthetic import GraphData, collate, ethanol_heavy
     d = ethanol_heavy()
