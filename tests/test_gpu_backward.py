@@ -43,6 +43,15 @@ def test_wgrad_tn_kernel_matches_f64():
         ref = dy[:, :n_out].double().t() @ a.double()
         assert rel_err(dw.cpu(), ref) < 3e-6, (m, n_out, k)
         assert rel_err(db.cpu(), dy[:, :n_out].double().sum(0)) < 3e-6
+        if n_out >= 100 and ld == n_out:   # every wave grid of the wide kernel on the same operands (tools/tn_tune.py)
+            need2 = max(need, 1024 * n_out * k * 4)
+            scratch2 = torch.empty(need2 + 256, dtype=torch.uint8, device=DEV)
+            for wn, wk in ((2, 2), (4, 2), (4, 4)):
+                dw2 = torch.full((n_out, k), float("nan"), device=DEV)
+                check(lib.gnnsaft_debug_linear_wgrad(dyd.data_ptr(), ld, ad.data_ptr(), k, m, n_out, k, dw2.data_ptr(), k,
+                                                     scratch2.data_ptr(), need2, wn, wk, 0, stream),
+                      "gnnsaft_debug_linear_wgrad")
+                assert rel_err(dw2.cpu(), ref) < 3e-6, (m, n_out, k, wn, wk)
 
 
 def grads_of(model, data, num_para, dtype, train=True):
