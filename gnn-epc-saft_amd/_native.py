@@ -22,6 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GNNSAFT_LIB") or os.path.join(_HERE, "lib", "libgnnsaft.so")  # override: A/B runs of two builds
 
 MAX_TABLES = 16
+ABI_VERSION = 4
 
 
 class ModelDesc(ctypes.Structure):
@@ -34,6 +35,7 @@ class ModelDesc(ctypes.Structure):
         ("atom_dims", c_int32 * MAX_TABLES), ("bond_dims", c_int32 * MAX_TABLES),
         ("bn_eps", c_float), ("bn_momentum", c_float), ("fold_degree_scalers", c_int32),
         ("fold_dst_term", c_int32), ("save_tape", c_int32), ("unfused_readout", c_int32), ("bn_eps_f64", ctypes.c_double),
+        ("debug_barrier_extra", c_int32), ("readout_dropout", c_float), ("dropout_seed", ctypes.c_uint64),
     ]
 
 
@@ -96,14 +98,14 @@ SIGNATURES = {
     "gnnsaft_adamw_step": (c_int32, [P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int64,
                                      c_float, P]),
     "gnnsaft_adamw_args_floats": (c_int32, []),
-    "gnnsaft_adamw_args": (c_int32, [c_float, c_float, c_float, c_float, c_float, c_int64, c_float, P]),
+    "gnnsaft_adamw_args": (c_int32, [c_float, c_float, c_float, c_float, c_float, c_int64, c_float, P, P]),
     "gnnsaft_adamw_step_dev": (c_int32, [P, P, P, P, P, c_int64, P, P]),
     "gnnsaft_sgd_step": (c_int32, [P, P, P, c_int64, c_float, c_float, c_float, c_int32, c_float, P]),
     "gnnsaft_aux_create": (c_int32, [POINTER(c_void_p)]),
     "gnnsaft_aux_destroy": (None, [P]),
     "gnnsaft_backward_scratch_bytes": (c_size_t, [POINTER(ModelDesc), c_int64, c_int64, c_int64]),
     "gnnsaft_backward": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), POINTER(c_void_p), c_int32, P, P, c_int64,
-                                   c_int64, c_int64, P, P, c_size_t, P, c_size_t, POINTER(c_void_p), P, P]),
+                                   c_int64, c_int64, P, P, c_size_t, P, c_size_t, POINTER(c_void_p), P, P, P]),
     "gnnsaft_mape_backward": (c_int32, [P, P, c_int64, c_int32, P, P, P]),
     "gnnsaft_wgrad_scratch_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "gnnsaft_debug_linear_wgrad": (c_int32, [P, c_int64, P, c_int64, c_int64, c_int32, c_int32, P, c_int64, P, c_size_t,
@@ -136,8 +138,8 @@ def _load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gnnsaft_abi_version() != 3:
-        raise ImportError(f"{LIB_PATH}: ABI version {lib.gnnsaft_abi_version()} != 3; rebuild the library")
+    if lib.gnnsaft_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.gnnsaft_abi_version()} != {ABI_VERSION}; rebuild the library")
     return lib
 
 

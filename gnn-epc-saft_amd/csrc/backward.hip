@@ -637,8 +637,8 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
                                 void *const *grads_host, int32_t num_weights, const int64_t *x_idx,
                                 const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
                                 const float *grad_out /* [G,P] */, void *tape, size_t tape_bytes, void *scratch,
-                                size_t scratch_bytes, void *const *segment_events, gnnsaft_aux *aux,
-                                gnnsaft_stream_t stream) {
+                                size_t scratch_bytes, void *const *segment_events, int32_t *err_flag,
+                                gnnsaft_aux *aux, gnnsaft_stream_t stream) {
   (void)batch;
   GS_REQUIRE(d && weights_host && grads_host && grad_out && tape && scratch && x_idx, GNNSAFT_ERR_NULL);
   GS_REQUIRE(d->save_tape, GNNSAFT_ERR_UNSUPPORTED);
@@ -731,7 +731,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
   GS_REQUIRE(det != nullptr && wt_layers != nullptr && wt_readout != nullptr && rb_scratch != nullptr &&
                  rb_sync != nullptr,
              GNNSAFT_ERR_WORKSPACE);
-  const bool rb_fused = !d->unfused_readout && d->training && readout_bwd_fused_supported(g, h, P, p.nb);
+  const bool rb_fused = !d->unfused_readout && d->training && readout_fused_launchable(g, h, P, p.nb, true);
   const size_t slab_bytes = bs.slab;
   SlabQueue sq;   // one layer's reductions, summed by one launch (side stream)
   sq.base = slabs;
@@ -882,7 +882,8 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     rp.dpooled = dcur;
     rp.scratch = rb_scratch;
     rp.sync = rb_sync;
-    rp.err = nullptr;
+    rp.err = err_flag;   // a lost barrier raises GNNSAFT_FLAG_BARRIER_TIMEOUT and poisons the gradients with NaN
+    rp.barrier_extra = d->debug_barrier_extra;
     GS_TRY(launch_readout_bwd_fused(rp, sq, st));
     GS_TRY(launch_slab_queue_flush(sq, st));
   } else {

@@ -667,7 +667,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
 
   // ---- readout: one launch (readout.hip) while its workgroups are co-resident, the per-op path beyond
   // (an eval-mode tape keeps the readout's pre-activations through the per-op path)
-  if (readout_fused_supported(g, h, d->num_para, p.nb) && !d->unfused_readout && !(d->save_tape && !d->training)) {
+  if (!d->unfused_readout && !(d->save_tape && !d->training) && readout_fused_launchable(g, h, d->num_para, p.nb, false)) {
     GS_TRY(gnnsaft_add_pool(xc, I(p.graph_ptr), g, n, h, F(p.pooled), st));
     ReadoutFusedParams rp{};
     rp.x = xc;
@@ -696,6 +696,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     rp.scratch = ws + p.rd_scratch;
     rp.sync = I(p.rd_sync);
     rp.err = err_flag;
+    rp.barrier_extra = d->debug_barrier_extra;
     return launch_readout_fused(rp, st);
   }
   // ---- readout

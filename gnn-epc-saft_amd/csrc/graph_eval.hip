@@ -24,6 +24,8 @@
 // waves split K further when there are fewer than 256 columns; every thread keeps R row accumulators.  f32 / f64 FMA
 // on the vector ALU: with <= 64 rows per graph the matrix cores would idle on fragment padding, and the whole thing
 // is latency-bound on the weight stream from L2 (one CU), which is why 8 independent loads are kept in flight.
+#include <atomic>
+
 #include "plan.hpp"
 
 namespace gs {
@@ -882,11 +884,16 @@ static int gf_plan(const gnnsaft_model_desc *d, size_t elem, int64_t n, int64_t 
 
 template <typename T, int R, int NT = kGfThreads>
 static int gf_launch(const GraphArgs<T> &a, int64_t g, size_t lds_bytes, hipStream_t st) {
-  static bool attr_set = false;  // idempotent: the attribute is a property of the kernel, set once per process
-  if (!attr_set) {
+  // the dynamic-LDS limit is a property of (kernel, DEVICE): once per device this process drives, and safe from
+  // several host threads (the loader's prefetch thread makes HIP calls beside the main thread)
+  static std::atomic<unsigned long long> attr_devices{0};   // bit d: raised on device d (devices >= 64: every launch)
+  int dev = 0;
+  GS_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+  if ((attr_devices.load(std::memory_order_acquire) & bit) == 0ull) {
     GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_graph_forward<T, R, NT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGfLdsBudget));
-    attr_set = true;
+    attr_devices.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL((k_graph_forward<T, R, NT>), dim3((unsigned)g), dim3(NT), lds_bytes, st, a);
   GS_CHECK_LAUNCH();
@@ -960,7 +967,7 @@ static int graph_forward_impl(const gnnsaft_model_desc *d, const void *pack, con
 using namespace gs;
 
 #ifdef GS_GF_TIMING
-extern "C" int gnnsaft_debug_graph_stamps(long long *host_out) {
+extern "C" GNNSAFT_API int gnnsaft_debug_graph_stamps(long long *host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gf_stamp), sizeof(long long) * 256);
 }
 #endif

@@ -75,7 +75,13 @@ __global__ __launch_bounds__(256) void k_adamw(float *__restrict__ p, const floa
 }
 
 // the step's scalars (learning rate, bias corrections: they change every step) read from DEVICE memory, so that the
-// launch can sit in a captured hipGraph and be replayed with new values (gnnsaft_adamw_args writes them)
+// launch can sit in a captured hipGraph and be replayed with new values.  gnnsaft_adamw_args publishes them with a
+// one-thread launch whose values travel as KERNEL ARGUMENTS (copied at enqueue time): stream-ordered in front of the
+// replay that reads them, and no host buffer a queued replay could see in a later step's state.
+__global__ void k_adamw_publish(AdamArgs a, AdamArgs *__restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *out = a;
+}
+
 __global__ __launch_bounds__(256) void k_adamw_dev(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v,
                                                    float *__restrict__ vmax, int64_t count,
@@ -146,11 +152,13 @@ extern "C" int gnnsaft_adamw_step(float *param, const float *grad, float *exp_av
 extern "C" int32_t gnnsaft_adamw_args_floats(void) { return (int32_t)(sizeof(gs::AdamArgs) / sizeof(float)); }
 
 extern "C" int gnnsaft_adamw_args(float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                                  float grad_scale, float *args_host) {
-  GS_REQUIRE(args_host != nullptr, GNNSAFT_ERR_NULL);
+                                  float grad_scale, float *args_dev, gnnsaft_stream_t stream) {
+  GS_REQUIRE(args_dev != nullptr && (reinterpret_cast<uintptr_t>(args_dev) & 3) == 0, GNNSAFT_ERR_NULL);
   GS_REQUIRE(step >= 1, GNNSAFT_ERR_SHAPE);
   const gs::AdamArgs a = adam_args(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
-  std::memcpy(args_host, &a, sizeof(a));
+  hipLaunchKernelGGL(gs::k_adamw_publish, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a,
+                     reinterpret_cast<gs::AdamArgs *>(args_dev));
+  GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }
 

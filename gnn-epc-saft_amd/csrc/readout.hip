@@ -9,9 +9,15 @@
 // of its 64 rows, the grid meets at a device-scope barrier (release / acquire atomics on a counter zeroed by the
 // forward's prologue kernel), and every workgroup folds the <= 256 partials itself (f64, same pivot scheme as
 // bn_train.hip).  The barrier is only safe while all workgroups are co-resident: the launcher uses this kernel for up
-// to 256 workgroups (16 384 graphs, one per CU is always resident) and the per-op path beyond; the spin is bounded and
-// raises GNNSAFT_FLAG_BARRIER_TIMEOUT instead of hanging.  The MAPE sum is closed by the last workgroup to arrive (an
+// to as many workgroups as the device's occupancy calculator says are co-resident (readout_resident_workgroups:
+// hipOccupancyMaxActiveBlocksPerMultiprocessor x CU count, per device) and the per-op path beyond.  What the calculator
+// cannot see -- another process on the GPU, a CU mask -- ends in the bounded spin: the kernel then raises
+// GNNSAFT_FLAG_BARRIER_TIMEOUT AND writes NaN to its outputs (forward: out / loss3; backward: the pooled-row
+// gradient, which poisons every gradient below it), so that a caller who never reads the flag word cannot train on
+// incomplete BatchNorm statistics.  The MAPE sum is closed by the last workgroup to arrive (an
 // atomic ticket), which adds the per-workgroup partials in workgroup order: deterministic, no float atomics.
+#include <atomic>
+
 #include "plan.hpp"
 #include "readout.hpp"
 
@@ -52,23 +58,38 @@ struct ReadoutArgs {
   float *mape_part;          // [W]
   int32_t *sync;             // [nb + 1] counters, zero at launch
   int32_t *err;
+  int barrier_extra;         // 0; > 0 (test hook): the barriers expect that many arrivals more than there are workgroups
 };
 
-// all workgroups of the grid meet here; returns after every one of them has arrived (or the spin bound is hit)
-__device__ __forceinline__ void grid_barrier(int32_t *counter, int expected, int32_t *err) {
+// all workgroups of the grid meet here; returns true after every one of them has arrived, false when the spin bound
+// was hit (the flag word is raised; the caller poisons its outputs)
+__device__ __forceinline__ bool grid_barrier(int32_t *counter, int expected, int32_t *err) {
+  __shared__ int s_barrier_ok;
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     long spins = 0;
+    int ok = 1;
     while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < expected) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1L << 22)) {  // ~1 s: a workgroup never became resident; give up loudly instead of hanging
+      if (++spins > (1L << 21)) {  // ~0.5 s: a workgroup never became resident; give up loudly instead of hanging
         if (err) atomicOr(err, GNNSAFT_FLAG_BARRIER_TIMEOUT);
+        ok = 0;
         break;
       }
     }
+    s_barrier_ok = ok;
   }
   __syncthreads();
+  return s_barrier_ok != 0;
+}
+
+// has THIS call lost a barrier anywhere?  (the flag word is sticky across calls until the host reads it: a later call
+// on a device that lost one keeps poisoning until somebody looks)
+__device__ __forceinline__ bool barrier_lost(bool all_ok, const int32_t *err) {
+  return !all_ok ||
+         (err != nullptr && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
+                             GNNSAFT_FLAG_BARRIER_TIMEOUT) != 0);
 }
 
 // y[64][n_out] = a[64][n_in] (LDS) x W^T + bias : 32 x 32 output tiles round-robin over the 8 waves, k in the order
@@ -132,6 +153,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_fused(ReadoutArgs a) {
   const int64_t row0 = (int64_t)blockIdx.x * kRdRows;
   const int rows = a.g - row0 < kRdRows ? (int)(a.g - row0) : kRdRows;   // >= 1
   const int nwg = gridDim.x;
+  bool barriers_ok = true;
 
   // ---- the pooled rows of this workgroup's graphs (k_add_pool ran as its own launch: one thread per (graph, float4)
   //      keeps ~1e5 loads in flight over the whole chip; pooling here, 64 graphs per workgroup, was measured at 20 us
@@ -192,7 +214,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_fused(ReadoutArgs a) {
         }
       }
       RD_STAMP(2 + 6 * b);
-      grid_barrier(a.sync + b, nwg, a.err);
+      barriers_ok &= grid_barrier(a.sync + b, nwg + a.barrier_extra, a.err);
       RD_STAMP(3 + 6 * b);
       {
         // every workgroup folds all partials: S1 = sum n_w (mean_w - K), S2 = sum (M2_w + n_w (mean_w - K)^2) in f64
@@ -283,9 +305,10 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_fused(ReadoutArgs a) {
     rd_gemm(at, ld, a.w[b], a.b[b], a.n_in[b], a.num_para, yt, ld);
     __syncthreads();
     float ape = 0.f;
+    const bool lost = a.training && barrier_lost(barriers_ok, a.err);   // block-uniform
     for (int idx = tid; idx < rows * a.num_para; idx += kRdThreads) {
       const int r = idx / a.num_para, c = idx - r * a.num_para;
-      const float v = yt[r * ld + c];
+      const float v = lost ? __builtin_nanf("") : yt[r * ld + c];
       a.out[(row0 + r) * a.num_para + c] = v;
       if (a.target != nullptr) {
         const float t = a.target[(row0 + r) * a.num_para + c];
@@ -306,6 +329,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_fused(ReadoutArgs a) {
           float tot = 0.f;
           for (int w = 0; w < nwg; ++w) tot += __builtin_nontemporal_load(a.mape_part + w);
           const float cnt = (float)(a.g * a.num_para);
+          if (a.training && barrier_lost(barriers_ok, a.err)) tot = __builtin_nanf("");
           a.loss3[0] = tot / cnt;
           a.loss3[1] = tot;
           a.loss3[2] = cnt;
@@ -340,6 +364,7 @@ struct ReadoutBwdArgs {
   float *dpooled;                              // [G, H]
   int32_t *sync;                               // [nb + 1] counters, zero at launch
   int32_t *err;
+  int barrier_extra;
 };
 
 // slab[n][k] = sum over this workgroup's 64 rows of dy[r][n] * in[r][k]: 32 x 32 output tiles round-robin over the
@@ -396,6 +421,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_bwd_fused(ReadoutBwdArgs
   const int rows = a.g - row0 < kRdRows ? (int)(a.g - row0) : kRdRows;   // >= 1
   const int nwg = gridDim.x, nb = a.nblocks, P = a.num_para;
   const int64_t rs = a.g * (int64_t)h;
+  bool barriers_ok = true;
 
   // ---- final Linear(H/4 -> P): dW_f = dOut^T x, db_f = column sums of dOut, dx = dOut W_f
   {
@@ -495,7 +521,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_bwd_fused(ReadoutBwdArgs
         pp[h + c] = (float)s2;
       }
     }
-    grid_barrier(a.sync + b, nwg, a.err);
+    barriers_ok &= grid_barrier(a.sync + b, nwg + a.barrier_extra, a.err);
     {
       const float *pp = a.part + (int64_t)b * nwg * 2 * h;
       const int cc = col_ok ? c : 0;
@@ -553,15 +579,19 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_bwd_fused(ReadoutBwdArgs
     rd_gemm(yt, ld, a.wt[b], nullptr, n_out, n_in, dt, ld);
     __syncthreads();
   }
-  // ---- gradient of the pooled rows
+  // ---- gradient of the pooled rows (NaN after a lost barrier: it reaches every gradient below the readout, and
+  //      through the flat gradient buffer the optimizer's parameters -- wrong statistics cannot train silently)
+  const bool lost = barrier_lost(barriers_ok, a.err);
+  const float nanv = __builtin_nanf("");
   for (int idx = tid; idx < rows * (h / 4); idx += kRdThreads) {
     const int r = idx / (h / 4), c4 = (idx - r * (h / 4)) * 4;
-    gs_st4(a.dpooled + (row0 + r) * h + c4, gs_ld4(dt + r * ld + c4));
+    gs_st4(a.dpooled + (row0 + r) * h + c4, lost ? f32x4{nanv, nanv, nanv, nanv} : gs_ld4(dt + r * ld + c4));
   }
+  if (lost && blockIdx.x == 0 && tid < P) a.dbias_final[tid] = nanv;
 }
 
 #ifdef GS_GF_TIMING
-extern "C" int gnnsaft_debug_readout_stamps(long long *host_out) {
+extern "C" GNNSAFT_API int gnnsaft_debug_readout_stamps(long long *host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_rd_stamp), sizeof(long long) * 64);
 }
 #endif
@@ -576,8 +606,53 @@ bool readout_fused_supported(int64_t g, int h, int num_para, int nblocks) {
          num_para >= 1 && num_para <= 32 && nblocks >= 2 && nblocks <= kRdMaxBlocks;
 }
 
+static size_t rd_fwd_lds(int h) {
+  return ((size_t)2 * kRdRows * (h + kRdPad) + 2 * (size_t)h + 8) * sizeof(float) + 2 * (size_t)kRdThreads * sizeof(double);
+}
+static size_t rd_bwd_lds(int h) {
+  return ((size_t)2 * kRdRows * (h + kRdPad) + 3 * (size_t)h + kRdRows * 8) * sizeof(float) +
+         2 * (size_t)kRdThreads * sizeof(double);
+}
+
+// Workgroups of the fused readout kernels the CURRENT device keeps resident at once (0: unknown / query failed).
+// A property of (device, kernel, LDS size): cached per device and hidden size; the first query of a device also
+// raises that device's dynamic-LDS limit for the kernel (the attribute is per device, not per process).
+static int readout_resident_workgroups(int h, bool backward) {
+  constexpr int kMaxDev = 64;
+  static std::atomic<int> cache[kMaxDev][2][9];   // zero-initialised: not yet queried
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  const int hi = h / 32;
+  if (hi < 1 || hi > 8) return 0;
+  const bool cached = dev >= 0 && dev < kMaxDev;
+  if (cached) {
+    const int v = cache[dev][backward ? 1 : 0][hi].load(std::memory_order_acquire);
+    if (v != 0) return v > 0 ? v : 0;
+  }
+  const void *fn = backward ? reinterpret_cast<const void *>(&k_readout_bwd_fused)
+                            : reinterpret_cast<const void *>(&k_readout_fused);
+  const size_t lds = backward ? rd_bwd_lds(h) : rd_fwd_lds(h);
+  int result = -1, cus = 0, per_cu = 0;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
+    const hipError_t e = backward
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_readout_bwd_fused, kRdThreads, lds)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_readout_fused, kRdThreads, lds);
+    if (e == hipSuccess && per_cu >= 1 && cus >= 1) result = per_cu * cus;
+  }
+  (void)hipGetLastError();   // a failed query must not surface as the next launch's error
+  if (cached) cache[dev][backward ? 1 : 0][hi].store(result, std::memory_order_release);
+  return result > 0 ? result : 0;
+}
+
+bool readout_fused_launchable(int64_t g, int h, int num_para, int nblocks, bool backward) {
+  const bool shape = backward ? readout_bwd_fused_supported(g, h, num_para, nblocks)
+                              : readout_fused_supported(g, h, num_para, nblocks);
+  return shape && gs_ceil_div(g, (int64_t)kRdRows) <= readout_resident_workgroups(h, backward);
+}
+
 int launch_readout_fused(const ReadoutFusedParams &p, hipStream_t st) {
-  GS_REQUIRE(readout_fused_supported(p.g, p.h, p.num_para, p.nblocks), GNNSAFT_ERR_UNSUPPORTED);
+  GS_REQUIRE(readout_fused_launchable(p.g, p.h, p.num_para, p.nblocks, false), GNNSAFT_ERR_UNSUPPORTED);
   GS_REQUIRE(p.pooled && p.out && p.scratch && p.sync, GNNSAFT_ERR_NULL);
   GS_REQUIRE(!p.training || p.g >= 2, GNNSAFT_ERR_SHAPE);   // torch: "Expected more than 1 value per channel"
   ReadoutArgs a;
@@ -627,14 +702,8 @@ int launch_readout_fused(const ReadoutFusedParams &p, hipStream_t st) {
                                           gs_align_up((size_t)p.nblocks * wgs * 2 * p.h * 4, 256));
   a.sync = p.sync;
   a.err = p.err;
-  const size_t lds = ((size_t)2 * kRdRows * (p.h + kRdPad) + 2 * (size_t)p.h + 8) * sizeof(float) +
-                     2 * (size_t)kRdThreads * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    GS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_readout_fused),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  a.barrier_extra = p.barrier_extra > 0 ? p.barrier_extra : 0;
+  const size_t lds = rd_fwd_lds(p.h);   // (the dynamic-LDS limit of this device was raised by the residency query)
   hipLaunchKernelGGL(k_readout_fused, dim3((unsigned)wgs), dim3(kRdThreads), lds, st, a);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
@@ -665,7 +734,7 @@ bool readout_bwd_fused_supported(int64_t g, int h, int num_para, int nblocks) {
 }
 
 int launch_readout_bwd_fused(const ReadoutBwdParams &p, SlabQueue &q, hipStream_t st) {
-  GS_REQUIRE(readout_bwd_fused_supported(p.g, p.h, p.num_para, p.nblocks), GNNSAFT_ERR_UNSUPPORTED);
+  GS_REQUIRE(readout_fused_launchable(p.g, p.h, p.num_para, p.nblocks, true), GNNSAFT_ERR_UNSUPPORTED);
   GS_REQUIRE(p.grad_out && p.pooled && p.ry && p.ro && p.rstat && p.scratch && p.sync && p.dpooled, GNNSAFT_ERR_NULL);
   GS_REQUIRE(q.count + p.nblocks + 1 <= kMaxSlabJobs, GNNSAFT_ERR_WORKSPACE);
   const int64_t wgs = gs_ceil_div(p.g, (int64_t)kRdRows);
@@ -684,6 +753,7 @@ int launch_readout_bwd_fused(const ReadoutBwdParams &p, SlabQueue &q, hipStream_
   a.dbias_final = p.db_final;
   a.sync = p.sync;
   a.err = p.err;
+  a.barrier_extra = p.barrier_extra > 0 ? p.barrier_extra : 0;
   a.part = p.scratch;
   a.bias_part = p.scratch + (size_t)p.nblocks * wgs * 2 * p.h;
   GS_REQUIRE(a.w_final != nullptr && a.dbias_final != nullptr, GNNSAFT_ERR_NULL);
@@ -715,13 +785,7 @@ int launch_readout_bwd_fused(const ReadoutBwdParams &p, SlabQueue &q, hipStream_
       GS_REQUIRE(!bl || (a.wt[i] && a.gamma[i] && a.beta[i]), GNNSAFT_ERR_NULL);
     }
   }
-  const size_t lds = ((size_t)2 * kRdRows * (p.h + kRdPad) + 3 * (size_t)p.h + kRdRows * 8) * sizeof(float) +
-                     2 * (size_t)kRdThreads * sizeof(double);
-  static const bool attr = [] {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_readout_bwd_fused),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-  }();
-  (void)attr;
+  const size_t lds = rd_bwd_lds(p.h);
   hipLaunchKernelGGL(k_readout_bwd_fused, dim3((unsigned)wgs), dim3(kRdThreads), lds, st, a);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;

@@ -5,7 +5,8 @@
 namespace gs {
 
 constexpr int kRdMaxBlocks = 10;        // BatchNorm blocks of the readout: num_mlp_layers (<= 8) + 2
-constexpr int kRdMaxWorkgroups = 256;   // all workgroups must be co-resident for the grid barrier: one per CU
+constexpr int kRdMaxWorkgroups = 1024;  // static upper bound (sizing); the launch-time bound is what the DEVICE can
+                                        // keep co-resident for the grid barrier: readout_resident_workgroups()
 constexpr int kRdSyncInts = 16;         // barrier / ticket counters, zeroed by the forward's prologue kernel
 
 struct ReadoutFusedParams {
@@ -22,6 +23,7 @@ struct ReadoutFusedParams {
   void *scratch;                          // readout_fused_scratch_bytes
   int32_t *sync;                          // kRdSyncInts ints, zero at launch
   int32_t *err;
+  int barrier_extra;                      // test hook (desc->debug_barrier_extra): arrivals the barriers wait for in vain
 };
 
 // Backward of the readout in one launch (k_readout_bwd_fused): per-workgroup partial weight gradients go to `q`'s
@@ -41,6 +43,7 @@ struct ReadoutBwdParams {
   float *scratch;                            // readout_bwd_scratch_floats
   int32_t *sync;                             // kRdSyncInts ints, zero at launch
   int32_t *err;                              // or null
+  int barrier_extra;                         // test hook, as in the forward
 };
 size_t readout_bwd_scratch_floats(int64_t g, int h, int nblocks);
 size_t readout_bwd_slab_floats(int64_t g, int h, int num_para, int nblocks);
@@ -48,7 +51,11 @@ bool readout_bwd_fused_supported(int64_t g, int h, int num_para, int nblocks);
 int launch_readout_bwd_fused(const ReadoutBwdParams &p, SlabQueue &q, hipStream_t st);
 
 size_t readout_fused_scratch_bytes(int64_t g, int h, int nblocks);
+// shape envelope of the fused kernels (host-only: sizing functions use it) ...
 bool readout_fused_supported(int64_t g, int h, int num_para, int nblocks);
+// ... and the launch-time decision: the envelope AND every workgroup co-resident on the CURRENT device
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor x multiProcessorCount, cached per device and hidden size)
+bool readout_fused_launchable(int64_t g, int h, int num_para, int nblocks, bool backward);
 int launch_readout_fused(const ReadoutFusedParams &p, hipStream_t st);
 
 }  // namespace gs

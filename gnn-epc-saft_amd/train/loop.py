@@ -130,6 +130,12 @@ def training_loop(lit: PNApcsaftL, batches: Iterable, max_steps: Optional[int] =
                     logged /= world
                 value = float(logged)   # the only host sync of the loop
                 flags = lit.model.input_error_flags()      # rides on that sync: clamped / dropped indices are not
+                if flags & 16:                              # fatal: BatchNorm statistics of the readout incomplete
+                    raise RuntimeError(f"GNNSAFT_FLAG_BARRIER_TIMEOUT (bit 16 of {flags:#x}) by step {step}: a grid "
+                                       "barrier of the fused readout (forward or backward) gave up waiting -- its "
+                                       "workgroups were not co-resident (GPU shared with another process, CU mask or "
+                                       "partition mode).  The affected outputs / gradients were poisoned with NaN; "
+                                       "set model.fused_readout = False on such a device")
                 if flags:                                   # silent (the reference's Embedding / scatter would fault)
                     raise ValueError(f"training batches raised GNNSAFT_FLAG_* bits {flags:#x} by step {step} (1 bad "
                                      "edge index, 2 categorical index outside its vocabulary, 4 batch vector not "
@@ -156,7 +162,9 @@ class GraphedTrainingStep:
     fixed-shape training and measurement, not a loader of ragged batches.
 
     The optimizer must be a ``FusedAdamW`` (it is switched to ``capturable``: learning rate and bias corrections are
-    read from device memory that a captured copy refreshes from a pinned host buffer); ``scheduler.step()`` runs
+    read from device memory that ``prepare_replay()`` rewrites with a one-thread launch in front of every replay --
+    kernel arguments, so replays may queue up behind a busy GPU without reading a later step's values);
+    ``scheduler.step()`` runs
     after every replay, on the host, as Lightning's ``interval="step"`` does.  ``warmup`` eager steps run first, on a
     side stream, as torch's whole-network capture recipe requires -- they are real training steps."""
 

@@ -180,6 +180,7 @@ class PNAPCSAFT(nn.Module):
         # add-pool -> readout MLP (train-mode BatchNorm across the batch through a grid barrier) -> MAPE in ONE launch
         # (csrc/readout.hip) for up to 16 384 graphs; False restores the nine per-op launches
         self.fused_readout = True
+        self._debug_barrier_extra = 0   # tests only: make the fused readout's grid barriers time out
         # Per-graph fused kernel (csrc/graph_eval.hip: one workgroup per molecule, whole network in one launch):
         # always for float64 modules; for float32 in eval mode without autograd when the input has at most this many
         # graphs and nodes.  Measured on MI355X (tools/single_molecule_latency.py, default model H=64 L=6): one
@@ -264,6 +265,7 @@ class PNAPCSAFT(nn.Module):
         d.fold_degree_scalers = int(self.fold_degree_scalers)
         d.fold_dst_term = int(self.fold_dst_term)
         d.unfused_readout = int(not self.fused_readout)
+        d.debug_barrier_extra = int(self._debug_barrier_extra)
         return d
 
     def _check_mode(self, x: torch.Tensor) -> None:
@@ -497,7 +499,8 @@ class PNAPCSAFT(nn.Module):
             rc = lib.gnnsaft_backward(ctypes.byref(desc), wtab, gtab, nw, ctx["x"].data_ptr(),
                                       None if ctx["batch"] is None else ctx["batch"].data_ptr(), ctx["n"], ctx["e"],
                                       ctx["g"], grad_out.data_ptr(), ctx["ws_ptr"], ctx["ws_bytes"], sp,
-                                      scratch.numel() - (sp - scratch.data_ptr()), events, aux, stream)
+                                      scratch.numel() - (sp - scratch.data_ptr()), events,
+                                      None if self._err_flag is None else self._err_flag.data_ptr(), aux, stream)
         check(rc, "gnnsaft_backward")
         self._last_flat_grad = flat
         return grads

@@ -60,7 +60,7 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.on_parameters_rewritten = None   # callable: the step kernel writes parameters behind torch's version counters
         self._step_tensor = None
         self.capturable = False              # FusedAdamW: per-step scalars from device memory (hipGraph capture)
-        self._args_host = self._args_dev = None
+        self._args_dev = None
         self._adopt()
 
     # ---- flat parameter buffer
@@ -114,8 +114,13 @@ class _FlatOptimizer(torch.optim.Optimizer):
                 if g is None or g._base is not owner:
                     zero_copy = False
                     break
-            last = self._params[-1].grad
-            zero_copy = zero_copy and last.storage_offset() == self._offsets[-1] and last.is_contiguous()
+            if zero_copy:      # ... laid out as this optimizer expects (first / middle / last, as _adopted() probes)
+                n = len(self._params)
+                for i in (0, n // 2, n - 1):
+                    g = self._params[i].grad
+                    if g.storage_offset() != self._offsets[i] or not g.is_contiguous():
+                        zero_copy = False
+                        break
             if zero_copy:
                 return owner
         if self._gather is None:
@@ -203,25 +208,28 @@ class FusedAdamW(_FlatOptimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad),
                          layout=layout)
 
-    # ---- hipGraph capture (train/loop.py::GraphedTrainingStep): the step's scalars live in device memory, refreshed
-    # from a pinned host buffer by a copy that is part of the graph
-    def _arg_buffers(self):
-        if self._args_host is None or self._args_dev.device != self._flat.device:
+    # ---- hipGraph capture (train/loop.py::GraphedTrainingStep): the step's scalars live in device memory.  They are
+    # published by a one-thread launch OUTSIDE the graph whose values travel as kernel arguments (copied at enqueue
+    # time, stream-ordered in front of the replay): no host buffer that a queued replay could read in a later step's
+    # state (a pinned buffer re-read by a captured copy raced with the host rewriting it for the next step).
+    def _arg_buffer(self):
+        if self._args_dev is None or self._args_dev.device != self._flat.device:
             n = int(lib.gnnsaft_adamw_args_floats())
-            self._args_host = torch.zeros(n, dtype=torch.float32).pin_memory()
             self._args_dev = torch.zeros(n, dtype=torch.float32, device=self._flat.device)
-        return self._args_host, self._args_dev
+        return self._args_dev
 
     def _write_args(self, step: int) -> None:
         g = self.param_groups[0]
-        host, _ = self._arg_buffers()
-        check(lib.gnnsaft_adamw_args(float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                     float(g["weight_decay"]), step, float(self.grad_scale), host.data_ptr()),
-              "gnnsaft_adamw_args")
+        dev = self._arg_buffer()
+        stream = torch.cuda.current_stream(dev.device).cuda_stream
+        with torch.cuda.device(dev.device):
+            check(lib.gnnsaft_adamw_args(float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                         float(g["weight_decay"]), step, float(self.grad_scale), dev.data_ptr(),
+                                         stream), "gnnsaft_adamw_args")
 
     def prepare_replay(self) -> None:
-        """Before every replay of a graph that holds a captured ``step()``: advance the step count and publish this
-        step's learning rate / bias corrections where the captured copy + kernel read them."""
+        """Before every replay of a graph that holds a captured ``step()``, on the stream of the replay: advance the
+        step count and enqueue this step's learning rate / bias corrections in front of it."""
         if not self.capturable:
             raise RuntimeError("prepare_replay() belongs to a capturable optimizer (opt.capturable = True)")
         self._write_args(self._tick())
@@ -240,11 +248,11 @@ class FusedAdamW(_FlatOptimizer):
         vmax = self._state_buffer("max_exp_avg_sq") if g["amsgrad"] else None
         stream = torch.cuda.current_stream(self._flat.device).cuda_stream
         if self.capturable:
-            host, dev = self._arg_buffers()
+            dev = self._arg_buffer()
             if not torch.cuda.is_current_stream_capturing():
                 self._write_args(self._tick())          # eager use of a capturable optimizer
-            # (while capturing nothing runs and nothing is counted: prepare_replay() does both per replay)
-            dev.copy_(host, non_blocking=True)
+            # (while capturing, only the step kernel is recorded and nothing is counted: prepare_replay() publishes
+            # the scalars and counts, once per replay, outside the graph)
             with torch.cuda.device(self._flat.device):
                 check(lib.gnnsaft_adamw_step_dev(self._flat.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
                                                  None if vmax is None else vmax.data_ptr(), self._total,

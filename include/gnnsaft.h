@@ -31,7 +31,14 @@
 extern "C" {
 #endif
 
-#define GNNSAFT_ABI_VERSION 3
+#define GNNSAFT_ABI_VERSION 4
+
+/* The library is built with -fvisibility=hidden: only the functions declared  */
+/* in this header (GNNSAFT_API) are exported; kernels, launchers and helpers   */
+/* stay internal, so a second HIP library in the process cannot interpose.     */
+#ifndef GNNSAFT_API
+#define GNNSAFT_API __attribute__((visibility("default")))
+#endif
 
 #define GNNSAFT_OK 0
 #define GNNSAFT_ERR_SHAPE (-1)      /* unsupported / inconsistent sizes          */
@@ -53,8 +60,8 @@ extern "C" {
 
 typedef void *gnnsaft_stream_t;     /* hipStream_t */
 
-int gnnsaft_abi_version(void);
-const char *gnnsaft_error_string(int code);
+GNNSAFT_API int gnnsaft_abi_version(void);
+GNNSAFT_API const char *gnnsaft_error_string(int code);
 
 /* ------------------------------------------------------------------------ */
 /* K0: graph structure.  Replaces add_self_loops (models.py:118-121) and the  */
@@ -67,9 +74,9 @@ const char *gnnsaft_error_string(int code);
 /* log_amp[i] = log(deg_i + 1), log_att[i] = log(max(deg_i,1) + 1) with deg_i  */
 /* the run-time in-degree INCLUDING the self-loop (PyG DegreeScalerAggregation).*/
 /* ------------------------------------------------------------------------ */
-size_t gnnsaft_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges);
+GNNSAFT_API size_t gnnsaft_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges);
 
-int gnnsaft_csr_build(const int64_t *edge_index, const int64_t *edge_attr,
+GNNSAFT_API int gnnsaft_csr_build(const int64_t *edge_index, const int64_t *edge_attr,
                       int64_t num_nodes, int64_t num_edges,
                       int32_t num_bond_cols, const int32_t *bond_dims_host,
                       int32_t self_loops,
@@ -83,7 +90,7 @@ int gnnsaft_csr_build(const int64_t *edge_index, const int64_t *edge_attr,
                       gnnsaft_stream_t stream);
 
 /* graph pointer from PyG's sorted `batch` vector (global_add_pool, models.py:133) */
-int gnnsaft_batch_to_ptr(const int64_t *batch, int64_t num_nodes, int64_t num_graphs,
+GNNSAFT_API int gnnsaft_batch_to_ptr(const int64_t *batch, int64_t num_nodes, int64_t num_graphs,
                          int32_t *graph_ptr /* [G+1] */, int32_t *err_flag,
                          gnnsaft_stream_t stream);
 
@@ -92,14 +99,14 @@ int gnnsaft_batch_to_ptr(const int64_t *batch, int64_t num_nodes, int64_t num_gr
 /* sum_k table_k[idx[i,k], :], left-to-right.  `tables_host` is a HOST array   */
 /* of `num_cols` device pointers, `dims_host` the vocabulary sizes.            */
 /* ------------------------------------------------------------------------ */
-int gnnsaft_embed_sum(const int64_t *idx, int64_t num_rows, int32_t num_cols,
+GNNSAFT_API int gnnsaft_embed_sum(const int64_t *idx, int64_t num_rows, int32_t num_cols,
                       const float *const *tables_host, const int32_t *dims_host,
                       int32_t hidden, float *out, int32_t *err_flag,
                       gnnsaft_stream_t stream);
 
 /* BondEncoder evaluated once per attribute combination instead of once per   */
 /* edge: out[c,:] = sum_k table_k[digit_k(c), :], c in [0, prod(dims)).        */
-int gnnsaft_bond_combo_embed(int32_t num_cols, const float *const *tables_host,
+GNNSAFT_API int gnnsaft_bond_combo_embed(int32_t num_cols, const float *const *tables_host,
                              const int32_t *dims_host, int32_t hidden, float *out,
                              gnnsaft_stream_t stream);
 
@@ -114,7 +121,7 @@ int gnnsaft_bond_combo_embed(int32_t num_cols, const float *const *tables_host,
 /* applies y*scale[c]+shift[c] (eval-mode BatchNorm folded), then ReLU if     */
 /* relu_out, then adds residual[row,c] if non-NULL.                           */
 /* ------------------------------------------------------------------------ */
-int gnnsaft_linear(const float *a, int64_t lda, int32_t relu_in,
+GNNSAFT_API int gnnsaft_linear(const float *a, int64_t lda, int32_t relu_in,
                    const float *w, int64_t ldw, const float *bias,
                    float *out, int64_t ldo,
                    int64_t m, int32_t n_out, int32_t k,
@@ -122,7 +129,7 @@ int gnnsaft_linear(const float *a, int64_t lda, int32_t relu_in,
                    const float *residual, int64_t ldr,
                    float *stats, gnnsaft_stream_t stream);
 
-int32_t gnnsaft_bn_rows_per_group(void);
+GNNSAFT_API int32_t gnnsaft_bn_rows_per_group(void);
 
 /* ------------------------------------------------------------------------ */
 /* PNAConv message, first pre-layer (PyG PNAConv.message; models.py:69-80,128):*/
@@ -132,11 +139,11 @@ int32_t gnnsaft_bn_rows_per_group(void);
 /*   rtab[c, 0:2F] = [W_t[:,2F:3F] (W_e emb_c + b_e) + b_t]_t  (per edge class) */
 /* so that msg[e,t,:] = pq[dst,tF:(t+1)F] + pq[src,2F+tF:...] + rtab[c(e),...]. */
 /* ------------------------------------------------------------------------ */
-int gnnsaft_pna_node_terms(const float *x, int64_t num_nodes, int32_t hidden,
+GNNSAFT_API int gnnsaft_pna_node_terms(const float *x, int64_t num_nodes, int32_t hidden,
                            const float *w_pre0, const float *w_pre1, /* [F,3F] each */
                            float *pq /* [N,4F] */, gnnsaft_stream_t stream);
 
-int gnnsaft_pna_edge_table(const float *combo_emb, int32_t num_combos, int32_t hidden,
+GNNSAFT_API int gnnsaft_pna_edge_table(const float *combo_emb, int32_t num_combos, int32_t hidden,
                            const float *w_edge, const float *b_edge,   /* edge_encoder */
                            const float *w_pre0, const float *b_pre0,
                            const float *w_pre1, const float *b_pre1,
@@ -145,7 +152,7 @@ int gnnsaft_pna_edge_table(const float *combo_emb, int32_t num_combos, int32_t h
 
 /* remaining pre-layers (pre_layers >= 2): msgs[r,t,:] =                       */
 /*   W2_t relu(pq[dst_r] + pq[src_r] + rtab[combo_r]) + b2_t  in CSR row order. */
-int gnnsaft_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *combo,
+GNNSAFT_API int gnnsaft_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *combo,
                          int64_t num_rows, int32_t hidden,
                          const float *pq, const float *rtab,
                          const float *w2_t0, const float *b2_t0,
@@ -154,7 +161,7 @@ int gnnsaft_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *
 
 /* pre-activation of the first pre layer per CSR row, out[r,:] = pq[dst_r] + pq[src_r] + rtab[combo_r]  */
 /* ([E',2F]); materialised only when the backward of pre_layers >= 2 needs it.                          */
-int gnnsaft_pna_edge_preact(const int32_t *src, const int32_t *dst, const int32_t *combo,
+GNNSAFT_API int gnnsaft_pna_edge_preact(const int32_t *src, const int32_t *dst, const int32_t *combo,
                             int64_t num_rows, int32_t hidden, const float *pq, const float *rtab,
                             float *out, gnnsaft_stream_t stream);
 
@@ -168,7 +175,7 @@ int gnnsaft_pna_edge_preact(const int32_t *src, const int32_t *dst, const int32_
 /* Exactly one of (pq,rtab) / msgs is used: msgs == NULL selects the fused     */
 /* gather form for pre_layers == 1.                                            */
 /* ------------------------------------------------------------------------ */
-int gnnsaft_pna_aggregate(const int32_t *rowptr, const int32_t *src, const int32_t *combo,
+GNNSAFT_API int gnnsaft_pna_aggregate(const int32_t *rowptr, const int32_t *src, const int32_t *combo,
                           int64_t num_nodes, int32_t hidden,
                           const float *pq, const float *rtab, const float *msgs,
                           float *agg, gnnsaft_stream_t stream);
@@ -179,7 +186,7 @@ int gnnsaft_pna_aggregate(const int32_t *rowptr, const int32_t *src, const int32
 /* A = agg[i,t,:], amp_i = log_amp[i]/avg_deg_log, att_i = avg_deg_log/log_att[i];*/
 /* the [N,T,13F] input is never materialised (scalers applied on operand load).*/
 /* ------------------------------------------------------------------------ */
-int gnnsaft_pna_update(const float *x, const float *agg, const float *log_amp,
+GNNSAFT_API int gnnsaft_pna_update(const float *x, const float *agg, const float *log_amp,
                        const float *log_att, const float *avg_deg_log /* device, [1] */,
                        int64_t num_nodes, int32_t hidden,
                        const float *w_post0, const float *b_post0, /* [F/2,13F] */
@@ -200,13 +207,13 @@ int gnnsaft_pna_update(const float *x, const float *agg, const float *log_amp,
 /*     present in the histogram are written);                                  */
 /*   gnnsaft_pna_update_folded: u[N,F] as gnnsaft_pna_update.                  */
 /* ------------------------------------------------------------------------ */
-int32_t gnnsaft_degree_buckets(void);
-int64_t gnnsaft_degree_tiles_capacity(int64_t num_nodes, int32_t hidden);
-size_t gnnsaft_degree_scratch_ints(int64_t num_nodes);
-int gnnsaft_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm,
+GNNSAFT_API int32_t gnnsaft_degree_buckets(void);
+GNNSAFT_API int64_t gnnsaft_degree_tiles_capacity(int64_t num_nodes, int32_t hidden);
+GNNSAFT_API size_t gnnsaft_degree_scratch_ints(int64_t num_nodes);
+GNNSAFT_API int gnnsaft_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm,
                          int32_t *tiles, int32_t *num_tiles, int32_t *scratch, int32_t *err_flag,
                          gnnsaft_stream_t stream);
-int gnnsaft_pna_fold_post_weights(const float *w_post0, const float *w_post1,
+GNNSAFT_API int gnnsaft_pna_fold_post_weights(const float *w_post0, const float *w_post1,
                                   const float *avg_deg_log, const int32_t *hist, int32_t hidden,
                                   float *w_eff, gnnsaft_stream_t stream);
 #define GNNSAFT_MAX_FOLD_LAYERS 8
@@ -216,7 +223,7 @@ int gnnsaft_pna_fold_post_weights(const float *w_post0, const float *w_post1,
 /* the constant P_i = W_dst x_i and leaves std unchanged, so W_eff's x-block gains              */
 /* sum_s scale_s(d) (W_s,mean+W_s,min+W_s,max) W_dst (for d > 0) and the aggregates are taken   */
 /* over m~ = W_src x_src + edge term (gnnsaft_pna_aggregate_src).  g_scratch: L*2*3*(F/2)*F f32. */
-int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const float *const *w_post0_host,
+GNNSAFT_API int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const float *const *w_post0_host,
                                         const float *const *w_post1_host,
                                         const float *const *avg_deg_log_host,
                                         const float *const *w_pre0_host /* or NULL */,
@@ -225,19 +232,19 @@ int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const float *const *
                                         int32_t hidden, float *w_eff, int64_t layer_stride,
                                         gnnsaft_stream_t stream);
 /* source term only: q[i, tF:(t+1)F] = W_t[:,F:2F] x_i   ([N,2F]) */
-int gnnsaft_pna_src_terms(const float *x, int64_t num_nodes, int32_t hidden, const float *w_pre0,
+GNNSAFT_API int gnnsaft_pna_src_terms(const float *x, int64_t num_nodes, int32_t hidden, const float *w_pre0,
                           const float *w_pre1, float *q /* [N,2F] */, gnnsaft_stream_t stream);
 /* K4 over m~ = q[src] + rtab[class]: same outputs as gnnsaft_pna_aggregate minus the per-node shift P_i */
-int gnnsaft_pna_aggregate_src(const int32_t *rowptr, const int32_t *src, const int32_t *combo,
+GNNSAFT_API int gnnsaft_pna_aggregate_src(const int32_t *rowptr, const int32_t *src, const int32_t *combo,
                               int64_t num_nodes, int32_t hidden, const float *q, const float *rtab,
                               float *agg, gnnsaft_stream_t stream);
-int gnnsaft_pna_update_folded(const float *x, const float *agg, const int32_t *perm,
+GNNSAFT_API int gnnsaft_pna_update_folded(const float *x, const float *agg, const int32_t *perm,
                               const int32_t *tiles, const int32_t *num_tiles, int64_t num_nodes,
                               int32_t hidden, const float *w_eff, const float *b_post0,
                               const float *b_post1, float *u, gnnsaft_stream_t stream);
 /* tuning / test hook: gnnsaft_linear (no epilogue options) with an explicit tile configuration    */
 /* 0..5 = 256x32, 128x64, 128x128, 64x64, 64x128, 128x32; per call, the library keeps no global state */
-int gnnsaft_debug_linear_tile(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
+GNNSAFT_API int gnnsaft_debug_linear_tile(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
                               float *out, int64_t ldo, int64_t m, int32_t n_out, int32_t k,
                               float *stats /* or NULL */, int32_t tile_config, gnnsaft_stream_t stream);
 
@@ -248,7 +255,7 @@ int gnnsaft_debug_linear_tile(const float *a, int64_t lda, const float *w, int64
 /* num_batches_tracked, and emit scale = gamma*rstd, shift = beta - mean*scale.*/
 /* training == 0: scale / shift from the running statistics.                   */
 /* ------------------------------------------------------------------------ */
-int gnnsaft_bn_finalize(const float *stats, int64_t num_rows, int32_t channels,
+GNNSAFT_API int gnnsaft_bn_finalize(const float *stats, int64_t num_rows, int32_t channels,
                         const float *gamma, const float *beta,
                         float *running_mean, float *running_var, int64_t *num_batches_tracked,
                         float momentum, float eps, int32_t training,
@@ -258,8 +265,8 @@ int gnnsaft_bn_finalize(const float *stats, int64_t num_rows, int32_t channels,
 /* gnnsaft_linear, normalises y, updates the running statistics and the counter.  One    */
 /* launch up to 4096 rows; above that a small pre-combine launch folds the partials into  */
 /* <= 64 f64 segment sums in `scratch` (8-byte aligned, gnnsaft_bn_train_scratch_bytes).  */
-size_t gnnsaft_bn_train_scratch_bytes(int64_t num_rows, int32_t channels);
-int gnnsaft_bn_train_apply(const float *stats, const float *y, int64_t num_rows, int32_t channels,
+GNNSAFT_API size_t gnnsaft_bn_train_scratch_bytes(int64_t num_rows, int32_t channels);
+GNNSAFT_API int gnnsaft_bn_train_apply(const float *stats, const float *y, int64_t num_rows, int32_t channels,
                            const float *gamma, const float *beta, float *running_mean,
                            float *running_var, int64_t *num_batches_tracked, float momentum,
                            float eps, const float *residual, float *out,
@@ -268,17 +275,17 @@ int gnnsaft_bn_train_apply(const float *stats, const float *y, int64_t num_rows,
                            size_t scratch_bytes, gnnsaft_stream_t stream);
 
 /* out = relu(y*scale + shift) (+ residual)   (models.py:128-131) */
-int gnnsaft_bn_relu_residual(const float *y, const float *scale, const float *shift,
+GNNSAFT_API int gnnsaft_bn_relu_residual(const float *y, const float *scale, const float *shift,
                              const float *residual, float *out,
                              int64_t num_rows, int32_t channels, gnnsaft_stream_t stream);
 
 /* global_add_pool (models.py:133): out[g,:] = sum of rows graph_ptr[g]..graph_ptr[g+1]-1 */
-int gnnsaft_add_pool(const float *x, const int32_t *graph_ptr, int64_t num_graphs,
+GNNSAFT_API int gnnsaft_add_pool(const float *x, const int32_t *graph_ptr, int64_t num_graphs,
                      int64_t num_nodes, int32_t hidden, float *out, gnnsaft_stream_t stream);
 
 /* torchmetrics MAPE (models.py:194): out[0] = sum(|p-t| / max(|t|,1.17e-6)) / n, */
 /* out[1] = the sum, out[2] = n (for the cross-rank all-reduce).                 */
-int gnnsaft_mape(const float *pred, const float *target, int64_t numel, float *out3,
+GNNSAFT_API int gnnsaft_mape(const float *pred, const float *target, int64_t numel, float *out3,
                  gnnsaft_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
@@ -308,9 +315,13 @@ typedef struct gnnsaft_model_desc {
   int32_t save_tape;           /* 1: every layer keeps its tensors in the workspace for gnnsaft_backward */
   int32_t unfused_readout;     /* 1: per-op readout (pool, GEMMs, BatchNorm, MAPE launches) instead of readout.hip */
   double bn_eps_f64;           /* BatchNorm eps in full precision for the float64 kernels (0: use bn_eps) */
+  int32_t debug_barrier_extra; /* 0.  Test hook: the grid barriers of the fused readout wait for this many arrivals */
+                               /* more than there are workgroups, i.e. time out (flag + NaN outputs)                */
+  float readout_dropout;       /* p of the readout MLP's Dropout layers (models.py:88,95,99); applied in training  */
+  uint64_t dropout_seed;       /* Philox key of this call's dropout masks (the backward regenerates them from it)   */
 } gnnsaft_model_desc;
 
-int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);
+GNNSAFT_API int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);
 
 /* Optional per-kernel timing: HIP event pairs recorded on the launch stream  */
 /* around selected launches of gnnsaft_forward (bench.py's roofline figure).  */
@@ -323,10 +334,10 @@ int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);
 #define GNNSAFT_PROF_LIN 8         /* lin GEMM (+ BN partials / epilogue)     */
 #define GNNSAFT_PROF_NUM_KERNELS 4
 typedef struct gnnsaft_profile gnnsaft_profile;
-int gnnsaft_profile_create(int32_t capacity, uint32_t mask, gnnsaft_profile **out);
-void gnnsaft_profile_destroy(gnnsaft_profile *prof);
-int gnnsaft_profile_reset(gnnsaft_profile *prof);
-int gnnsaft_profile_summary(gnnsaft_profile *prof, uint32_t kernel_bit, int32_t *count, float *total_ms);
+GNNSAFT_API int gnnsaft_profile_create(int32_t capacity, uint32_t mask, gnnsaft_profile **out);
+GNNSAFT_API void gnnsaft_profile_destroy(gnnsaft_profile *prof);
+GNNSAFT_API int gnnsaft_profile_reset(gnnsaft_profile *prof);
+GNNSAFT_API int gnnsaft_profile_summary(gnnsaft_profile *prof, uint32_t kernel_bit, int32_t *count, float *total_ms);
 
 /* Optional side stream (+ events) lent to gnnsaft_forward / gnnsaft_backward.  Forward: the structure chain */
 /* (CSR, graph ptr, degree tiles, folded weights) runs there, concurrently with the embedding */
@@ -335,13 +346,13 @@ int gnnsaft_profile_summary(gnnsaft_profile *prof, uint32_t kernel_bit, int32_t 
 /* handle per concurrently running call; create it on the device it will be used on.          */
 /* Backward: see gnnsaft_backward.                                                             */
 typedef struct gnnsaft_aux gnnsaft_aux;
-int gnnsaft_aux_create(gnnsaft_aux **out);
-void gnnsaft_aux_destroy(gnnsaft_aux *aux);
+GNNSAFT_API int gnnsaft_aux_create(gnnsaft_aux **out);
+GNNSAFT_API void gnnsaft_aux_destroy(gnnsaft_aux *aux);
 
-size_t gnnsaft_forward_workspace_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes,
+GNNSAFT_API size_t gnnsaft_forward_workspace_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes,
                                        int64_t num_edges, int64_t num_graphs);
 
-int gnnsaft_forward(const gnnsaft_model_desc *desc,
+GNNSAFT_API int gnnsaft_forward(const gnnsaft_model_desc *desc,
                     const void *const *weights_host, int32_t num_weights,
                     const int64_t *x, const int64_t *edge_index, const int64_t *edge_attr,
                     const int64_t *batch /* NULL => single graph */,
@@ -360,9 +371,9 @@ int gnnsaft_forward(const gnnsaft_model_desc *desc,
 /* gnnsaft_forward over the same (desc sizes, n, e, g) -- it replaces the K0 chain by one device    */
 /* copy.  `workspace` as for gnnsaft_forward.  The blob must come from the same desc->hidden /      */
 /* self_loops / bond_dims and the same (num_nodes, num_edges, num_graphs).                          */
-size_t gnnsaft_structure_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes, int64_t num_edges,
+GNNSAFT_API size_t gnnsaft_structure_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes, int64_t num_edges,
                                int64_t num_graphs);
-int gnnsaft_structure_build(const gnnsaft_model_desc *desc, const int64_t *edge_index,
+GNNSAFT_API int gnnsaft_structure_build(const gnnsaft_model_desc *desc, const int64_t *edge_index,
                             const int64_t *edge_attr, const int64_t *batch, int64_t num_nodes,
                             int64_t num_edges, int64_t num_graphs, void *structure_out,
                             int32_t *err_flag, void *workspace, size_t workspace_bytes,
@@ -391,27 +402,29 @@ int gnnsaft_structure_build(const gnnsaft_model_desc *desc, const int64_t *edge_
 /* class sums, the edge-table chain, the transposed CSR -- runs on the handle's    */
 /* side stream, forked from and joined back into `stream` inside the call.         */
 /* ------------------------------------------------------------------------ */
-size_t gnnsaft_backward_scratch_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes,
+GNNSAFT_API size_t gnnsaft_backward_scratch_bytes(const gnnsaft_model_desc *desc, int64_t num_nodes,
                                       int64_t num_edges, int64_t num_graphs);
-int gnnsaft_backward(const gnnsaft_model_desc *desc, const void *const *weights_host,
+GNNSAFT_API int gnnsaft_backward(const gnnsaft_model_desc *desc, const void *const *weights_host,
                      void *const *grads_host, int32_t num_weights, const int64_t *x,
                      const int64_t *batch, int64_t num_nodes, int64_t num_edges, int64_t num_graphs,
                      const float *grad_out, void *tape, size_t tape_bytes, void *scratch,
                      size_t scratch_bytes, void *const *segment_events,
+                     int32_t *err_flag /* GNNSAFT_FLAG_* word of the forward, or NULL: a lost grid barrier of */
+                                       /* the fused readout backward raises bit 16 and poisons the gradients  */,
                      gnnsaft_aux *aux /* or NULL */, gnnsaft_stream_t stream);
 /* d(MAPE)/d(pred) * dloss[0] (dloss NULL => 1): sign(p-t) / max(|t|,1.17e-6) / (G*P) */
-int gnnsaft_mape_backward(const float *pred, const float *target, int64_t num_graphs,
+GNNSAFT_API int gnnsaft_mape_backward(const float *pred, const float *target, int64_t num_graphs,
                           int32_t num_para, const float *dloss, float *dpred,
                           gnnsaft_stream_t stream);
 /* tuning aid: gnnsaft_linear_wgrad with an explicit wave grid (wn x wk waves of 64 x 64 outputs, 1 x 1 = the    */
 /* 64 x 64 four-wave kernel) and slab count (0 = the library's choice)                                          */
-int gnnsaft_debug_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t lda, int64_t m,
+GNNSAFT_API int gnnsaft_debug_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t lda, int64_t m,
                                int32_t n_out, int32_t k, float *dw, int64_t ld_dw, void *scratch,
                                size_t scratch_bytes, int32_t wn, int32_t wk, int64_t chunks,
                                gnnsaft_stream_t stream);
 /* dW[n_out,k] (+)= dY^T A (deterministic slab reduction), dbias (+)= column sums of dY  */
-size_t gnnsaft_wgrad_scratch_bytes(int64_t m, int32_t n_out, int32_t k);
-int gnnsaft_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t lda, int32_t relu_a,
+GNNSAFT_API size_t gnnsaft_wgrad_scratch_bytes(int64_t m, int32_t n_out, int32_t k);
+GNNSAFT_API int gnnsaft_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t lda, int32_t relu_a,
                          int64_t m, int32_t n_out, int32_t k, float *dw, int64_t ld_dw,
                          int32_t accumulate, float *dbias, void *scratch, size_t scratch_bytes,
                          gnnsaft_stream_t stream);
@@ -432,13 +445,13 @@ int gnnsaft_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t l
 /* ------------------------------------------------------------------------ */
 #define GNNSAFT_DTYPE_F32 0
 #define GNNSAFT_DTYPE_F64 1
-size_t gnnsaft_eval_pack_bytes(const gnnsaft_model_desc *desc, int32_t dtype);
-int gnnsaft_eval_pack(const gnnsaft_model_desc *desc, const void *const *weights_host,
+GNNSAFT_API size_t gnnsaft_eval_pack_bytes(const gnnsaft_model_desc *desc, int32_t dtype);
+GNNSAFT_API int gnnsaft_eval_pack(const gnnsaft_model_desc *desc, const void *const *weights_host,
                       int32_t num_weights, int32_t dtype, void *pack, size_t pack_bytes,
                       gnnsaft_stream_t stream);
-size_t gnnsaft_graph_forward_workspace_bytes(const gnnsaft_model_desc *desc, int32_t dtype,
+GNNSAFT_API size_t gnnsaft_graph_forward_workspace_bytes(const gnnsaft_model_desc *desc, int32_t dtype,
                                              int64_t num_nodes, int64_t num_edges, int64_t num_graphs);
-int gnnsaft_graph_forward(const gnnsaft_model_desc *desc, int32_t dtype, const void *pack,
+GNNSAFT_API int gnnsaft_graph_forward(const gnnsaft_model_desc *desc, int32_t dtype, const void *pack,
                           const int64_t *x, const int64_t *edge_index, const int64_t *edge_attr,
                           const int64_t *batch /* NULL => single graph */, int64_t num_nodes,
                           int64_t num_edges, int64_t num_graphs, void *out /* [G,P] of dtype */,
@@ -457,7 +470,7 @@ typedef struct gnnsaft_workspace_map {
   size_t x_stride;  /* tape (save_tape): x_0 .. x_L contiguous from x_embed, x_stride BYTES apart; 0 without a tape */
 } gnnsaft_workspace_map;
 
-int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int64_t num_nodes,
+GNNSAFT_API int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int64_t num_nodes,
                                   int64_t num_edges, int64_t num_graphs,
                                   gnnsaft_workspace_map *map);
 
@@ -469,20 +482,22 @@ int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int64_t num_no
 /* world size after a SUM all-reduce).  max_exp_avg_sq == NULL: amsgrad off.   */
 /* All pointers 16-byte aligned, `count` floats each.  `step` counts from 1.   */
 /* ------------------------------------------------------------------------ */
-int gnnsaft_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+GNNSAFT_API int gnnsaft_adamw_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                        float *max_exp_avg_sq, int64_t count, float lr, float beta1, float beta2,
                        float eps, float weight_decay, int64_t step, float grad_scale,
                        gnnsaft_stream_t stream);
 /* The same step with its per-step scalars (learning rate, bias corrections) read from DEVICE memory, for a     */
-/* launch that lives in a captured hipGraph: gnnsaft_adamw_args writes the gnnsaft_adamw_args_floats() floats  */
-/* of step `step` into HOST memory (pinned: a captured host-to-device copy re-reads it at every replay).       */
-int32_t gnnsaft_adamw_args_floats(void);
-int gnnsaft_adamw_args(float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                       float grad_scale, float *args_host);
-int gnnsaft_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+/* launch that lives in a captured hipGraph: gnnsaft_adamw_args enqueues, on `stream`, the write of the         */
+/* gnnsaft_adamw_args_floats() floats of step `step` into DEVICE memory `args_dev`.  The values travel as kernel */
+/* arguments (copied when the call returns), so a replay queued behind it reads exactly this step's scalars      */
+/* however far the host runs ahead; call it outside the captured region, on the stream the graph is replayed on. */
+GNNSAFT_API int32_t gnnsaft_adamw_args_floats(void);
+GNNSAFT_API int gnnsaft_adamw_args(float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                       float grad_scale, float *args_dev, gnnsaft_stream_t stream);
+GNNSAFT_API int gnnsaft_adamw_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                            float *max_exp_avg_sq, int64_t count, const float *args_dev,
                            gnnsaft_stream_t stream);
-int gnnsaft_sgd_step(float *param, const float *grad, float *momentum_buf, int64_t count, float lr,
+GNNSAFT_API int gnnsaft_sgd_step(float *param, const float *grad, float *momentum_buf, int64_t count, float lr,
                      float momentum, float weight_decay, int32_t first_step, float grad_scale,
                      gnnsaft_stream_t stream);
 

@@ -81,8 +81,9 @@ def test_fused_readout_feeds_the_backward_tape():
 
 
 def test_large_batches_take_the_per_op_readout_and_many_steps_reuse_the_counters():
-    """More than 256 workgroups' worth of graphs (16 384) cannot be co-resident: per-op path, same results API;
-    repeated steps and a hipGraph replay keep working because the prologue re-zeroes the barrier counters."""
+    """Repeated steps and a hipGraph replay keep working because the prologue re-zeroes the barrier counters; a batch
+    with more workgroups' worth of graphs than the device keeps co-resident (occupancy x CU count, asked of the
+    runtime per device) takes the per-op path behind the same API."""
     from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
     data = make_synthetic_batch(300, 8)
     oracle = oracle_model(64, 1, 1, 1, 1, 3, True, True, degree_histogram(data), seed=1).train()
@@ -110,5 +111,44 @@ def test_large_batches_take_the_per_op_readout_and_many_steps_reuse_the_counters
     ob = oracle_model(64, 1, 1, 1, 0, 3, False, True, degree_histogram(big), seed=2).eval()
     mb, rb = hip_twin(copy.deepcopy(ob)), hip_twin(copy.deepcopy(ob))
     rb.fused_readout = False
+    with torch.no_grad():     # fused or per-op, whatever this device's residency bound says: same results
+        assert rel_err(mb(big.to(DEV)), rb(big.to(DEV))) < 2e-6
+        assert rel_err(mb.train()(big.to(DEV)), rb.train()(big.to(DEV))) < 2e-6
+    assert mb.input_error_flags() == 0
+
+
+def test_a_lost_grid_barrier_raises_the_flag_and_poisons_the_results():
+    """The fused readout's grid barriers are only safe while every workgroup is resident.  The launcher asks the
+    occupancy calculator; what that cannot see (another process on the GPU, a CU mask) ends in the bounded spin.  Force
+    it (desc.debug_barrier_extra: the barriers wait for one arrival that never comes) and demand the loud failure:
+    GNNSAFT_FLAG_BARRIER_TIMEOUT raised, predictions / loss NaN in the forward, every gradient below the readout NaN in
+    the backward, the training loop's flag check fatal -- wrong BatchNorm statistics can never train silently."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    from gnn_epc_saft_amd.train.models import mape_loss
+    data = make_synthetic_batch(130, 21)
+    oracle = oracle_model(64, 1, 1, 1, 1, 3, True, True, degree_histogram(data), seed=3).train()
+    m = hip_twin(copy.deepcopy(oracle))
+    dd, tgt = data.to(DEV), data.para.view(-1, 3).to(DEV)
     with torch.no_grad():
-        assert torch.equal(mb(big.to(DEV)), rb(big.to(DEV)))      # both take the per-op path
+        good, gl = m.run(dd, target=tgt)
+        assert bool(torch.isfinite(good).all()) and m.input_error_flags() == 0
+        m._debug_barrier_extra = 1
+        bad, bl = m.run(dd, target=tgt)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(bad).all()) and bool(torch.isnan(bl[0]))
+        assert m.input_error_flags() & 16
+        assert m.input_error_flags() == 0                 # cleared by the read
+        m.eval()                                          # no batch statistics, no barrier: nothing to lose
+        ok = m(dd)
+        assert bool(torch.isfinite(ok).all()) and m.input_error_flags() == 0
+        m.train()
+    # backward: the forward's barriers pass, the backward's are lost
+    m._debug_barrier_extra = 0
+    pred = m(dd)
+    pred.grad_fn.tape["desc"].debug_barrier_extra = 1
+    mape_loss(pred, tgt).backward()
+    torch.cuda.synchronize()
+    assert m.input_error_flags() & 16
+    grads = dict(m.named_parameters())
+    assert bool(torch.isnan(grads["convs.0.lin.weight"].grad).all())
+    assert bool(torch.isnan(grads["node_embed.atom_embedding_list.0.weight"].grad).any())

@@ -261,6 +261,44 @@ def test_graphed_training_step_equals_eager_steps(two_streams):
             assert torch.equal(sa[i][key], sb[i][key]), (i, key)
 
 
+def test_graphed_replays_issued_back_to_back_equal_eager_steps():
+    """N replays enqueued WITHOUT a host synchronisation in between (the host runs several steps ahead of the GPU:
+    bench.py's hipgraph loop, any fixed-batch training loop) against N eager steps: same bits.  Early steps are the
+    sensitive ones (the learning rate / bias corrections of steps 3 and 4 differ by ~27 %): a replay that read the
+    per-step scalars of a LATER step -- a host buffer rewritten while replays are still queued -- fails here."""
+    import gnn_epc_saft_amd as G
+    lit_a, batches, _ = _setup()
+    lit_b, _, _ = _setup()
+    batch = batches[0]
+    steps, warm = 12, 1
+    conf = lit_a.configure_optimizers()
+    opt_a, sched_a = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    lit_a.train()
+    for _ in range(steps):
+        opt_a.zero_grad(set_to_none=True)
+        lit_a.training_step(batch).backward()
+        opt_a.step()
+        sched_a.step()
+    conf = lit_b.configure_optimizers()
+    opt_b, sched_b = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    lit_b.train()
+    graphed = G.GraphedTrainingStep(lit_b, opt_b, batch, scheduler=sched_b, warmup=warm)
+    torch.cuda.synchronize()
+    # keep the GPU busy so that the replays below queue up behind it while the host runs ahead
+    ballast = torch.randn(8192, 8192, device=DEV)
+    for _ in range(4):
+        ballast = ballast @ ballast * 1e-4
+    for _ in range(steps - warm):
+        graphed()                 # no .item(), no synchronize: the host publishes step k+1 while step k is queued
+    torch.cuda.synchronize()
+    for (ka, va), (kb, vb) in zip(lit_a.state_dict().items(), lit_b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    sa, sb = opt_a.state_dict()["state"], opt_b.state_dict()["state"]
+    for i in sa:
+        for key in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+            assert torch.equal(sa[i][key], sb[i][key]), (i, key)
+
+
 def test_loader_prefetch_thread_yields_the_same_batches_and_stops_cleanly():
     """GraphLoader(prefetch=2) -- batches collated, staged and copied by a background thread -- against prefetch=0
     (caller's thread): identical batches in identical order over two reshuffled epochs; forever() continues across

@@ -25,7 +25,13 @@ def test_library_exports_every_symbol_declared_in_the_header():
         assert hasattr(lib, name), f"{name} declared in include/gnnsaft.h but not exported"
         assert name in _native.SIGNATURES, f"{name} has no ctypes signature in _native.py"
     assert set(_native.SIGNATURES) <= declared
-    assert _native.lib.gnnsaft_abi_version() == 3
+    # ... and NOTHING else: the library is built with -fvisibility=hidden + csrc/exports.map, so the dynamic symbol
+    # table is exactly the C ABI (no mangled launchers / kernel handles another HIP library could interpose)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], check=True, capture_output=True, text=True)
+    exported = {line.split()[-1] for line in nm.stdout.splitlines() if line.strip()}
+    assert exported == declared, sorted(exported ^ declared)[:10]
+    assert _native.lib.gnnsaft_abi_version() == _native.ABI_VERSION == 4
     assert _native.lib.gnnsaft_error_string(-2) == b"workspace too small"
 
 
