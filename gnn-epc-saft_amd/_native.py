@@ -88,6 +88,7 @@ SIGNATURES = {
     "gnnsaft_add_pool": (c_int32, [P, P, c_int64, c_int64, c_int32, P, P]),
     "gnnsaft_mape": (c_int32, [P, P, c_int64, P, P]),
     "gnnsaft_num_weights": (c_int32, [POINTER(ModelDesc)]),
+    "gnnsaft_readout_resident_workgroups": (c_int32, [c_int32, c_int32]),
     "gnnsaft_forward_workspace_bytes": (c_size_t, [POINTER(ModelDesc), c_int64, c_int64, c_int64]),
     "gnnsaft_forward_workspace_map": (c_int32, [POINTER(ModelDesc), c_int64, c_int64, c_int64, POINTER(WorkspaceMap)]),
     "gnnsaft_forward": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p), c_int32, P, P, P, P, c_int64, c_int64,

@@ -270,7 +270,7 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
                             const int32_t *bond_dims_host, int32_t hidden, float *x_out, float *cemb,
                             int32_t *zero_ptr, int64_t zero_count, int32_t fold_layers,
                             const float *const *w_post0_host, const float *const *w_post1_host,
-                            const float *const *w_pre0_host, const float *const *w_pre1_host, float *g_all,
+                            const float *const *w_pre0_host, const float *const *w_pre1_host, double *g_all,
                             int32_t *err_flag, hipStream_t st, int32_t *zero2_ptr = nullptr, int zero2_count = 0,
                             const struct EdgeTableLayers *tables = nullptr /* fold.hpp */, int32_t table_layers = 0,
                             float *cenc = nullptr, float *rtab = nullptr);
@@ -285,7 +285,7 @@ int launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_
 struct DegreeFoldRequest {
   int num_layers;
   const float *const *w_post0, *const *w_post1, *const *avg;
-  const float *g_all;   // destination-term products (k_dst_fold) or null
+  const double *g_all;  // destination-term products (k_dst_fold, float64) or null
   float *w_eff;
   int64_t layer_stride;
 };
@@ -294,7 +294,7 @@ int launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden
                         const DegreeFoldRequest *fold = nullptr);
 int launch_fold_post_weights(int32_t num_layers, const float *const *w_post0_host, const float *const *w_post1_host,
                              const float *const *avg_deg_log_host, const float *const *w_pre0_host,
-                             const float *const *w_pre1_host, float *g_scratch, const int32_t *hist, int32_t hidden,
+                             const float *const *w_pre1_host, double *g_scratch, const int32_t *hist, int32_t hidden,
                              float *w_eff, int64_t layer_stride, int phases /* 1: dst fold, 2: degree fold */,
                              hipStream_t st);
 

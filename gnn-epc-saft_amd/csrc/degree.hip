@@ -121,14 +121,14 @@ __global__ __launch_bounds__(kDegBlock) void k_degree_fill(const int32_t *__rest
   degree_fill_body(rowptr, n, block_base, start, perm);
 }
 
-__global__ __launch_bounds__(256) void k_dst_fold(FoldLayers fl, int f, float *__restrict__ g_all) {
+__global__ __launch_bounds__(256) void k_dst_fold(FoldLayers fl, int f, double *__restrict__ g_all) {
   dst_fold_body(fl, f, g_all, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // slot: float4 index inside one [F/2, 5F] block; t: tower; dz: degree + kDegreeBuckets * layer
 __device__ __forceinline__ void fold_post_weights_body(const FoldLayers &fl, const int32_t *__restrict__ hist, int f,
                                                        float *__restrict__ w_eff_all, int64_t layer_stride,
-                                                       const float *__restrict__ g_all, int64_t slot, int t, int dz) {
+                                                       const double *__restrict__ g_all, int64_t slot, int t, int dz) {
   const int d = dz % kDegreeBuckets;
   const int layer = dz / kDegreeBuckets;
   if (hist[d] == 0) return;  // degree absent from this batch
@@ -139,26 +139,31 @@ __device__ __forceinline__ void fold_post_weights_body(const FoldLayers &fl, con
   if (o >= f / 2) return;
   const int c = (int)(slot - o * per_row4) * 4;
   const float *w = (t == 0 ? w0 : w1) + o * (int64_t)(13 * f);
-  const float avgv = avg[0];
-  const float amp = logf((float)d + 1.f) / avgv;
-  const float att = avgv / logf(fmaxf((float)d, 1.f) + 1.f);
+  float amp_f, att_f;
+  degree_scalers(d, avg[0], amp_f, att_f);
+  const double amp = (double)amp_f, att = (double)att_f;
+  // float64 accumulate, ONE rounding per folded weight (fold.hpp)
   f32x4 v;
   if (c < f) {
     v = gs_ld4(w + c);
     if (g_all != nullptr && d > 0) {  // d == 0: no in-edge, the aggregates (and the P term) are zero
-      const float *g = g_all + ((((int64_t)layer * 2 + t) * 3) * (f / 2) + o) * f + c;
+      const double *g = g_all + ((((int64_t)layer * 2 + t) * 3) * (f / 2) + o) * f + c;
       const int64_t gs = (int64_t)(f / 2) * f;
-      v = v + (gs_ld4(g) + gs_ld4(g + gs) * amp + gs_ld4(g + 2 * gs) * att);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        v[j] = (float)((double)v[j] + (g[j] + g[gs + j] * amp + g[2 * gs + j] * att));
     }
   } else {
-    v = gs_ld4(w + c) + gs_ld4(w + 4 * f + c) * amp + gs_ld4(w + 8 * f + c) * att;
+    const f32x4 w_id = gs_ld4(w + c), w_amp = gs_ld4(w + 4 * f + c), w_att = gs_ld4(w + 8 * f + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (float)((double)w_id[j] + (double)w_amp[j] * amp + (double)w_att[j] * att);
   }
   gs_st4(w_eff + (((int64_t)d * 2 + t) * (f / 2) + o) * (int64_t)(5 * f) + c, v);
 }
 
 __global__ __launch_bounds__(256) void k_fold_post_weights(FoldLayers fl, const int32_t *__restrict__ hist, int f,
                                                            float *__restrict__ w_eff_all, int64_t layer_stride,
-                                                           const float *__restrict__ g_all) {
+                                                           const double *__restrict__ g_all) {
   fold_post_weights_body(fl, hist, f, w_eff_all, layer_stride, g_all, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
                          blockIdx.y, blockIdx.z);
 }
@@ -171,7 +176,7 @@ struct FoldJob {
   int f;
   float *w_eff_all;
   int64_t layer_stride;
-  const float *g_all;
+  const double *g_all;
   int x_blocks;      // kDegBlock-thread workgroups per [F/2, 5F] block
   int num_layers;
 };
@@ -261,16 +266,17 @@ extern "C" int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const flo
                                                    const float *const *w_post1_host,
                                                    const float *const *avg_deg_log_host,
                                                    const float *const *w_pre0_host, const float *const *w_pre1_host,
-                                                   float *g_scratch, const int32_t *hist, int32_t hidden,
+                                                   void *g_scratch, const int32_t *hist, int32_t hidden,
                                                    float *w_eff, int64_t layer_stride, gnnsaft_stream_t stream) {
+  GS_REQUIRE((reinterpret_cast<uintptr_t>(g_scratch) & 7) == 0, GNNSAFT_ERR_SHAPE);
   return gs::launch_fold_post_weights(num_layers, w_post0_host, w_post1_host, avg_deg_log_host, w_pre0_host,
-                                      w_pre1_host, g_scratch, hist, hidden, w_eff, layer_stride, 3,
+                                      w_pre1_host, static_cast<double *>(g_scratch), hist, hidden, w_eff, layer_stride, 3,
                                       static_cast<hipStream_t>(stream));
 }
 
 int gs::launch_fold_post_weights(int32_t num_layers, const float *const *w_post0_host,
                                  const float *const *w_post1_host, const float *const *avg_deg_log_host,
-                                 const float *const *w_pre0_host, const float *const *w_pre1_host, float *g_scratch,
+                                 const float *const *w_pre0_host, const float *const *w_pre1_host, double *g_scratch,
                                  const int32_t *hist, int32_t hidden, float *w_eff, int64_t layer_stride, int phases,
                                  hipStream_t st) {
   GS_REQUIRE(w_post0_host && w_post1_host && avg_deg_log_host && hist && w_eff, GNNSAFT_ERR_NULL);

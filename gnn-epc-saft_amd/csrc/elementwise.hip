@@ -96,7 +96,7 @@ struct PrologueArgs {
   int zero2_count;
   // destination-term fold (dst_blocks == 0: off)
   FoldLayers fl;
-  float *g_all;
+  double *g_all;
   int dst_gx, dst_gy;
   int h;
   unsigned dst_blocks;             // workgroups [0, dst_blocks): destination fold
@@ -339,7 +339,7 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
                             const int32_t *bond_dims_host, int32_t hidden, float *x_out, float *cemb,
                             int32_t *zero_ptr, int64_t zero_count, int32_t fold_layers,
                             const float *const *w_post0_host, const float *const *w_post1_host,
-                            const float *const *w_pre0_host, const float *const *w_pre1_host, float *g_all,
+                            const float *const *w_pre0_host, const float *const *w_pre1_host, double *g_all,
                             int32_t *err_flag, hipStream_t st, int32_t *zero2_ptr, int zero2_count,
                             const EdgeTableLayers *tables, int32_t table_layers, float *cenc, float *rtab) {
   GS_REQUIRE(x_idx && x_out && cemb && num_rows >= 1, GNNSAFT_ERR_NULL);

@@ -408,6 +408,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
   const int64_t n = num_nodes, g = num_graphs;
   auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
   auto I = [&](size_t off) { return reinterpret_cast<int32_t *>(ws + off); };
+  auto D = [&](size_t off) { return reinterpret_cast<double *>(ws + off); };
 
   WeightCursor wc{weights_host, num_weights};
   const float *atom_tab[GNNSAFT_MAX_TABLES], *bond_tab[GNNSAFT_MAX_TABLES];
@@ -484,7 +485,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     }
     GS_TRY(launch_forward_prologue(x_idx, n, d->num_atom_cols, atom_tab, d->atom_dims, d->num_bond_cols, bond_tab,
                                    d->bond_dims, h, F(p.x0), F(p.cemb), zero_ptr, zero_count,
-                                   dst_in_prologue ? d->num_layers : 0, w0, w1, p0, p1, F(p.gfold), err_flag, st,
+                                   dst_in_prologue ? d->num_layers : 0, w0, w1, p0, p1, D(p.gfold), err_flag, st,
                                    I(p.rd_sync), kRdSyncInts, &et, tables_in_prologue ? d->num_layers : 0, F(p.cenc),
                                    F(p.rtab)));
   }
@@ -507,7 +508,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
         p1[i] = lw[l0 + i].wpre[1][0];
       }
       GS_TRY(launch_fold_post_weights(nl, w0, w1, av, fold_dst ? p0 : nullptr, fold_dst ? p1 : nullptr,
-                                      fold_dst ? F(p.gfold) + (int64_t)l0 * 6 * (h / 2) * h : nullptr, I(p.hist3), h,
+                                      fold_dst ? D(p.gfold) + (int64_t)l0 * 6 * (h / 2) * h : nullptr, I(p.hist3), h,
                                       F(p.weff) + l0 * wstride, wstride, phases, sa));
     }
     return GNNSAFT_OK;
@@ -534,7 +535,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
         w1[i] = lw[i].wpost[1][0];
         av[i] = lw[i].avg;
       }
-      const DegreeFoldRequest req{d->num_layers, w0, w1, av, fold_dst ? F(p.gfold) : nullptr, F(p.weff), wstride};
+      const DegreeFoldRequest req{d->num_layers, w0, w1, av, fold_dst ? D(p.gfold) : nullptr, F(p.weff), wstride};
       GS_TRY(launch_degree_tiles(I(p.rowptr), n, h, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3), err_flag,
                                  true, sa, &req));
     } else {

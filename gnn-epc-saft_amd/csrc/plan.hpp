@@ -137,7 +137,7 @@ static inline int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, i
     p.rd_sync = take(64);
   }
   p.weff = d->fold_degree_scalers ? take(nl * (size_t)kDegreeBuckets * 5 * h * h * 4) : 0;
-  p.gfold = d->fold_degree_scalers ? take(nl * 2 * 3 * (h / 2) * h * 4) : 0;
+  p.gfold = d->fold_degree_scalers ? take(nl * 2 * 3 * (h / 2) * h * 8) : 0;   // float64 (fold.hpp)
   p.total = off;
   return GNNSAFT_OK;
 }

@@ -17,6 +17,8 @@
 // incomplete BatchNorm statistics.  The MAPE sum is closed by the last workgroup to arrive (an
 // atomic ticket), which adds the per-workgroup partials in workgroup order: deterministic, no float atomics.
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 
 #include "plan.hpp"
 #include "readout.hpp"
@@ -633,17 +635,26 @@ static int readout_resident_workgroups(int h, bool backward) {
                             : reinterpret_cast<const void *>(&k_readout_fused);
   const size_t lds = backward ? rd_bwd_lds(h) : rd_fwd_lds(h);
   int result = -1, cus = 0, per_cu = 0;
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
-    const hipError_t e = backward
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_readout_bwd_fused, kRdThreads, lds)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_readout_fused, kRdThreads, lds);
-    if (e == hipSuccess && per_cu >= 1 && cus >= 1) result = per_cu * cus;
-  }
+  // (the kernels also hold a few bytes of static LDS: ask for what the launch needs, not for the device's 160 KB)
+  const hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const hipError_t e2 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const hipError_t e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kRdThreads, lds);
+  if (getenv("GNNSAFT_DEBUG"))
+    fprintf(stderr, "readout residency h=%d bwd=%d: setattr %d, cus %d (%d), occupancy %d (%d), lds %zu\n", h,
+            (int)backward, (int)e1, cus, (int)e2, per_cu, (int)e3, lds);
+  if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && per_cu >= 1 && cus >= 1) result = per_cu * cus;
   (void)hipGetLastError();   // a failed query must not surface as the next launch's error
   if (cached) cache[dev][backward ? 1 : 0][hi].store(result, std::memory_order_release);
   return result > 0 ? result : 0;
 }
+
+}  // namespace gs
+
+extern "C" int32_t gnnsaft_readout_resident_workgroups(int32_t hidden, int32_t backward) {
+  return gs::readout_resident_workgroups(hidden, backward != 0);
+}
+
+namespace gs {
 
 bool readout_fused_launchable(int64_t g, int h, int num_para, int nblocks, bool backward) {
   const bool shape = backward ? readout_bwd_fused_supported(g, h, num_para, nblocks)

@@ -246,7 +246,7 @@ def pna_update_folded_dst(x, agg_src, perm, tiles, num_tiles, hist3, avg_deg_log
     n, h = x.shape
     buckets = int(lib.gnnsaft_degree_buckets())
     w_eff = torch.full((buckets, 2, h // 2, 5 * h), float("nan"), dtype=torch.float32, device=x.device)
-    g = torch.empty((2, 3, h // 2, h), dtype=torch.float32, device=x.device)
+    g = torch.empty((2, 3, h // 2, h), dtype=torch.float64, device=x.device)
     arr = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
     check(lib.gnnsaft_pna_fold_post_weights_multi(1, arr(w_post0), arr(w_post1), arr(avg_deg_log), arr(w_pre0),
                                                   arr(w_pre1), _p(g), _p(hist3), h, _p(w_eff), 0, _stream(x)),

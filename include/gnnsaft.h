@@ -222,13 +222,14 @@ GNNSAFT_API int gnnsaft_pna_fold_post_weights(const float *w_post0, const float 
 /* term of the message is folded too: msg = W_dst x_dst + m~ shifts mean/min/max of a node by   */
 /* the constant P_i = W_dst x_i and leaves std unchanged, so W_eff's x-block gains              */
 /* sum_s scale_s(d) (W_s,mean+W_s,min+W_s,max) W_dst (for d > 0) and the aggregates are taken   */
-/* over m~ = W_src x_src + edge term (gnnsaft_pna_aggregate_src).  g_scratch: L*2*3*(F/2)*F f32. */
+/* over m~ = W_src x_src + edge term (gnnsaft_pna_aggregate_src).  g_scratch: L*2*3*(F/2)*F f64  */
+/* (8-byte aligned).  Every folded weight is accumulated in float64 and rounded to f32 once.      */
 GNNSAFT_API int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const float *const *w_post0_host,
                                         const float *const *w_post1_host,
                                         const float *const *avg_deg_log_host,
                                         const float *const *w_pre0_host /* or NULL */,
                                         const float *const *w_pre1_host /* or NULL */,
-                                        float *g_scratch /* or NULL */, const int32_t *hist,
+                                        void *g_scratch /* or NULL */, const int32_t *hist,
                                         int32_t hidden, float *w_eff, int64_t layer_stride,
                                         gnnsaft_stream_t stream);
 /* source term only: q[i, tF:(t+1)F] = W_t[:,F:2F] x_i   ([N,2F]) */
@@ -322,6 +323,13 @@ typedef struct gnnsaft_model_desc {
 } gnnsaft_model_desc;
 
 GNNSAFT_API int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);
+
+/* Workgroups (of 64 graphs each) of the one-launch readout (forward: backward = 0; its backward: 1) that the  */
+/* CURRENT device keeps co-resident for hidden size `hidden`: hipOccupancyMaxActiveBlocksPerMultiprocessor x    */
+/* multiProcessorCount, 0 when the query fails.  gnnsaft_forward / gnnsaft_backward take the one-launch readout  */
+/* (train-mode BatchNorm statistics meet at a grid barrier) up to this many workgroups and the per-op launches   */
+/* beyond, unless desc->unfused_readout.  Needs a device.                                                        */
+GNNSAFT_API int32_t gnnsaft_readout_resident_workgroups(int32_t hidden, int32_t backward);
 
 /* Optional per-kernel timing: HIP event pairs recorded on the launch stream  */
 /* around selected launches of gnnsaft_forward (bench.py's roofline figure).  */

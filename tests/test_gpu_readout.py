@@ -123,8 +123,12 @@ def test_a_lost_grid_barrier_raises_the_flag_and_poisons_the_results():
     it (desc.debug_barrier_extra: the barriers wait for one arrival that never comes) and demand the loud failure:
     GNNSAFT_FLAG_BARRIER_TIMEOUT raised, predictions / loss NaN in the forward, every gradient below the readout NaN in
     the backward, the training loop's flag check fatal -- wrong BatchNorm statistics can never train silently."""
+    from gnn_epc_saft_amd._native import lib
     from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
     from gnn_epc_saft_amd.train.models import mape_loss
+    # the residency query must WORK on this device (a failing query would silently route everything per-op)
+    assert lib.gnnsaft_readout_resident_workgroups(64, 0) >= 64 and lib.gnnsaft_readout_resident_workgroups(64, 1) >= 64
+    assert lib.gnnsaft_readout_resident_workgroups(256, 0) >= 64 and lib.gnnsaft_readout_resident_workgroups(256, 1) >= 64
     data = make_synthetic_batch(130, 21)
     oracle = oracle_model(64, 1, 1, 1, 1, 3, True, True, degree_histogram(data), seed=3).train()
     m = hip_twin(copy.deepcopy(oracle))
