@@ -371,16 +371,16 @@ __global__ __launch_bounds__(256) void k_fold_post_weights_t(FoldLayers fl, cons
   const int d = dz / 2, t = dz % 2;
   if (hist[d] == 0) return;
   const float *w = t == 0 ? fl.pp[layer].w0 : fl.pp[layer].w1;
-  const float avgv = fl.avg[layer][0];
-  const float amp = logf((float)d + 1.f) / avgv;
-  const float att = avgv / logf(fmaxf((float)d, 1.f) + 1.f);
+  float amp_f, att_f;
+  degree_scalers(d, fl.avg[layer][0], amp_f, att_f);
+  const double amp = (double)amp_f, att = (double)att_f;   // float64 accumulate, one rounding (fold.hpp)
   const int o0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int o = o0 + ty + 8 * j;
     const float *wr = w + (int64_t)o * (13 * f) + f + c0 + tx;
-    tl[ty + 8 * j][tx] = wr[0] + wr[4 * f] * amp + wr[8 * f] * att;
+    tl[ty + 8 * j][tx] = (float)((double)wr[0] + (double)wr[4 * f] * amp + (double)wr[8 * f] * att);
   }
   __syncthreads();
   float *out = wta_all + layer * wta_per_layer + (((int64_t)d * 2 + t) * (4 * f)) * (f / 2);

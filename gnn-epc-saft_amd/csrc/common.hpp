@@ -230,6 +230,16 @@ __device__ __forceinline__ int clamp_degree(int d, int32_t *err) {
   return d;
 }
 
+// The degree scalers of PyG's DegreeScalerAggregation, as float32 values the way the
+// reference forms them: log of a float32 integer (here the correctly rounded float32 logarithm -- one definition for
+// every kernel that needs it), float32 division by / of the float32 buffer avg_deg_log.
+__device__ __forceinline__ float degree_log_amp(int d) { return (float)log((double)d + 1.0); }                 // log(d + 1)
+__device__ __forceinline__ float degree_log_att(int d) { return (float)log((double)(d > 1 ? d : 1) + 1.0); }   // log(max(d,1) + 1)
+__device__ __forceinline__ void degree_scalers(int d, float avg, float &amp, float &att) {
+  amp = degree_log_amp(d) / avg;
+  att = avg / degree_log_att(d);
+}
+
 // Per-wave counts of every degree among this wave's nodes -> wcount[wave][bucket] (LDS), and
 // the lane's rank among the wave's nodes of the same degree.  No atomics: deterministic.
 __device__ __forceinline__ int wave_degree_ranks(int d, bool live, int32_t (*wcount)[kDegreeBuckets]) {

@@ -230,8 +230,8 @@ __device__ __forceinline__ int finish_row(const int64_t *__restrict__ edge_index
     combo[beg + cnt] = 0;
     deg += 1;
   }
-  log_amp[i] = logf((float)deg + 1.f);
-  log_att[i] = logf(fmaxf((float)deg, 1.f) + 1.f);
+  log_amp[i] = degree_log_amp(deg);
+  log_att[i] = degree_log_att(deg);
   return deg;
 }
 

@@ -7,14 +7,7 @@ namespace gs {
 // w_eff[d][t][o][0:F] = W_t[o][0:F];  w_eff[d][t][o][F+j] = W_t[o][F+j] + amp(d) W_t[o][5F+j] + att(d) W_t[o][9F+j]
 // Every folded weight is formed in float64 and rounded to float32 ONCE (degree_scalers() below gives the scalers as
 // the float32 values the reference multiplies the activations with).
-
-// amp(d) = log(d + 1) / avg_deg_log, att(d) = avg_deg_log / log(max(d, 1) + 1) as PyG's DegreeScalerAggregation forms
-// them: float32 log (here: the correctly rounded one), float32 division
-__device__ __forceinline__ void degree_scalers(int d, float avg, float &amp, float &att) {
-  const float la = (float)log((double)d + 1.0), lt = (float)log((double)(d > 1 ? d : 1) + 1.0);
-  amp = la / avg;
-  att = avg / lt;
-}
+// (degree_scalers: common.hpp)
 struct FoldLayers {
   const float *w0[GNNSAFT_MAX_FOLD_LAYERS];
   const float *w1[GNNSAFT_MAX_FOLD_LAYERS];

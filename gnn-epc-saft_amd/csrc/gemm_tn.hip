@@ -375,8 +375,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn_postfold(TnFoldArgs a, float *_
       __syncthreads();
     }
     if (agg_part) {  // fold this degree's partial product
-      const float amp = logf((float)deg + 1.f) / avgv;
-      const float att = avgv / logf(fmaxf((float)deg, 1.f) + 1.f);
+      float amp, att;
+      degree_scalers(deg, avgv, amp, att);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         acc_id[r] += acc[r];

@@ -159,7 +159,7 @@ __device__ __forceinline__ double t_sqrt<double>(double v) { return sqrt(v); }
 template <typename T>
 __device__ __forceinline__ T t_log(T v);
 template <>
-__device__ __forceinline__ float t_log<float>(float v) { return logf(v); }
+__device__ __forceinline__ float t_log<float>(float v) { return (float)log((double)v); }   // correctly rounded, as common.hpp's degree scalers
 template <>
 __device__ __forceinline__ double t_log<double>(double v) { return log(v); }
 template <typename T>

@@ -296,3 +296,106 @@ def mini4() -> GraphData:
 
 def to_numpy_state(model: torch.nn.Module) -> Dict[str, np.ndarray]:
     return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Branch-forced evaluation of the oracle.  The network is piecewise smooth: std masks (var <= 1e-5), ReLU gates and the
+# min / max routing are discrete decisions.  On a small batch one can search for a seed on which every evaluation takes
+# them alike; at BASELINE size (1024 graphs: ~1e7 decisions) some always differ.  `forced_forward` evaluates the
+# oracle's own modules ON A GIVEN BRANCH -- the decisions are inputs, read off the HIP tape -- so that the HIP
+# gradients can be compared with the exact (f64) gradients of the very function the HIP forward evaluated, at any size.
+# Checked against the free oracle in tests/test_oracle_cpu.py (decisions taken from the oracle itself: same output,
+# same gradients to 1e-12).  pre_layers = post_layers = 1 (no ReLU inside the towers).
+# ---------------------------------------------------------------------------------------------------------------------
+def branch_of_oracle(model: torch.nn.Module, data, skip: bool, loops: bool):
+    """The branch the (free) oracle takes on ``data``: dict(std=[L], gate=[L], amin=[L], amax=[L], ro=[blocks]) with the
+    routing masks in the ORACLE's edge order (real edges, then self-loops)."""
+    stages, dec = oracle_decisions(model, data, skip)
+    layers = len(model.convs)
+    std, gate = [dec[2 * l] for l in range(layers)], [dec[2 * l + 1] for l in range(layers)]
+    ro = dec[2 * layers:]
+    order, _ = _csr_order(data, loops)
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel())
+    routing = oracle_routing(stages, data, loops)                  # CSR order
+    amin = [routing[2 * l][inv] for l in range(layers)]
+    amax = [routing[2 * l + 1][inv] for l in range(layers)]
+    return dict(std=std, gate=gate, amin=amin, amax=amax, ro=list(ro))
+
+
+def branch_of_tape(pred: torch.Tensor, data, skip: bool, loops: bool):
+    """The branch the taped HIP forward behind ``pred`` took, in the same form."""
+    dec = tape_decisions(pred, skip)
+    layers = pred.grad_fn.tape["desc"].num_layers
+    std, gate = [dec[2 * l] for l in range(layers)], [dec[2 * l + 1] for l in range(layers)]
+    ro = dec[2 * layers:]
+    order, _ = _csr_order(data, loops)
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel())
+    routing = tape_routing(pred)
+    amin = [routing[2 * l][inv] for l in range(layers)]
+    amax = [routing[2 * l + 1][inv] for l in range(layers)]
+    return dict(std=std, gate=gate, amin=amin, amax=amax, ro=list(ro))
+
+
+def branch_differences(a, b) -> Dict[str, int]:
+    """Number of decisions two branches take differently, per kind (+ the total number of decisions)."""
+    out = {}
+    total = 0
+    for key in ("std", "gate", "amin", "amax", "ro"):
+        out[key] = int(sum(int((x.cpu() != y.cpu()).sum()) for x, y in zip(a[key], b[key])))
+        total += sum(x.numel() for x in a[key])
+    out["decisions"] = total
+    return out
+
+
+def forced_forward(model: torch.nn.Module, data, branch) -> torch.Tensor:
+    """The oracle's forward (oracle/pna_torch.py ``OraclePNAPCSAFT.forward``, same modules, same op order) with every
+    discrete decision taken from ``branch`` instead of from the data: differentiable, float32 or float64."""
+    from oracle.pna_torch import add_self_loops, global_add_pool, pna_scale, scatter_mean
+    pp = model.pna_params
+    assert pp.pre_layers == 1 and pp.post_layers == 1 and pp.dropout == 0.0
+    x, edge_index, edge_attr = data.x, data.edge_index, data.edge_attr
+    batch = getattr(data, "batch", None)
+    if pp.self_loops:
+        edge_index, edge_attr = add_self_loops(edge_index, edge_attr, x.size(0))
+    x = model.node_embed(x)
+    edge_emb = model.edge_embed(edge_attr)
+    n = x.size(0)
+    dst = edge_index[1]
+    for l, (conv, bn) in enumerate(zip(model.convs, model.batch_norms)):
+        x_prev = x
+        xr = x.view(n, 1, conv.f_in).repeat(1, 2, 1)
+        msgs = conv.messages(x, edge_index, edge_emb)                     # [E', T, F]
+        mean = scatter_mean(msgs, dst, n)
+        parts = [mean]
+        for key in ("amin", "amax"):                                      # forced routing, ties share evenly (as torch)
+            sel = branch[key][l].view_as(msgs).to(msgs.dtype)
+            bidx = dst.view(-1, 1, 1).expand_as(msgs)
+            cnt = torch.zeros_like(mean).scatter_add_(0, bidx, sel)
+            parts.append(torch.zeros_like(mean).scatter_add_(0, bidx, msgs * sel) / cnt.clamp(min=1))
+        var = scatter_mean(msgs * msgs, dst, n) - mean * mean
+        keep = branch["std"][l].view_as(var)
+        parts.append(torch.where(keep, var.clamp(min=1e-12).sqrt(), torch.zeros_like(var)))
+        agg = torch.cat(parts, dim=-1)
+        z = torch.cat([xr, pna_scale(agg, dst, n, conv.aggr_module.avg_deg_log)], dim=-1)
+        u = torch.cat([net(z[:, t]) for t, net in enumerate(conv.post_nns)], dim=1)
+        x = bn(conv.lin(u)) * branch["gate"][l].to(x.dtype)               # forced ReLU gate
+        if pp.skip_connections:
+            x = x + x_prev
+    g = global_add_pool(x, batch)
+    gates = iter(branch["ro"])
+
+    def run(seq, v):
+        for mod in seq:
+            if isinstance(mod, torch.nn.Sequential):
+                v = run(mod, v)
+            elif isinstance(mod, torch.nn.ReLU):
+                v = v * next(gates).to(v.dtype)
+            elif isinstance(mod, torch.nn.Dropout):
+                assert mod.p == 0.0
+            else:
+                v = mod(v)
+        return v
+
+    return run(model.mlp, g)

@@ -164,6 +164,45 @@ def test_shape_envelope_vs_oracle(cfg, mode):
                 assert int(sd_h[k]) == int(sd_o[k]) == 1
 
 
+ABLATION = [(128, 3, 1, 1, 1, 3, True, True), (64, 6, 1, 1, 1, 5, True, True), (256, 5, 1, 1, 1, 3, True, True)]
+
+
+@pytest.mark.parametrize("cfg", ABLATION, ids=[str(c) for c in ABLATION])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_fold_ablation_against_f64_oracle(cfg, mode):
+    """Which algebraic fold owns how much of the distance to the exact (f64) result?  The same 96-graph batch through
+    (a) the unfolded update (scalers on load, K = 13F: the reference's own formulation of the update), (b) the
+    degree-folded update, (c) degree fold + destination-term fold (what a no-grad forward runs), each judged by the
+    per-element gate per graph against the f64 oracle, next to the f32 oracle.  The folded weights are accumulated in
+    float64 and rounded once (csrc/fold.hpp), so a fold must not cost accuracy: every quantile of (b) and (c) within
+    1.5x of the larger of (a)'s and the f32 oracle's (floor: the 1e-5 gate itself)."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    hidden, depth, pre, post, mlp, num_para, skip, loops = cfg
+    data = make_synthetic_batch(96, 4321 + hidden + depth, num_para=num_para)
+    oracle = oracle_model(hidden, depth, pre, post, mlp, num_para, skip, loops, degree_histogram(data), seed=depth)
+    oracle.train(mode == "train")
+    with torch.no_grad():
+        want32 = copy.deepcopy(oracle)(data)
+        want64 = copy.deepcopy(oracle).double()(data)
+    qs = torch.tensor([0.5, 0.9, 0.99, 1.0], dtype=torch.float64)
+    q32 = torch.quantile(gate_err(want32, want64, per_row=True), qs)
+    rows = {}
+    for name, (fold_deg, fold_dst) in (("unfolded", (False, False)), ("degree fold", (True, False)),
+                                       ("degree + destination fold", (True, True))):
+        hip = hip_twin(copy.deepcopy(oracle))
+        hip.fold_degree_scalers, hip.fold_dst_term = fold_deg, fold_dst
+        with torch.no_grad():
+            out = hip(data.to(DEV)).cpu()
+        assert hip.input_error_flags() == 0
+        rows[name] = torch.quantile(gate_err(out, want64, per_row=True), qs)
+    fmt = lambda q: "[" + ", ".join("%.1e" % v for v in q.tolist()) + "]"
+    print(f"fold ablation H={hidden} L={depth} {mode}: per-graph gate quantiles 50/90/99/100% -- f32 oracle {fmt(q32)}; "
+          + "; ".join(f"{k} {fmt(v)}" for k, v in rows.items()))
+    bar = 1.5 * torch.maximum(torch.maximum(rows["unfolded"], q32), torch.full_like(q32, TOL))
+    for name in ("degree fold", "degree + destination fold"):
+        assert bool((rows[name][:3] <= bar[:3]).all()), (name, fmt(rows[name]), fmt(bar))
+
+
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_nine_layers_take_the_chunked_weight_paths(mode):
     """More layers than one fused launch carries (GNNSAFT_MAX_FOLD_LAYERS = 8): the destination-term fold, the

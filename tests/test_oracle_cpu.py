@@ -133,3 +133,38 @@ def test_pool_and_mape_small_cases():
     assert pooled.shape == (4, 2) and torch.equal(pooled[2], torch.zeros(2, dtype=torch.float64))
     pred, tgt = torch.tensor([[1.0, 2.0]], dtype=torch.float64), torch.tensor([[2.0, 0.0]], dtype=torch.float64)
     assert abs(float(mape(pred, tgt)) - (0.5 + 2.0 / 1.17e-06) / 2) < 1e-6  # |target| clamped at 1.17e-6
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_branch_forced_oracle_equals_the_free_oracle_on_its_own_branch(mode):
+    """helpers.forced_forward (the oracle's modules with the discrete decisions as inputs: what the full-size gradient
+    test compares the HIP backward with) on the branch the free oracle itself takes: same output and same parameter
+    gradients to float64 rounding -- i.e. forcing a branch changes nothing but who takes the decisions.  Forcing ONE
+    other std decision must change the gradient (the test is not vacuous)."""
+    import copy
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    from helpers import branch_differences, branch_of_oracle, forced_forward, oracle_model
+    data = make_synthetic_batch(20, 5, num_para=3)
+    model = oracle_model(64, 2, 1, 1, 1, 3, True, True, degree_histogram(data), seed=2, dtype=torch.float64)
+    model.train(mode == "train")
+    branch = branch_of_oracle(copy.deepcopy(model), data, True, True)
+    assert branch_differences(branch, branch)["std"] == 0
+    target = data.para.view(-1, 3).double()
+
+    def grads(fn):
+        m = copy.deepcopy(model)
+        out = fn(m)
+        mape(out, target).backward()
+        return out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    out_free, g_free = grads(lambda m: m(data))
+    out_forced, g_forced = grads(lambda m: forced_forward(m, data, branch))
+    assert float((out_free - out_forced).abs().max()) <= 1e-12 * float(out_free.abs().max())
+    scale = max(float(g.abs().max()) for g in g_free.values())
+    for k in g_free:
+        assert float((g_free[k] - g_forced[k]).abs().max()) <= 1e-11 * scale, k
+    other = {k: [t.clone() for t in v] for k, v in branch.items()}
+    idx = int(torch.nonzero(other["std"][0].reshape(-1))[0])
+    other["std"][0].view(-1)[idx] = False                       # mask one std entry the oracle keeps
+    _, g_other = grads(lambda m: forced_forward(m, data, other))
+    assert max(float((g_other[k] - g_free[k]).abs().max()) for k in g_free) > 1e-7 * scale
