@@ -164,6 +164,37 @@ def test_shape_envelope_vs_oracle(cfg, mode):
                 assert int(sd_h[k]) == int(sd_o[k]) == 1
 
 
+def test_zero_crossing_case_behind_the_coarse_gate():
+    """The one case of the suite that needs check_population's coarse gate, pinned with its numbers: envelope case
+    (64, 2, 2, 2, 0, 5, no skip, no loops), train mode.  Its worst per-element gate value is ~0.1 for the HIP path
+    against ~0.02 for the f32 oracle -- on an output element whose exact value is ~1e-5 of the output scale, where the
+    HIP path's ABSOLUTE error is no larger than the f32 oracle's worst absolute error.  If this test starts failing,
+    the excess is no longer a zero crossing and the coarse gate must not absorb it."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    hidden, depth, pre, post, mlp, num_para, skip, loops = 64, 2, 2, 2, 0, 5, False, False
+    data = make_synthetic_batch(96, 4321 + hidden + depth, num_para=num_para)
+    oracle = oracle_model(hidden, depth, pre, post, mlp, num_para, skip, loops, degree_histogram(data), seed=depth).train()
+    hip = hip_twin(copy.deepcopy(oracle))
+    with torch.no_grad():
+        out = hip(data.to(DEV)).cpu().double()
+        want32 = copy.deepcopy(oracle)(data).double()
+        want64 = copy.deepcopy(oracle).double()(data)
+    scale = float(want64.abs().max())
+    gate = (out - want64).abs() / want64.abs().clamp(min=1e-6 * scale)
+    worst = int(gate.argmax())
+    b = float(want64.view(-1)[worst])
+    abs_h = float((out - want64).abs().view(-1)[worst]) / scale
+    abs_o_max = float((want32 - want64).abs().max()) / scale
+    print(f"worst element: exact value {b / scale:.2e} of the output scale, HIP gate value {float(gate.view(-1)[worst]):.2e}, "
+          f"HIP absolute error there {abs_h:.2e} of scale; f32 oracle's largest absolute error {abs_o_max:.2e} of scale")
+    if float(gate.max()) > FLIP_BAR:
+        assert abs(b) <= 1e-3 * scale          # the excess sits on an output passing through zero ...
+        assert abs_h <= 1.5 * abs_o_max        # ... and is an ordinary f32 absolute error
+
+
+FLIP_BAR = 5e-3
+
+
 ABLATION = [(128, 3, 1, 1, 1, 3, True, True), (64, 6, 1, 1, 1, 5, True, True), (256, 5, 1, 1, 1, 3, True, True)]
 
 
