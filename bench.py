@@ -13,7 +13,11 @@ metric.  Weak scaling: every rank owns its own G graphs; there is no data-path c
 Rank 0 prints ONE JSON line.
 
 `--config 2` (default) is BASELINE.json configs[1], the configuration the metric is quoted on; the N = 1 line
-also carries a `c3` block (configs[2], beyond the 256 MiB Infinity Cache: the HBM-honest roofline figures).
+also carries a `c3` block (configs[2], beyond the 256 MiB Infinity Cache: the HBM-honest roofline figures), and every
+N > 1 line a `c4` block: BASELINE.json configs[3] -- 8192 graphs PER RANK on the H=256 / L=5 model, forward + loss with
+the loss all-reduce, and a full training step with the 28 MB flat gradient all-reduce timed on its own (single
+collective and segment-overlapped).  Every line carries `input_error_flags` (GNNSAFT_FLAG_* bits raised by any of its
+forwards, incl. BARRIER_TIMEOUT); a non-zero value fails the run.
 `--config 3` runs configs[2] as the headline; `--config 5` is the C5 stand-in of SURVEY.md 8(d) (2 000 synthetic
 graphs, batch 512, default model) where a step is a full TRAINING step.
 """
@@ -247,6 +251,7 @@ def main() -> None:
     ap.add_argument("--train-steps", type=int, default=20, help="extra forward+backward steps timed (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the secondary C3 roofline block of the N = 1 line")
+    ap.add_argument("--no-c4", action="store_true", help="skip the C4 block (8192 graphs per rank, H=256 L=5) of an N > 1 line")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -452,10 +457,19 @@ def main() -> None:
         except Exception as exc:  # noqa: BLE001
             c3_block = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
+    # ---- N > 1: BASELINE.json configs[3] (65 536 graphs = 8 x 8192 on the H=256 / L=5 model): every rank takes part
+    flag_words = {"c2": model.model.input_error_flags()}
+    c4_block = None
+    if world > 1 and args.config == 2 and not args.no_c4:
+        c4_block, flag_words["c4"] = measure_c4(dev, rank, world, stream)
+    if c3_block is not None:
+        flag_words["c3"] = int(c3_block.pop("_flags", 0))
+
     t = torch.tensor([elapsed, elapsed_instr, elapsed_eager], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, elapsed_instr, elapsed_eager = float(t[0]), float(t[1]), float(t[2])
+    flags = reduce_flags(flag_words, dev, world)
 
     if rank == 0:
         total_graphs = cfg["graphs"] * world * args.steps
@@ -489,6 +503,10 @@ def main() -> None:
         }
         if c3_block is not None:
             out["c3"] = c3_block
+        if c4_block is not None:
+            out["c4"] = c4_block
+        out["input_error_flags"] = flags["any"]
+        out["input_error_flags_by_block"] = flags["by_block"]
         if not args.no_cpu_baseline and world == 1:   # timed on rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, wl.data, wl.deg, args.cpu_budget)
@@ -498,6 +516,140 @@ def main() -> None:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if flags["any"]:
+        raise SystemExit(f"bench.py: GNNSAFT_FLAG_* bits raised during the run: {flags} "
+                         "(16 = BARRIER_TIMEOUT of the fused readout: results invalid)")
+
+
+def reduce_flags(words, dev, world):
+    """OR of the per-block flag words over all ranks (bit by bit through a MAX all-reduce: RCCL has no bitwise OR)."""
+    import torch.distributed as dist
+    names = sorted(words)
+    bits = torch.tensor([[(int(words[n]) >> b) & 1 for b in range(8)] for n in names], dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.all_reduce(bits, op=dist.ReduceOp.MAX)
+    by_block = {n: int(sum(int(v) << b for b, v in enumerate(row))) for n, row in zip(names, bits.tolist())}
+    total = 0
+    for v in by_block.values():
+        total |= v
+    return {"any": total, "by_block": by_block}
+
+
+def measure_c4(dev, rank, world, stream, steps: int = 10, warmup: int = 3, train_steps: int = 5):
+    """BASELINE.json configs[3] on `world` ranks: 8192 synthetic graphs PER RANK (65 536 at 8 ranks), H=256 / L=5 model.
+    (a) forward + MAPE loss with the [sum(ape), count] all-reduce: whole-job graphs/s from the max-over-ranks time of
+    `steps` eager steps; (b) the full training step (forward with tape, backward, gradient exchange, fused AdamW,
+    scheduler) in both exchange modes the loop offers -- ONE flat all-reduce of the whole gradient buffer (28 MB), and
+    the segment-wise exchange overlapped with the backward -- with the collective itself bracketed by HIP events on the
+    compute stream: `allreduce_ms` (single collective: the stream waits for RCCL between the two events) resp.
+    `exposed_exchange_ms` (overlapped: from the end of the backward to the last segment's arrival).  Replaces what
+    Lightning DDP does for the reference (train/train.py:142-156, sync_dist at models.py:195-201)."""
+    import torch.distributed as dist
+
+    from gnn_epc_saft_amd import parallel
+    from gnn_epc_saft_amd.train.loop import broadcast_training_state
+    wl = Workload(CONFIGS[3], dev, rank, 3)
+    model, ddev = wl.model, wl.ddev
+
+    def sync():
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def max_over_ranks(seconds):
+        tt = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt[0])
+
+    # ---- (a) forward + loss
+    with torch.no_grad(), torch.cuda.stream(stream):
+        pend = []
+        for _ in range(warmup):
+            pend.append(parallel.global_mape_async(model.training_step_parts(ddev)))
+        loss = pend[-1].result()
+        sync()
+        t0 = time.perf_counter()
+        pend = []
+        for _ in range(steps):
+            pend.append(parallel.global_mape_async(model.training_step_parts(ddev)))
+        for h in pend:
+            loss = h.result()
+        sync()
+        fwd = max_over_ranks(time.perf_counter() - t0)
+    block = {
+        "workload": wl.describe() + f", x {world} ranks = {wl.cfg['graphs'] * world} graphs per step (BASELINE.json "
+                                    "configs[3]); per-rank BatchNorm statistics, as the reference (no SyncBatchNorm)",
+        "forward_loss": {"steps": steps, "warmup": warmup, "ms_per_step": fwd / steps * 1e3,
+                         "graphs_per_s": wl.cfg["graphs"] * world * steps / fwd, "global_mape": float(loss),
+                         "exchange": "all-reduce(SUM) of [sum(ape), count] per step, asynchronous"},
+    }
+
+    # ---- (b) training step, both exchange modes
+    conf = model.configure_optimizers()
+    opt, sched = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    broadcast_training_state(model, opt, sched, 0)
+    grad_bytes = int(opt._total) * 4
+    exchange = parallel.OverlappedGradientExchange(model.model, dev)
+
+    def step_single(ev):
+        opt.zero_grad(set_to_none=True)
+        model.training_step(ddev).backward()
+        flat = opt._flat_grad()                       # gnnsaft_backward's own buffer: zero copy
+        ev[0].record()
+        scale = parallel.allreduce_flat_sum(flat)     # ONE collective over the whole gradient
+        ev[1].record()
+        opt.use_reduced_gradient(flat, scale)
+        opt.step()
+        sched.step()
+
+    def step_overlap(ev):
+        opt.zero_grad(set_to_none=True)
+        model.training_step(ddev).backward()          # records an event per finished gradient segment
+        flat = parallel.common_gradient_buffer(opt._params)
+        ev[0].record()                                # end of the backward on the compute stream
+        opt.use_reduced_gradient(flat, exchange.launch(flat))
+        exchange.wait()                               # compute stream waits for the exchange stream
+        ev[1].record()
+        opt.step()
+        sched.step()
+
+    train = {"gradient_bytes": grad_bytes}
+    try:
+        for name, fn in (("single_collective", step_single), ("segment_overlapped", step_overlap)):
+            with torch.cuda.stream(stream):
+                scratch = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                for _ in range(2):
+                    fn(scratch)
+                sync()
+                pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                         for _ in range(train_steps)]
+                t0 = time.perf_counter()
+                for ev in pairs:
+                    fn(ev)
+                sync()
+                el = max_over_ranks(time.perf_counter() - t0)
+            ex_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
+            ex_ms = max_over_ranks(ex_ms)
+            entry = {"steps": train_steps, "ms_per_step": el / train_steps * 1e3,
+                     "graphs_per_s": wl.cfg["graphs"] * world * train_steps / el}
+            if name == "single_collective":
+                entry["allreduce_ms"] = ex_ms
+                entry["allreduce_bus_gb_per_s"] = 2.0 * (world - 1) / world * grad_bytes / (ex_ms * 1e-3) / 1e9
+                entry["how"] = ("HIP events on the compute stream around dist.all_reduce(flat, SUM): the stream waits "
+                                "for the collective between them (median over the steps, max over ranks)")
+            else:
+                entry["exposed_exchange_ms"] = ex_ms
+                entry["segments"] = len(exchange.segments)
+                entry["how"] = ("readout / layer L-1..0 / embedding segments all-reduced on a second stream behind "
+                                "gnnsaft_backward's per-segment events; events from the end of the backward to the "
+                                "arrival of the last segment (what the overlap leaves exposed)")
+            train[name] = entry
+    finally:
+        exchange.close()
+    block["train_step"] = train
+    flags = model.model.input_error_flags()
+    del wl, model, ddev, opt, conf
+    torch.cuda.empty_cache()
+    return (block if rank == 0 else None), flags
 
 
 def measure_c3(dev, stream, event_overhead_ms, steps: int = 10, warmup: int = 3):
@@ -521,7 +673,7 @@ def measure_c3(dev, stream, event_overhead_ms, steps: int = 10, warmup: int = 3)
     out = {"workload": wl.describe() + ", train-mode BatchNorm forward + MAPE loss, eager", "steps": steps,
            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "graphs_per_s": wl.cfg["graphs"] * steps / elapsed,
            "nodes": wl.n, "edges_with_self_loops": wl.e_prime, "final_loss": float(parts[0]),
-           "roofline": roof, "roofline_gemm": gemm}
+           "roofline": roof, "roofline_gemm": gemm, "_flags": wl.model.model.input_error_flags()}
     del wl
     torch.cuda.empty_cache()
     return out
@@ -592,7 +744,7 @@ def bench_training_loop(args, dev, rank: int, world: int) -> None:
         elapsed, total = float(tm[0]), float(ts[0])
     else:
         total = float(seen[0])
-    flags = lit.model.input_error_flags()
+    flags = reduce_flags({"c5": lit.model.input_error_flags()}, dev, world)["any"]
     if rank == 0:
         print(json.dumps({
             "metric": "molecular graphs/sec (training step: forward+loss+backward+optimizer)",
@@ -611,6 +763,8 @@ def bench_training_loop(args, dev, rank: int, world: int) -> None:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if flags:
+        raise SystemExit(f"bench.py: GNNSAFT_FLAG_* bits {flags:#x} raised during the run")
 
 
 if __name__ == "__main__":

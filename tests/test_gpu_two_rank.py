@@ -102,7 +102,7 @@ def test_bench_two_rank_rehearsal_prints_one_whole_job_line(config):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
            "--warmup", "2", "--config", str(config), "--train-steps", "2", "--no-cpu-baseline", "--no-c3"]
-    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]          # rank 0 alone prints
@@ -112,5 +112,17 @@ def test_bench_two_rank_rehearsal_prints_one_whole_job_line(config):
     per_step = 512 if config == 5 else 1024          # graphs per rank and step (C5: the last batch of a rank's epoch
     ratio = d["value"] * d["ms_per_step"] * 1e-3 / (2 * per_step)     # is short: 1000 graphs = 512 + 488)
     assert (0.9 < ratio <= 1.001) if config == 5 else abs(ratio - 1.0) < 0.02   # whole-job graphs / max-rank time
+    assert d["input_error_flags"] == 0                # every line carries the flag word; non-zero fails the run
     if config == 2:
         assert "error" not in (d.get("train_step") or {}), d.get("train_step")
+        assert d["input_error_flags_by_block"] == {"c2": 0, "c4": 0}
+        # BASELINE.json configs[3]: 8192 graphs per rank on the H=256 / L=5 model, forward + loss with the loss
+        # all-reduce, and the training step with the flat gradient all-reduce timed on its own, in both exchange modes
+        c4 = d["c4"]
+        assert "8192 synthetic molecular graphs per GPU" in c4["workload"] and "H=256 L=5" in c4["workload"]
+        fl = c4["forward_loss"]
+        assert abs(fl["graphs_per_s"] * fl["ms_per_step"] * 1e-3 / (2 * 8192) - 1.0) < 0.02 and fl["global_mape"] > 0
+        tr = c4["train_step"]
+        assert tr["gradient_bytes"] > 28_000_000           # 7.05 M parameters (+ 64-float padding) in one flat buffer
+        assert tr["single_collective"]["allreduce_ms"] > 0 and tr["single_collective"]["ms_per_step"] > 0
+        assert tr["segment_overlapped"]["exposed_exchange_ms"] >= 0 and tr["segment_overlapped"]["segments"] == 7
