@@ -9,58 +9,23 @@
 // With more than kBnFusedGroups partials that redundant fold costs more L2 traffic than the pass over y itself
 // (every workgroup re-reads all partials of its slab), so k_bn_combine first folds them into <= 64 segment sums
 // (f64, same pivot) in its own small launch and the apply workgroups fold only those.
-#include "common.hpp"
+#include "bn_fold.hpp"
 
 namespace gs {
 
-constexpr int kBnCols = 32;
-constexpr int kBnGroupLanes = 8;  // 256 threads = 8 partial-lanes x 32 columns
-constexpr int kBnFusedGroups = 64;  // up to this many partials: single launch
-constexpr int kBnMaxSegments = 64;
-constexpr int kBnSegGroups = 64;    // partials folded per segment (8 per thread, one round of loads)
-
-// (S1, S2) of one thread's share of the partials [g_beg, g_end) of column colc around `pivot`
-__device__ __forceinline__ void bn_fold_partials(const float *__restrict__ stats, int64_t g_beg, int64_t g_end,
-                                                 int64_t rows, int ch, int colc, int gl, double pivot, double &s1,
-                                                 double &s2) {
-  constexpr int kUnroll = 8;  // independent loads in flight per thread
-  for (int64_t g0 = g_beg + gl; g0 < g_end; g0 += kBnGroupLanes * kUnroll) {
-    float gm[kUnroll], g2[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      int64_t g = g0 + (int64_t)u * kBnGroupLanes;
-      g = g < g_end ? g : g_end - 1;
-      gm[u] = stats[(g * 2 + 0) * ch + colc];
-      g2[u] = stats[(g * 2 + 1) * ch + colc];
-    }
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int64_t g = g0 + (int64_t)u * kBnGroupLanes;
-      if (g < g_end) {
-        const int64_t left = rows - g * kBnRowsPerGroup;
-        const double gn = (double)(left < kBnRowsPerGroup ? left : kBnRowsPerGroup);
-        const double m = (double)gm[u] - pivot;
-        s1 += gn * m;
-        s2 += (double)g2[u] + gn * m * m;
-      }
-    }
-  }
-}
-
 // segment sums: seg[(s*2 + {0,1}) * ch + col] = (S1, S2) of partials [s*kBnSegGroups, (s+1)*kBnSegGroups)
 __global__ __launch_bounds__(256) void k_bn_combine(const float *__restrict__ stats, int64_t rows, int ch,
-                                                    double *__restrict__ seg) {
+                                                    double *__restrict__ seg, int64_t per_seg) {
   __shared__ double s_a[kBnGroupLanes][kBnCols], s_b[kBnGroupLanes][kBnCols];
   const int cl = threadIdx.x & (kBnCols - 1), gl = threadIdx.x / kBnCols;
   const int col = blockIdx.x * kBnCols + cl;
   const int colc = col < ch ? col : ch - 1;
   const int64_t groups = (rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup;
-  const int64_t per_seg = (groups + gridDim.y - 1) / gridDim.y;
   const int64_t g_beg = (int64_t)blockIdx.y * per_seg;
   int64_t g_end = g_beg + per_seg;
   if (g_end > groups) g_end = groups;
   double s1 = 0.0, s2 = 0.0;
-  if (g_beg < g_end) bn_fold_partials(stats, g_beg, g_end, rows, ch, colc, gl, (double)stats[colc], s1, s2);
+  if (g_beg < g_end) bn_fold_partials(stats, g_beg, g_end, rows, ch, colc, gl, s1, s2);
   s_a[gl][cl] = s1;
   s_b[gl][cl] = s2;
   __syncthreads();
@@ -94,12 +59,7 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
 
   // ---- phase 1: batch statistics of this slab's columns
   const int64_t groups = (rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup;
-  // Division-free combine around a pivot K = mean of group 0 (any value near the column mean):
-  //   S1 = sum n_g (mean_g - K),  S2 = sum (M2_g + n_g (mean_g - K)^2)   in f64
-  //   mean = K + S1/N,  M2 = S2 - N (S1/N)^2
-  // The differences are of the size of the between-group scatter, so the final subtraction is benign even
-  // for columns with |mean| >> std (the case Chan's pairwise update protects against).
-  const double pivot = (double)stats[colc];
+  // (S1, S2) in f64: bn_fold.hpp
   double s1 = 0.0, s2 = 0.0;
   if (seg != nullptr) {
     for (int sg = gl; sg < num_seg; sg += kBnGroupLanes) {
@@ -107,7 +67,7 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
       s2 += seg[((int64_t)sg * 2 + 1) * ch + colc];
     }
   } else {
-    bn_fold_partials(stats, 0, groups, rows, ch, colc, gl, pivot, s1, s2);
+    bn_fold_partials(stats, 0, groups, rows, ch, colc, gl, s1, s2);
   }
   s_mean[gl][cl] = s1;
   s_m2[gl][cl] = s2;
@@ -117,26 +77,18 @@ __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict_
       s1 += s_mean[o][cl];
       s2 += s_m2[o][cl];
     }
-    const double n = (double)rows;
-    const double dmean = s1 / n;
-    const double mean = pivot + dmean;
-    double m2 = s2 - n * dmean * dmean;
-    m2 = m2 > 0.0 ? m2 : 0.0;
-    const float mean_f = (float)mean;
-    const float var_f = (float)(m2 / n);  // biased: used for normalisation
-    const float rstd = 1.f / sqrtf(var_f + eps);
-    const float sc = rstd * (gamma != nullptr ? gamma[colc] : 1.f);
-    s_scale[cl] = sc;
-    s_shift[cl] = (beta != nullptr ? beta[colc] : 0.f) - mean_f * sc;
+    const BnColumn bc = bn_finish_column(s1, s2, rows, gamma != nullptr ? gamma[colc] : 1.f,
+                                         beta != nullptr ? beta[colc] : 0.f, eps);
+    s_scale[cl] = bc.scale;
+    s_shift[cl] = bc.shift;
     if (blockIdx.y == 0 && col_ok && save_stat != nullptr) {
-      save_stat[col] = mean_f;
-      save_stat[ch + col] = rstd;
+      save_stat[col] = bc.mean;
+      save_stat[ch + col] = bc.rstd;
     }
     if (blockIdx.y == 0 && col_ok) {
       if (running_mean != nullptr) {
-        const float unbiased = (float)(n > 1.0 ? m2 / (n - 1.0) : m2);
-        running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * mean_f;
-        running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
+        running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * bc.mean;
+        running_var[col] = (1.f - momentum) * running_var[col] + momentum * bc.unbiased;
       }
       if (nbt != nullptr && col == 0) nbt[0] += 1;
     }
@@ -243,10 +195,10 @@ extern "C" int gnnsaft_bn_train_apply(const float *stats, const float *y, int64_
                    (reinterpret_cast<uintptr_t>(scratch) & 7) == 0,
                GNNSAFT_ERR_WORKSPACE);
     seg = static_cast<double *>(scratch);
-    num_seg = (int)gs_ceil_div(groups, (int64_t)gs::kBnSegGroups);
-    if (num_seg > gs::kBnMaxSegments) num_seg = gs::kBnMaxSegments;
+    int64_t per_seg = 0;
+    gs::bn_segments(groups, &num_seg, &per_seg);
     hipLaunchKernelGGL(gs::k_bn_combine, dim3((unsigned)slabs, (unsigned)num_seg), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), stats, num_rows, channels, seg);
+                       static_cast<hipStream_t>(stream), stats, num_rows, channels, seg, per_seg);
     GS_CHECK_LAUNCH();
   }
   // ~1024 workgroups in total, at least 64 rows each

@@ -74,6 +74,24 @@ struct GemmBatchEntry {
 constexpr int kMaxGemmBatch = 8;
 constexpr int kBnRowsPerGroup = 64;  // rows covered by one wave's accumulator tile
 
+// In-GEMM BatchNorm statistics tail (gemm.hip, STATS epilogue; arithmetic: bn_fold.hpp): after a workgroup has written its partials it takes a ticket of
+// its segment; the LAST arriver folds the segment (level 1), takes a ticket of its column block; the last of those
+// folds the segment sums and writes scale / shift / saved (mean, rstd) / running statistics (level 2).
+struct BnTail {
+  int enabled;               // 0: the STATS epilogue only leaves partials (separate combine / apply launches)
+  int num_seg;
+  int64_t per_seg;           // groups per segment (multiple of 4)
+  int64_t rows;              // N
+  double *seg;               // [num_seg][2][ch]
+  int32_t *counters;         // [num_seg * col_blocks] segment tickets, then [col_blocks] final tickets; zero at launch
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+  int64_t *nbt;
+  float momentum, eps;
+  float *scale, *shift;      // [ch] out: y * scale + shift
+  float *save_stat;          // [2][ch] (mean, rstd) for the backward, or null
+};
+
 struct LinearEpilogue {
   const float *scale = nullptr;   // eval-mode BN folded
   const float *shift = nullptr;
@@ -86,6 +104,7 @@ struct LinearEpilogue {
   // epilogue forms scale = gamma / sqrt(var + eps), shift = beta - mean scale itself (no finalize launch)
   const float *bn_mean = nullptr, *bn_var = nullptr;
   float bn_eps = 0.f;
+  const BnTail *tail = nullptr;   // with `stats`: close the batch statistics inside the GEMM (scale / shift out)
 };
 
 struct GemmBatch {
@@ -102,6 +121,7 @@ struct EpiArgs {
   int residual_is_mask;  // 1: out = residual > 0 ? v : 0 (ReLU backward) instead of v + residual
   const float *bn_mean, *bn_var;   // eval-mode BatchNorm parameters (scale / shift then hold gamma / beta), or null
   float bn_eps;
+  BnTail tail;
 };
 
 __device__ __forceinline__ f32x4 gs_relu4(f32x4 v) {
@@ -119,6 +139,13 @@ int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const Ge
 int launch_linear_concat2(const float *a0, int64_t lda0, int k0, const float *a1, int64_t lda1, int k1,
                           const GemmBatchEntry &entry, int64_t ldw, int64_t ldo, int64_t m, int n_out,
                           const LinearEpilogue &epi, hipStream_t stream);
+
+// out = relu(y * scale + shift) (+ xprev) as A operand, W^T as B; workgroups of column block 0 also write that A
+// to `xout` (or null): train-mode BatchNorm + ReLU + residual applied while the next GEMM stages its operand
+constexpr int kBnTailCounterInts = 1024;   // >= (kBnMaxSegments + 1) * column blocks of the statistics tail
+int launch_linear_bnres(const float *y, const float *xprev, const float *scale, const float *shift, float *xout,
+                        int nbatch, const GemmBatchEntry *entries, int64_t ldw, int64_t ldo, int64_t m, int n_out, int k,
+                        hipStream_t stream);
 
 int launch_pna_update(const float *x, const float *agg, const float *log_amp, const float *log_att,
                       const float *avg_deg_log, int64_t n, int hidden, const GemmBatchEntry *entries /*2*/,
@@ -284,6 +311,9 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
                             int32_t *err_flag, hipStream_t st, int32_t *zero2_ptr = nullptr, int zero2_count = 0,
                             const struct EdgeTableLayers *tables = nullptr /* fold.hpp */, int32_t table_layers = 0,
                             float *cenc = nullptr, float *rtab = nullptr);
+int launch_add_pool_bn(const float *y, const float *xprev, const float *scale, const float *shift, float *xout,
+                       const int32_t *graph_ptr, int64_t num_graphs, int64_t num_nodes, int hidden, float *out,
+                       hipStream_t st);
 void csr_zero_region(void *workspace, int64_t num_nodes, int32_t **ptr, int64_t *count);
 int launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_t num_nodes, int64_t num_edges,
                      int32_t num_bond_cols, const int32_t *bond_dims_host, int32_t self_loops, int32_t *rowptr,

@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void k_forward_prologue(PrologueArgs a) {
   } else {
     const int64_t i = (int64_t)(b - a.end_combo) * 256 + threadIdx.x;
     if (i < a.zero_count) a.zero_ptr[i] = 0;
-    if (b == a.end_combo && (int)threadIdx.x < a.zero2_count) a.zero2_ptr[threadIdx.x] = 0;
+    if (b == a.end_combo)
+      for (int t = threadIdx.x; t < a.zero2_count; t += 256) a.zero2_ptr[t] = 0;
   }
 }
 
@@ -302,6 +303,50 @@ __global__ __launch_bounds__(256) void k_add_pool(const float *__restrict__ x, c
   gs_st4(out + g * h + c, acc);
 }
 
+// global_add_pool of x = relu(y * scale + shift) (+ xprev): the last layer's train-mode BatchNorm + ReLU + residual
+// (models.py:128-131) applied while pooling (models.py:133) -- same arithmetic and summation order as
+// k_bn_train_apply followed by k_add_pool, one pass over y instead of a write and a re-read of x_L.  `xout` (tape)
+// receives x_L.
+__global__ __launch_bounds__(256) void k_add_pool_bn(const float *__restrict__ y, const float *__restrict__ xprev,
+                                                     const float *__restrict__ scale, const float *__restrict__ shift,
+                                                     float *__restrict__ xout, const int32_t *__restrict__ ptr,
+                                                     int64_t graphs, int64_t nodes, int h, float *__restrict__ out,
+                                                     RowSplit rs) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t g;
+  int lane_in_row;
+  gs_split(rs, slot, g, lane_in_row);
+  if (g >= graphs) return;
+  const int c = lane_in_row * 4;
+  int64_t beg = ptr[g], end = ptr[g + 1];
+  beg = beg < 0 ? 0 : (beg > nodes ? nodes : beg);
+  end = end < beg ? beg : (end > nodes ? nodes : end);
+  const f32x4 sc = gs_ld4(scale + c), sh = gs_ld4(shift + c);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc = zero;
+  int64_t r = beg;
+  for (; r + 4 <= end; r += 4) {
+    f32x4 v[4], q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = gs_ld4(y + (r + u) * h + c);
+      q[u] = xprev != nullptr ? gs_ld4(xprev + (r + u) * h + c) : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x4 o = gs_relu4(v[u] * sc + sh) + q[u];
+      if (xout != nullptr) gs_st4(xout + (r + u) * h + c, o);
+      acc += o;
+    }
+  }
+  for (; r < end; ++r) {
+    const f32x4 o = gs_relu4(gs_ld4(y + r * h + c) * sc + sh) + (xprev != nullptr ? gs_ld4(xprev + r * h + c) : zero);
+    if (xout != nullptr) gs_st4(xout + r * h + c, o);
+    acc += o;
+  }
+  gs_st4(out + g * h + c, acc);
+}
+
 __global__ __launch_bounds__(1024) void k_mape(const float *__restrict__ pred, const float *__restrict__ target,
                                                int64_t n, float *__restrict__ out3) {
   __shared__ float part[1024 / 64];
@@ -345,7 +390,7 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
                             int32_t *err_flag, hipStream_t st, int32_t *zero2_ptr, int zero2_count,
                             const EdgeTableLayers *tables, int32_t table_layers, float *cenc, float *rtab) {
   GS_REQUIRE(x_idx && x_out && cemb && num_rows >= 1, GNNSAFT_ERR_NULL);
-  GS_REQUIRE(zero2_count >= 0 && zero2_count <= 256, GNNSAFT_ERR_SHAPE);
+  GS_REQUIRE(zero2_count >= 0 && zero2_count <= 65536, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(hidden >= 4 && (hidden % 4) == 0, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(fold_layers >= 0 && fold_layers <= GNNSAFT_MAX_FOLD_LAYERS, GNNSAFT_ERR_SHAPE);
   PrologueArgs a;
@@ -410,6 +455,19 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
     hipLaunchKernelGGL(k_forward_prologue<9>, grid, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL(k_forward_prologue<GNNSAFT_MAX_TABLES>, grid, dim3(256), 0, st, a);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+int launch_add_pool_bn(const float *y, const float *xprev, const float *scale, const float *shift, float *xout,
+                       const int32_t *graph_ptr, int64_t num_graphs, int64_t num_nodes, int hidden, float *out,
+                       hipStream_t st) {
+  GS_REQUIRE(y && scale && shift && graph_ptr && out, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 4 && (hidden % 4) == 0 && num_graphs >= 0, GNNSAFT_ERR_SHAPE);
+  if (num_graphs == 0) return GNNSAFT_OK;
+  const int64_t threads = num_graphs * (hidden / 4);
+  hipLaunchKernelGGL(k_add_pool_bn, dim3((unsigned)gs_ceil_div(threads, 256)), dim3(256), 0, st, y, xprev, scale, shift,
+                     xout, graph_ptr, num_graphs, num_nodes, hidden, out, gs_row_split(hidden / 4));
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }

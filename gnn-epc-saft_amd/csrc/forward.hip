@@ -16,6 +16,7 @@
 //            Linear(H,H/2) w,b, BN x5, Linear(H/2,H/4) w,b, BN x5, Linear(H/4,P) w,b
 #include <vector>
 
+#include "bn_fold.hpp"
 #include "common.hpp"
 #include "fold.hpp"
 #include "plan.hpp"
@@ -77,12 +78,39 @@ struct ProfScope {
 
 // Linear -> BatchNorm -> ReLU (-> + residual): eval folds BN into the GEMM epilogue,
 // train writes y with (mean, M2) partials, finalises the statistics and applies them.
+// `defer_apply` (train mode): the batch statistics are closed inside the GEMM (BnTail: scale / shift land in
+// ws + p.scale / p.shift, running statistics updated) and NOTHING is applied here -- the consumer of the layer's
+// output applies relu(y scale + shift) (+ residual) while it loads y (launch_linear_bnres, launch_add_pool_bn).
 static int linear_bn_relu(const float *a, int64_t lda, const float *w, const float *b, int64_t rows, int n_out, int k,
                           const BnPtrs &bn, const gnnsaft_model_desc *d, char *ws, const Plan &p, float *y_tmp,
                           const float *residual, float *out, hipStream_t st, gnnsaft_profile *prof = nullptr,
-                          float *save_stat = nullptr) {
+                          float *save_stat = nullptr, bool defer_apply = false) {
   float *stats = reinterpret_cast<float *>(ws + p.stats);
   GemmBatchEntry ent{w, b, nullptr, 0};
+  if (d->training && defer_apply) {
+    GS_REQUIRE(rows >= 2, GNNSAFT_ERR_SHAPE);
+    ent.out = y_tmp;
+    BnTail tl{};
+    bn_segments(gs_ceil_div(rows, (int64_t)kBnRowsPerGroup), &tl.num_seg, &tl.per_seg);
+    tl.rows = rows;
+    tl.seg = reinterpret_cast<double *>(ws + p.bn_tail_seg);
+    tl.counters = reinterpret_cast<int32_t *>(ws + p.rd_sync) + kRdSyncInts;
+    tl.gamma = bn.gamma;
+    tl.beta = bn.beta;
+    tl.running_mean = bn.rmean;
+    tl.running_var = bn.rvar;
+    tl.nbt = bn.nbt;
+    tl.momentum = d->bn_momentum;
+    tl.eps = d->bn_eps;
+    tl.scale = reinterpret_cast<float *>(ws + p.scale);
+    tl.shift = reinterpret_cast<float *>(ws + p.shift);
+    tl.save_stat = save_stat;
+    LinearEpilogue epi;
+    epi.stats = stats;
+    epi.tail = &tl;
+    ProfScope ps(prof, GNNSAFT_PROF_LIN, st);
+    return launch_linear(a, lda, 0, 1, &ent, k, n_out, rows, n_out, k, epi, st);
+  }
   if (d->training) {
     GS_REQUIRE(rows >= 2, GNNSAFT_ERR_SHAPE);
     ent.out = y_tmp;
@@ -122,17 +150,33 @@ static int linear_bn_relu(const float *a, int64_t lda, const float *w, const flo
   return GNNSAFT_OK;
 }
 
-static int node_terms(const float *x, int64_t n, int h, const float *w0, const float *w1, float *pq, hipStream_t st) {
+// The node state a layer reads: materialised (`x`), or still pending as the previous layer's pre-activation `y`
+// with its BatchNorm (scale, shift) and residual -- then the message GEMM applies it on load and writes it to `xdst`.
+struct NodeState {
+  const float *x = nullptr;
+  const float *y = nullptr, *xres = nullptr, *scale = nullptr, *shift = nullptr;
+  float *xdst = nullptr;
+};
+
+static int node_terms(const NodeState &ns, int64_t n, int h, const float *w0, const float *w1, float *pq,
+                      hipStream_t st) {
   GemmBatchEntry e[4] = {{w0, nullptr, pq, 0}, {w1, nullptr, pq + h, 0}, {w0 + h, nullptr, pq + 2 * h, 0},
                          {w1 + h, nullptr, pq + 3 * h, 0}};
+  if (ns.y != nullptr)
+    return launch_linear_bnres(ns.y, ns.xres, ns.scale, ns.shift, ns.xdst, 4, e, 3 * (int64_t)h, 4 * (int64_t)h, n, h, h,
+                               st);
   LinearEpilogue epi;
-  return launch_linear(x, h, 0, 4, e, 3 * (int64_t)h, 4 * (int64_t)h, n, h, h, epi, st);
+  return launch_linear(ns.x, h, 0, 4, e, 3 * (int64_t)h, 4 * (int64_t)h, n, h, h, epi, st);
 }
 
-static int src_terms(const float *x, int64_t n, int h, const float *w0, const float *w1, float *q, hipStream_t st) {
+static int src_terms(const NodeState &ns, int64_t n, int h, const float *w0, const float *w1, float *q,
+                     hipStream_t st) {
   GemmBatchEntry e[2] = {{w0 + h, nullptr, q, 0}, {w1 + h, nullptr, q + h, 0}};
+  if (ns.y != nullptr)
+    return launch_linear_bnres(ns.y, ns.xres, ns.scale, ns.shift, ns.xdst, 2, e, 3 * (int64_t)h, 2 * (int64_t)h, n, h, h,
+                               st);
   LinearEpilogue epi;
-  return launch_linear(x, h, 0, 2, e, 3 * (int64_t)h, 2 * (int64_t)h, n, h, h, epi, st);
+  return launch_linear(ns.x, h, 0, 2, e, 3 * (int64_t)h, 2 * (int64_t)h, n, h, h, epi, st);
 }
 
 static int edge_table(const float *cemb, int64_t combos, int h, const float *we, const float *be, const float *w0,
@@ -195,14 +239,18 @@ extern "C" int gnnsaft_pna_node_terms(const float *x, int64_t num_nodes, int32_t
                                       const float *w_pre1, float *pq, gnnsaft_stream_t stream) {
   GS_REQUIRE(x && w_pre0 && w_pre1 && pq, GNNSAFT_ERR_NULL);
   GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
-  return node_terms(x, num_nodes, hidden, w_pre0, w_pre1, pq, static_cast<hipStream_t>(stream));
+  NodeState ns;
+  ns.x = x;
+  return node_terms(ns, num_nodes, hidden, w_pre0, w_pre1, pq, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gnnsaft_pna_src_terms(const float *x, int64_t num_nodes, int32_t hidden, const float *w_pre0,
                                      const float *w_pre1, float *q, gnnsaft_stream_t stream) {
   GS_REQUIRE(x && w_pre0 && w_pre1 && q, GNNSAFT_ERR_NULL);
   GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
-  return src_terms(x, num_nodes, hidden, w_pre0, w_pre1, q, static_cast<hipStream_t>(stream));
+  NodeState ns;
+  ns.x = x;
+  return src_terms(ns, num_nodes, hidden, w_pre0, w_pre1, q, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int gnnsaft_pna_edge_table(const float *combo_emb, int32_t num_combos, int32_t hidden,
@@ -486,7 +534,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     GS_TRY(launch_forward_prologue(x_idx, n, d->num_atom_cols, atom_tab, d->atom_dims, d->num_bond_cols, bond_tab,
                                    d->bond_dims, h, F(p.x0), F(p.cemb), zero_ptr, zero_count,
                                    dst_in_prologue ? d->num_layers : 0, w0, w1, p0, p1, D(p.gfold), err_flag, st,
-                                   I(p.rd_sync), kRdSyncInts, &et, tables_in_prologue ? d->num_layers : 0, F(p.cenc),
+                                   I(p.rd_sync), kRdSyncInts + kBnTailCounterInts, &et, tables_in_prologue ? d->num_layers : 0, F(p.cenc),
                                    F(p.rtab)));
   }
   hipStream_t sa = st;
@@ -575,7 +623,11 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
 
   const bool tape = d->save_tape != 0;
   float *xc = F(p.x0), *xn = tape ? F(p.x0) + p.sx : F(p.x1);
+  // train-mode node BatchNorm without launches of its own (linear_bn_relu / NodeState)
+  const bool bn_deferred = d->training && !d->unfused_bn_apply && h <= 256 && (h % 32) == 0;
+  NodeState state;
   for (int l = 0; l < d->num_layers; ++l) {
+    if (state.y == nullptr) state.x = xc;   // (otherwise x_l is still pending: formed by this layer's message GEMM)
     const LayerW &w = lw[l];
     float *pq_l = F(p.pq) + l * p.spq, *agg_l = F(p.agg) + l * p.sagg, *u_l = F(p.u0) + l * p.su;
     float *y_l = F(p.y) + l * p.sy;
@@ -593,9 +645,11 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     {
       ProfScope ps(prof, GNNSAFT_PROF_NODE_TERMS, st);
       if (fold_dst)
-        GS_TRY(src_terms(xc, n, h, wpre[0][0], wpre[1][0], pq_l, st));
+        GS_TRY(src_terms(state, n, h, wpre[0][0], wpre[1][0], pq_l, st));
       else
-        GS_TRY(node_terms(xc, n, h, wpre[0][0], wpre[1][0], pq_l, st));
+        GS_TRY(node_terms(state, n, h, wpre[0][0], wpre[1][0], pq_l, st));
+      state = NodeState{};   // x_l (= xc) is in memory now
+      state.x = xc;
     }
     GS_TRY(join_structure());
     const float *msgs = nullptr;
@@ -655,7 +709,15 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     }
     // lin -> BatchNorm -> ReLU -> (+ x)
     GS_TRY(linear_bn_relu(ua, h, wlin, blin, n, h, h, bn, d, ws, p, y_l, d->skip_connections ? xc : nullptr, xn, st,
-                          prof, F(p.bnstat) + (int64_t)l * 2 * h));
+                          prof, F(p.bnstat) + (int64_t)l * 2 * h, bn_deferred));
+    if (bn_deferred) {   // x_{l+1} = relu(y_l scale + shift) (+ x_l): formed by whoever reads it next
+      state = NodeState{};
+      state.y = y_l;
+      state.xres = d->skip_connections ? xc : nullptr;
+      state.scale = F(p.scale);
+      state.shift = F(p.shift);
+      state.xdst = xn;
+    }
     if (tape) {
       xc = xn;
       xn = xn + p.sx;
@@ -666,10 +728,18 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     }
   }
 
+  // global_add_pool of the final node state; a pending BatchNorm of the last layer is applied on load (the tape
+  // keeps x_L: the tests read the ReLU gates off it)
+  auto pool = [&](hipStream_t s_) -> int {
+    if (state.y != nullptr)
+      return launch_add_pool_bn(state.y, state.xres, state.scale, state.shift, tape ? state.xdst : nullptr,
+                                I(p.graph_ptr), g, n, h, F(p.pooled), s_);
+    return gnnsaft_add_pool(xc, I(p.graph_ptr), g, n, h, F(p.pooled), s_);
+  };
   // ---- readout: one launch (readout.hip) while its workgroups are co-resident, the per-op path beyond
   // (an eval-mode tape keeps the readout's pre-activations through the per-op path)
   if (!d->unfused_readout && !(d->save_tape && !d->training) && readout_fused_launchable(g, h, d->num_para, p.nb, false)) {
-    GS_TRY(gnnsaft_add_pool(xc, I(p.graph_ptr), g, n, h, F(p.pooled), st));
+    GS_TRY(pool(st));
     ReadoutFusedParams rp{};
     rp.x = xc;
     rp.graph_ptr = I(p.graph_ptr);
@@ -701,7 +771,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     return launch_readout_fused(rp, st);
   }
   // ---- readout
-  GS_TRY(gnnsaft_add_pool(xc, I(p.graph_ptr), g, n, h, F(p.pooled), st));
+  GS_TRY(pool(st));
   const float *cur = F(p.pooled);
   int width = h, bi = 0;
   const int64_t rs = g * (int64_t)h;  // floats per readout block buffer

@@ -23,7 +23,9 @@
 // before the MFMAs, so no s_waitcnt in front of them), run the 16 k-steps of
 // tile t out of LDS, then `finish` (scale / add / ReLU) the raw registers and
 // write them to the other LDS buffer; one barrier per tile.
-#include "common.hpp"
+#include <type_traits>
+
+#include "bn_fold.hpp"
 
 namespace gs {
 
@@ -152,6 +154,51 @@ struct EdgeA {
   }
 };
 
+// The node state of the next layer formed while it is staged: A = relu(y * scale + shift) (+ x_prev), i.e. train-mode
+// BatchNorm + ReLU + residual of models.py:128-131 applied to the previous layer's pre-activation y with the batch
+// statistics the producing GEMM's tail left in (scale, shift).  Replaces the k_bn_train_apply launch: the message
+// GEMM of layer l+1 reads y_l and x_l instead of x_{l+1}, and the workgroups of column block 0 write x_{l+1} on their
+// way (the update GEMM and the backward's tape still want it in memory).  scale / shift sit in LDS for the whole kernel
+// (K = H <= 256), so the staging registers hold only the two raw operands.
+struct BnResA {
+  const float *y;       // [M, K] pre-activation
+  const float *xprev;   // [M, K] residual, or null
+  const float *scale;   // [K]
+  const float *shift;   // [K]
+  float *xout;          // [M, K] side output, or null
+  int64_t m;
+  int k;                // multiple of BK, <= kMaxAffineK
+  static constexpr bool kNeedsAffine = true;
+  struct Row {
+    const float *py;
+    const float *px;
+    float *po;
+  };
+  struct Raw {
+    f32x4 y, x;
+  };
+  __device__ __forceinline__ TileInfo tile(int bx, int bm) const { return gs_plain_tile(bx, bm, m); }
+  __device__ __forceinline__ int64_t out_row(const TileInfo &t, int lr) const { return t.row0 + lr; }
+  __device__ __forceinline__ Row row(int64_t r, int64_t) const {
+    // (rows past the end are clamped duplicates: they re-write the last row's values, harmless)
+    const bool writer = (blockIdx.y | blockIdx.z) == 0 && xout != nullptr;
+    return Row{y + r * k, (xprev != nullptr ? xprev : y) + r * k, writer ? xout + r * k : nullptr};
+  }
+  __device__ __forceinline__ Raw load(const Row &r, int k0, int c) const {
+    return Raw{gs_ld4(r.py + k0 + c), gs_ld4(r.px + k0 + c)};
+  }
+  // `aff`: LDS copy of [scale | shift]
+  __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &r, int k0, int c, const float *aff) const {
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(aff + k0 + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4 *>(aff + k + k0 + c);
+    f32x4 v = gs_relu4(w.y * sc + sh);      // the arithmetic of k_bn_train_apply: mul, add, max, add
+    if (xprev != nullptr) v = v + w.x;
+    if (r.po != nullptr) gs_st4(r.po + k0 + c, v);
+    return v;
+  }
+};
+constexpr int kMaxAffineK = 256;
+
 // Two row-major matrices side by side, A = [A0 | A1] (the backward's merged input-gradient GEMM
 // dx = [du | dPQ] [W_x | W_pq]^T: one pass instead of two chained residual GEMMs).  k0 is a multiple of BK.
 struct Concat2A {
@@ -254,6 +301,11 @@ struct PermPlainA {
 // --------------------------------------------------------------------------
 // kernel
 // --------------------------------------------------------------------------
+template <class T, class = void>
+struct provider_needs_affine : std::false_type {};
+template <class T>
+struct provider_needs_affine<T, std::void_t<decltype(T::kNeedsAffine)>> : std::bool_constant<T::kNeedsAffine> {};
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, class AProv, bool STATS, bool AFFINE, bool RESID>
 __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int64_t ldw, int64_t ldo, int64_t m,
                                                    int n_out, int k, EpiArgs epi) {
@@ -269,6 +321,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   constexpr int STAGE = (BM + BN) * LDS_LD;
 
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  constexpr bool kAffineA = provider_needs_affine<AProv>::value;
+  __shared__ __attribute__((aligned(16))) float s_aff[kAffineA ? 2 * kMaxAffineK : 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -331,7 +385,12 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < A_LD4; ++j) {
-      const f32x4 v = ap.finish(ra[j], arow[j], k0, c4 * 4);
+      f32x4 v;
+      if constexpr (kAffineA) {
+        v = live ? ap.finish(ra[j], arow[j], k0, c4 * 4, s_aff) : zero;   // (side output only for real tiles)
+      } else {
+        v = ap.finish(ra[j], arow[j], k0, c4 * 4);
+      }
       gs_st4(as + (r0 + 32 * j) * LDS_LD + c4 * 4, live ? v : zero);
     }
 #pragma unroll
@@ -363,6 +422,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
 
   // the big tile cannot afford the second register set (it would halve the waves per SIMD)
   constexpr bool kDeepPrefetch = BM * BN <= 128 * 64;
+  if constexpr (kAffineA) {   // [scale | shift] of the BatchNorm the provider applies: resident for the whole kernel
+    for (int i = tid; i < 2 * ap.k; i += 256) s_aff[i] = i < ap.k ? ap.scale[i] : ap.shift[i - ap.k];
+    __syncthreads();
+  }
   fetch(0, ra0, rb0);
   stash(0, ra0, rb0);
   if (kDeepPrefetch) fetch(1, ra0, rb0);
@@ -490,6 +553,124 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
       }
     }
   }
+
+  // ---- BatchNorm statistics closed inside the GEMM (bn_fold.hpp): the last workgroup to arrive in a segment of row
+  //      tiles folds that segment's partials (this column block), the last segment-folder folds the segment sums and
+  //      writes scale / shift / saved statistics / running statistics.  Fixed summation order: the same bits as the
+  //      separate k_bn_combine + k_bn_train_apply launches.
+  if constexpr (STATS) {
+    const BnTail &tl = epi.tail;
+    if (tl.enabled) {
+      constexpr int NP = BN / kBnCols;
+      static_assert(NP >= 1 && NP <= 4, "column slabs per workgroup");
+      double *s_a = reinterpret_cast<double *>(lds);            // [NP][8][32] (the staging buffers are dead now)
+      double *s_b = s_a + NP * kBnGroupLanes * kBnCols;
+      __shared__ int s_last;
+      const int cl = tid & (kBnCols - 1), gl = tid / kBnCols;
+      const int ch = n_out;
+      const int64_t groups = (tl.rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup;
+      const int wg_per_seg = (int)(tl.per_seg / WAVES_M);       // per_seg is a multiple of 4 >= WAVES_M
+      const int sgm = (int)(blockIdx.x / wg_per_seg);
+      const int first = sgm * wg_per_seg;
+      const int expected = (int)gridDim.x - first < wg_per_seg ? (int)gridDim.x - first : wg_per_seg;
+      int32_t *seg_ticket = tl.counters + (int64_t)sgm * gridDim.y + blockIdx.y;
+      int32_t *fin_ticket = tl.counters + (int64_t)tl.num_seg * gridDim.y + blockIdx.y;
+      __syncthreads();                                          // every wave's partials are issued; lds is free
+      if (tid == 0)
+        s_last = __hip_atomic_fetch_add(seg_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == expected - 1;
+      __syncthreads();
+      if (!s_last) return;                                      // block-uniform
+      int colc[NP];
+      bool colok[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int c = n0 + p * kBnCols + cl;
+        colok[p] = c < ch;
+        colc[p] = colok[p] ? c : ch - 1;
+      }
+      {
+        double s1[NP], s2[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s1[p] = s2[p] = 0.0;
+        const int64_t g_beg = (int64_t)sgm * tl.per_seg;
+        int64_t g_end = g_beg + tl.per_seg;
+        if (g_end > groups) g_end = groups;
+        bn_fold_partials_multi<NP>(epi.stats, g_beg, g_end, tl.rows, ch, colc, gl, s1, s2);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          s_a[(p * kBnGroupLanes + gl) * kBnCols + cl] = s1[p];
+          s_b[(p * kBnGroupLanes + gl) * kBnCols + cl] = s2[p];
+        }
+        __syncthreads();
+        if (gl == 0) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            double a = s1[p], b = s2[p];
+            for (int o = 1; o < kBnGroupLanes; ++o) {
+              a += s_a[(p * kBnGroupLanes + o) * kBnCols + cl];
+              b += s_b[(p * kBnGroupLanes + o) * kBnCols + cl];
+            }
+            if (colok[p]) {
+              tl.seg[((int64_t)sgm * 2 + 0) * ch + colc[p]] = a;
+              tl.seg[((int64_t)sgm * 2 + 1) * ch + colc[p]] = b;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0)
+        s_last = __hip_atomic_fetch_add(fin_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == tl.num_seg - 1;
+      __syncthreads();
+      if (!s_last) return;
+      {
+        double s1[NP], s2[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s1[p] = s2[p] = 0.0;
+        for (int sg = gl; sg < tl.num_seg; sg += kBnGroupLanes) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            s1[p] += __builtin_nontemporal_load(tl.seg + ((int64_t)sg * 2 + 0) * ch + colc[p]);
+            s2[p] += __builtin_nontemporal_load(tl.seg + ((int64_t)sg * 2 + 1) * ch + colc[p]);
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          s_a[(p * kBnGroupLanes + gl) * kBnCols + cl] = s1[p];
+          s_b[(p * kBnGroupLanes + gl) * kBnCols + cl] = s2[p];
+        }
+        __syncthreads();
+        if (gl == 0) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            double a = s1[p], b = s2[p];
+            for (int o = 1; o < kBnGroupLanes; ++o) {
+              a += s_a[(p * kBnGroupLanes + o) * kBnCols + cl];
+              b += s_b[(p * kBnGroupLanes + o) * kBnCols + cl];
+            }
+            if (!colok[p]) continue;
+            const int c = colc[p];
+            const BnColumn bc = bn_finish_column(a, b, tl.rows, tl.gamma != nullptr ? tl.gamma[c] : 1.f,
+                                                 tl.beta != nullptr ? tl.beta[c] : 0.f, tl.eps);
+            tl.scale[c] = bc.scale;
+            tl.shift[c] = bc.shift;
+            if (tl.save_stat != nullptr) {
+              tl.save_stat[c] = bc.mean;
+              tl.save_stat[ch + c] = bc.rstd;
+            }
+            if (tl.running_mean != nullptr) {
+              tl.running_mean[c] = (1.f - tl.momentum) * tl.running_mean[c] + tl.momentum * bc.mean;
+              tl.running_var[c] = (1.f - tl.momentum) * tl.running_var[c] + tl.momentum * bc.unbiased;
+            }
+            if (tl.nbt != nullptr && c == 0) tl.nbt[0] += 1;
+          }
+        }
+      }
+      // this workgroup is the last to touch its column block's tickets: leave them zero for the next launch that
+      // uses the same counters (the next layer, on the same stream)
+      if (tid < tl.num_seg) tl.counters[(int64_t)tid * gridDim.y + blockIdx.y] = 0;
+      if (tid == 0) *fin_ticket = 0;
+    }
+  }
 }
 
 // --------------------------------------------------------------------------
@@ -568,7 +749,16 @@ static int dispatch(const AProv &ap, int nbatch, const GemmBatchEntry *entries, 
     GS_REQUIRE((reinterpret_cast<uintptr_t>(entries[i].w) & 15) == 0, GNNSAFT_ERR_SHAPE);
   }
   EpiArgs ea{epi.scale, epi.shift, epi.relu_out, epi.residual, epi.ldr, epi.stats, epi.residual_is_mask,
-             epi.bn_mean, epi.bn_var, epi.bn_eps};
+             epi.bn_mean, epi.bn_var, epi.bn_eps, BnTail{}};
+  if (epi.tail != nullptr) {
+    constexpr bool plain = std::is_same<AProv, PlainA>::value;   // (every workgroup of the grid owns rows)
+    const bool tail_ok = epi.stats != nullptr && epi.tail->seg && epi.tail->counters && epi.tail->scale &&
+                         epi.tail->shift && epi.tail->num_seg >= 1 && epi.tail->num_seg <= kBnMaxSegments &&
+                         (epi.tail->per_seg % 4) == 0 && epi.tail->rows == m && plain;
+    GS_REQUIRE(tail_ok, GNNSAFT_ERR_SHAPE);
+    ea.tail = *epi.tail;
+    ea.tail.enabled = 1;
+  }
   GS_REQUIRE((epi.bn_var == nullptr) == (epi.bn_mean == nullptr) && (epi.bn_var == nullptr || epi.scale != nullptr),
              GNNSAFT_ERR_NULL);
   GS_REQUIRE((epi.scale == nullptr) == (epi.shift == nullptr), GNNSAFT_ERR_NULL);
@@ -595,6 +785,18 @@ int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const Ge
   GS_REQUIRE((lda % 4) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0, GNNSAFT_ERR_SHAPE);
   PlainA ap{a, lda, relu_in, m, k};
   return dispatch<PlainA, true>(ap, nbatch, entries, ldw, ldo, m, n_out, k, epi, stream, cfg);
+}
+
+int launch_linear_bnres(const float *y, const float *xprev, const float *scale, const float *shift, float *xout,
+                        int nbatch, const GemmBatchEntry *entries, int64_t ldw, int64_t ldo, int64_t m, int n_out, int k,
+                        hipStream_t stream) {
+  GS_REQUIRE(y && scale && shift, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(k >= BK && (k % BK) == 0 && k <= kMaxAffineK && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(xprev) & 15) == 0 && (reinterpret_cast<uintptr_t>(xout) & 15) == 0,
+             GNNSAFT_ERR_SHAPE);
+  BnResA ap{y, xprev, scale, shift, xout, m, k};
+  LinearEpilogue epi;
+  return dispatch<BnResA, false>(ap, nbatch, entries, ldw, ldo, m, n_out, k, epi, stream);
 }
 
 int launch_pna_update(const float *x, const float *agg, const float *log_amp, const float *log_att,
@@ -644,7 +846,7 @@ int launch_pna_update_folded(const float *x, const float *agg, const int32_t *pe
   b.e[0] = GemmBatchEntry{w_eff, b_post0, u, 0};
   b.e[1] = GemmBatchEntry{w_eff + per_tower, b_post1, u + hidden / 2, 4 * (int64_t)hidden};
   for (int i = 2; i < kMaxGemmBatch; ++i) b.e[i] = b.e[0];
-  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0.f};
+  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0.f, BnTail{}};
   return launch_cfg<PostFoldA, false, false, false>(ap, 2, b, 5 * (int64_t)hidden, hidden, n, hidden / 2, 5 * hidden,
                                                     ea, stream, tiled_cfg_for(hidden), max_tiles);
 }
@@ -660,7 +862,7 @@ int launch_linear_degree_tiled(const float *a, int64_t lda, const int32_t *perm,
   PermPlainA ap{a, lda, perm, tiles, num_tiles, w_stride, k};
   GemmBatch b;
   for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entries[i < nbatch ? i : 0];
-  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0.f};
+  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0.f, BnTail{}};
   return launch_cfg<PermPlainA, false, false, false>(ap, nbatch, b, ldw, ldo, n, n_out, k, ea, stream,
                                                      tiled_cfg_for(hidden), max_tiles);
 }
@@ -679,7 +881,7 @@ int launch_linear_concat2(const float *a0, int64_t lda0, int k0, const float *a1
   GemmBatch b;
   for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entry;
   EpiArgs ea{nullptr, nullptr, epi.relu_out, epi.residual, epi.ldr, nullptr, epi.residual_is_mask, nullptr, nullptr,
-             0.f};
+             0.f, BnTail{}};
   if (epi.residual != nullptr)
     return launch_cfg<Concat2A, false, false, true>(ap, 1, b, ldw, ldo, m, n_out, k0 + k1, ea, stream);
   return launch_cfg<Concat2A, false, false, false>(ap, 1, b, ldw, ldo, m, n_out, k0 + k1, ea, stream);

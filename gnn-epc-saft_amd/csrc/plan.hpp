@@ -33,7 +33,8 @@ struct Plan {
   size_t csr_ws, rowptr, src, dst, combo, log_amp, log_att, graph_ptr;
   size_t x0, x1, pq, agg, u0, u1, y, msg0, msg1, cemb, cenc, rtab, stats, bnseg, bnseg_bytes, scale, shift, pooled, m0, m1, m2;
   size_t perm, tiles, num_tiles, hist3, weff, gfold;
-  size_t rd_scratch, rd_sync;   // fused readout: per-workgroup partials, barrier counters
+  size_t rd_scratch, rd_sync;   // fused readout: per-workgroup partials, barrier counters (+ BatchNorm tail tickets)
+  size_t bn_tail_seg;
   size_t struct_begin, struct_bytes;  // [rowptr .. hist3]: everything that depends on edge_index / batch only
   int64_t tile_cap;
   // per-layer strides in floats (0 unless desc->save_tape: then every layer keeps its own tensors for backward)
@@ -134,7 +135,10 @@ static inline int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, i
   {
     const size_t wgs = (gg + 63) / 64;   // readout.hip: 64 graphs per workgroup
     p.rd_scratch = take(gs_align_up((size_t)p.nb * wgs * 2 * h * 4, 256) + gs_align_up(wgs * 4, 256));
-    p.rd_sync = take(64);
+    // barrier / ticket counters zeroed by the prologue launch of every forward: the fused readout's (kRdSyncInts = 16),
+    // then the BatchNorm statistics tail's (kBnTailCounterInts)
+    p.rd_sync = take((16 + (size_t)kBnTailCounterInts) * 4);
+    p.bn_tail_seg = take((size_t)64 * 2 * h * 8);   // [kBnMaxSegments][2][H] f64 segment sums of the in-GEMM tail
   }
   p.weff = d->fold_degree_scalers ? take(nl * (size_t)kDegreeBuckets * 5 * h * h * 4) : 0;
   p.gfold = d->fold_degree_scalers ? take(nl * 2 * 3 * (h / 2) * h * 8) : 0;   // float64 (fold.hpp)

@@ -180,6 +180,10 @@ class PNAPCSAFT(nn.Module):
         # add-pool -> readout MLP (train-mode BatchNorm across the batch through a grid barrier) -> MAPE in ONE launch
         # (csrc/readout.hip) for up to 16 384 graphs; False restores the nine per-op launches
         self.fused_readout = True
+        # train-mode node BatchNorm without its own launches: statistics closed by the last-arriving workgroups of the
+        # lin GEMM, normalisation + ReLU + residual applied while the next layer's message GEMM (resp. the pooling)
+        # stages its operand; False restores k_bn_combine + k_bn_train_apply (same bits)
+        self.fused_batchnorm = True
         self._debug_barrier_extra = 0   # tests only: make the fused readout's grid barriers time out
         # Per-graph fused kernel (csrc/graph_eval.hip: one workgroup per molecule, whole network in one launch):
         # always for float64 modules; for float32 in eval mode without autograd when the input has at most this many
@@ -266,6 +270,7 @@ class PNAPCSAFT(nn.Module):
         d.fold_dst_term = int(self.fold_dst_term)
         d.unfused_readout = int(not self.fused_readout)
         d.debug_barrier_extra = int(self._debug_barrier_extra)
+        d.unfused_bn_apply = int(not self.fused_batchnorm)
         return d
 
     def _check_mode(self, x: torch.Tensor) -> None:

@@ -320,6 +320,9 @@ typedef struct gnnsaft_model_desc {
                                /* more than there are workgroups, i.e. time out (flag + NaN outputs)                */
   float readout_dropout;       /* p of the readout MLP's Dropout layers (models.py:88,95,99); applied in training  */
   uint64_t dropout_seed;       /* Philox key of this call's dropout masks (the backward regenerates them from it)   */
+  int32_t unfused_bn_apply;    /* 1: train-mode node BatchNorm as separate combine / apply launches instead of the   */
+                               /* statistics tail inside the lin GEMM + apply-on-load in the next message GEMM      */
+  int32_t reserved0;
 } gnnsaft_model_desc;
 
 GNNSAFT_API int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);

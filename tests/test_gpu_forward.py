@@ -164,6 +164,42 @@ def test_shape_envelope_vs_oracle(cfg, mode):
                 assert int(sd_h[k]) == int(sd_o[k]) == 1
 
 
+@pytest.mark.parametrize("cfg", [(64, 2, True, 96), (128, 3, True, 1024), (256, 2, False, 300), (64, 6, True, 3000)],
+                         ids=["H64", "C2", "H256-noskip", "default-model-3000"])
+def test_deferred_batchnorm_equals_the_separate_launches_bit_for_bit(cfg):
+    """Train-mode node BatchNorm without launches of its own -- statistics closed by the last-arriving workgroups of
+    the lin GEMM (segment tickets, csrc/bn_fold.hpp), normalisation + ReLU + residual applied on load by the next
+    layer's message GEMM (BnResA) resp. by the pooling kernel -- against k_bn_combine + k_bn_train_apply: the same
+    sums in the same order, so outputs, loss, running statistics and (taped forward) every gradient are EQUAL, whatever
+    workgroup happens to arrive last."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    from gnn_epc_saft_amd.train.models import mape_loss
+    hidden, depth, skip, graphs = cfg
+    data = make_synthetic_batch(graphs, 11 + graphs, num_para=3)
+    oracle = oracle_model(hidden, depth, 1, 1, 1, 3, skip, True, degree_histogram(data), seed=4).train()
+    dd, tgt = data.to(DEV), data.para.view(-1, 3).to(DEV)
+    res = {}
+    for fused in (True, False):
+        hip = hip_twin(copy.deepcopy(oracle))
+        hip.fused_batchnorm = fused
+        with torch.no_grad():
+            for _ in range(3):                      # repeated launches reuse (and must re-zero) the ticket counters
+                pred, loss3 = hip.run(dd, target=tgt)
+        out = hip(dd)                               # taped forward (no destination fold: the 4H-wide message GEMM)
+        mape_loss(out, tgt).backward()
+        torch.cuda.synchronize()
+        assert hip.input_error_flags() == 0
+        res[fused] = (pred.clone(), loss3.clone(), out.detach().clone(),
+                      {k: v.detach().clone() for k, v in hip.state_dict().items()},
+                      {k: p.grad.detach().clone() for k, p in hip.named_parameters()})
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), k
+
+
 def test_zero_crossing_case_behind_the_coarse_gate():
     """The one case of the suite that needs check_population's coarse gate, pinned with its numbers: envelope case
     (64, 2, 2, 2, 0, 5, no skip, no loops), train mode.  Its worst per-element gate value is ~0.1 for the HIP path
