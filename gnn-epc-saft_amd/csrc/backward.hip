@@ -110,7 +110,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float *__restrict_
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float yh = (yv[u][j] - mean[j]) * rstd[j];
-        const float dz = (ok && (yh * gm[j] + bt[j]) > 0.f) ? dv[u][j] : 0.f;
+        // the ReLU gate exactly as the forward took it: relu(y * scale + shift) with scale = rstd * gamma,
+        // shift = beta - mean * scale (bn_fold.hpp) -- "yhat * gamma + beta > 0" rounds differently near zero and
+        // then differentiates another branch than the one the forward evaluated
+        const float sc = rstd[j] * gm[j], sh = bt[j] - mean[j] * sc;
+        const float dz = (ok && (yv[u][j] * sc + sh) > 0.f) ? dv[u][j] : 0.f;
         s1[j] += (double)dz;
         s2[j] += (double)dz * (double)yh;
       }
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float yh = (yv[j] - s_mean[c4 + j]) * s_rstd[c4 + j];
-      const float dz = (yh * s_g[c4 + j] + s_bt[c4 + j]) > 0.f ? dv[j] : 0.f;
+      const float sc = s_rstd[c4 + j] * s_g[c4 + j], sh = s_bt[c4 + j] - s_mean[c4 + j] * sc;   // the forward's gate
+      const float dz = (yv[j] * sc + sh) > 0.f ? dv[j] : 0.f;
       res[j] = s_a[c4 + j] * dz - s_b[c4 + j] - s_c[c4 + j] * yh;
     }
     gs_st4(dy + o, res);

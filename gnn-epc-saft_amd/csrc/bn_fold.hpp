@@ -1,17 +1,16 @@
 // Train-mode BatchNorm statistics: combining the per-64-row (mean, M2) column partials a STATS GEMM epilogue leaves
 // (torch BatchNorm1d semantics: SURVEY.md Appendix A.3; reference call sites models.py:82,128).  Shared by
-// bn_train.hip (separate combine / apply launches: readout blocks, C ABI) and gemm.hip (the statistics are closed
-// INSIDE the producing GEMM by its last-arriving workgroups: no combine launch, and the normalisation is applied by the
-// A-operand provider of the next GEMM instead of an apply launch).
+// the kernels of bn_train.hip: combine + apply (readout blocks, C ABI) and k_bn_stats_close (node layers: the
+// statistics are closed in ONE small launch, the normalisation is applied by the A-operand provider of the next GEMM
+// instead of an apply pass over y).
 //
 // Division-free combine in f64:
 //   S1 = sum n_g mean_g,  S2 = sum (M2_g + n_g mean_g^2);   mean = S1/N,  M2 = S2 - N mean^2
 // (no pivot: in float64 the final subtraction loses 1e-16 (mean/std)^2 of M2 -- 1e-10 for a column whose mean is a
-// thousand standard deviations -- and a pivot taken from another workgroup's partial would be a cross-workgroup
-// dependency inside the GEMM tail)
+// thousand standard deviations)
 // Two levels: segments of `per_seg` groups -> (S1, S2) per segment, then over the <= 64 segments.  Every sum has a
-// fixed order (thread layout 32 columns x 8 partial-lanes, lanes folded 0..7), whoever executes it: the separate
-// launches and the in-GEMM tail give the same bits.
+// fixed order (thread layout 32 columns x 8 partial-lanes, lanes folded 0..7), whoever executes it: both kernel
+// families give the same bits.
 #pragma once
 #include "common.hpp"
 
@@ -67,8 +66,7 @@ __device__ __forceinline__ void bn_fold_partials(const float *__restrict__ stats
 }
 
 // The same sums for NP column slabs of 32 at once (column of slab p: colc[p]): all slabs' loads of a round are in
-// flight together -- the in-GEMM tail is one workgroup's dependent chain, its cost is rounds of L2 latency.  Per slab
-// the order of the additions is that of bn_fold_partials.
+// flight together.  Per slab the order of the additions is that of bn_fold_partials.
 template <int NP>
 __device__ __forceinline__ void bn_fold_partials_multi(const float *__restrict__ stats, int64_t g_beg, int64_t g_end,
                                                        int64_t rows, int ch, const int (&colc)[NP], int gl,
@@ -122,7 +120,5 @@ __device__ __forceinline__ BnColumn bn_finish_column(double s1, double s2, int64
   c.unbiased = (float)(n > 1.0 ? m2 / (n - 1.0) : m2);
   return c;
 }
-
-// (BnTail, the argument record of the in-GEMM statistics tail: common.hpp)
 
 }  // namespace gs

@@ -39,6 +39,81 @@ __global__ __launch_bounds__(256) void k_bn_combine(const float *__restrict__ st
   }
 }
 
+// combine + finalize in one launch: workgroup (slab, segment) folds its segment like k_bn_combine, then takes a
+// ticket of its slab; the LAST of the slab's workgroups folds the segment sums and writes what k_bn_train_apply's
+// first phase computes -- scale, shift, saved (mean, rstd), running statistics.  (The partials were written by the
+// previous kernel; only the few KB of segment sums cross workgroups inside this one, behind an agent-scope release /
+// acquire on the ticket.)  Same sums, same order as combine + apply.
+__global__ __launch_bounds__(256) void k_bn_stats_close(const float *__restrict__ stats, int64_t rows, int ch,
+                                                        double *__restrict__ seg, int64_t per_seg,
+                                                        int32_t *__restrict__ tickets,
+                                                        const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta,
+                                                        float *__restrict__ running_mean,
+                                                        float *__restrict__ running_var, int64_t *nbt,
+                                                        float momentum, float eps, float *__restrict__ scale,
+                                                        float *__restrict__ shift, float *__restrict__ save_stat) {
+  __shared__ double s_a[kBnGroupLanes][kBnCols], s_b[kBnGroupLanes][kBnCols];
+  __shared__ int s_last;
+  const int cl = threadIdx.x & (kBnCols - 1), gl = threadIdx.x / kBnCols;
+  const int col = blockIdx.x * kBnCols + cl;
+  const bool col_ok = col < ch;
+  const int colc = col_ok ? col : ch - 1;
+  const int num_seg = gridDim.y;
+  const int64_t groups = (rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup;
+  const int64_t g_beg = (int64_t)blockIdx.y * per_seg;
+  int64_t g_end = g_beg + per_seg;
+  if (g_end > groups) g_end = groups;
+  double s1 = 0.0, s2 = 0.0;
+  if (g_beg < g_end) bn_fold_partials(stats, g_beg, g_end, rows, ch, colc, gl, s1, s2);
+  s_a[gl][cl] = s1;
+  s_b[gl][cl] = s2;
+  __syncthreads();
+  if (gl == 0) {
+    for (int o = 1; o < kBnGroupLanes; ++o) {
+      s1 += s_a[o][cl];
+      s2 += s_b[o][cl];
+    }
+    if (col_ok) {
+      seg[((int64_t)blockIdx.y * 2 + 0) * ch + col] = s1;
+      seg[((int64_t)blockIdx.y * 2 + 1) * ch + col] = s2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == num_seg - 1;
+  __syncthreads();
+  if (!s_last) return;   // block-uniform
+  s1 = s2 = 0.0;
+  for (int sg = gl; sg < num_seg; sg += kBnGroupLanes) {
+    s1 += __builtin_nontemporal_load(seg + ((int64_t)sg * 2 + 0) * ch + colc);
+    s2 += __builtin_nontemporal_load(seg + ((int64_t)sg * 2 + 1) * ch + colc);
+  }
+  s_a[gl][cl] = s1;
+  s_b[gl][cl] = s2;
+  __syncthreads();
+  if (gl == 0 && col_ok) {
+    for (int o = 1; o < kBnGroupLanes; ++o) {
+      s1 += s_a[o][cl];
+      s2 += s_b[o][cl];
+    }
+    const BnColumn bc = bn_finish_column(s1, s2, rows, gamma != nullptr ? gamma[col] : 1.f,
+                                         beta != nullptr ? beta[col] : 0.f, eps);
+    scale[col] = bc.scale;
+    shift[col] = bc.shift;
+    if (save_stat != nullptr) {
+      save_stat[col] = bc.mean;
+      save_stat[ch + col] = bc.rstd;
+    }
+    if (running_mean != nullptr) {
+      running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * bc.mean;
+      running_var[col] = (1.f - momentum) * running_var[col] + momentum * bc.unbiased;
+    }
+    if (nbt != nullptr && col == 0) nbt[0] += 1;
+  }
+  if (threadIdx.x == 0) tickets[blockIdx.x] = 0;   // last to touch it: zero again for the next launch on this stream
+}
+
 __global__ __launch_bounds__(256) void k_bn_train_apply(const float *__restrict__ stats, const float *__restrict__ y,
                                                         int64_t rows, int ch, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta,
@@ -156,6 +231,23 @@ __global__ __launch_bounds__(256) void k_bn_eval_apply(const float *__restrict__
     gs_st4(save_stat + c, mn);
     gs_st4(save_stat + ch + c, rs);
   }
+}
+
+int launch_bn_stats_close(const float *stats, int64_t rows, int ch, const float *gamma, const float *beta,
+                          float *running_mean, float *running_var, int64_t *nbt, float momentum, float eps,
+                          float *scale, float *shift, float *save_stat, double *seg, int32_t *tickets, hipStream_t st) {
+  GS_REQUIRE(stats && scale && shift && seg && tickets, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(rows >= 2 && ch >= 4 && (ch % 4) == 0 && (reinterpret_cast<uintptr_t>(seg) & 7) == 0, GNNSAFT_ERR_SHAPE);
+  const int slabs = (ch + kBnCols - 1) / kBnCols;
+  GS_REQUIRE(slabs <= kBnTailCounterInts, GNNSAFT_ERR_UNSUPPORTED);
+  int num_seg = 0;
+  int64_t per_seg = 0;
+  bn_segments(gs_ceil_div(rows, (int64_t)kBnRowsPerGroup), &num_seg, &per_seg);
+  hipLaunchKernelGGL(k_bn_stats_close, dim3((unsigned)slabs, (unsigned)num_seg), dim3(256), 0, st, stats, rows, ch, seg,
+                     per_seg, tickets, gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift,
+                     save_stat);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
 }
 
 int launch_bn_eval_apply(const float *y, int64_t rows, int ch, const float *gamma, const float *beta,

@@ -74,24 +74,6 @@ struct GemmBatchEntry {
 constexpr int kMaxGemmBatch = 8;
 constexpr int kBnRowsPerGroup = 64;  // rows covered by one wave's accumulator tile
 
-// In-GEMM BatchNorm statistics tail (gemm.hip, STATS epilogue; arithmetic: bn_fold.hpp): after a workgroup has written its partials it takes a ticket of
-// its segment; the LAST arriver folds the segment (level 1), takes a ticket of its column block; the last of those
-// folds the segment sums and writes scale / shift / saved (mean, rstd) / running statistics (level 2).
-struct BnTail {
-  int enabled;               // 0: the STATS epilogue only leaves partials (separate combine / apply launches)
-  int num_seg;
-  int64_t per_seg;           // groups per segment (multiple of 4)
-  int64_t rows;              // N
-  double *seg;               // [num_seg][2][ch]
-  int32_t *counters;         // [num_seg * col_blocks] segment tickets, then [col_blocks] final tickets; zero at launch
-  const float *gamma, *beta;
-  float *running_mean, *running_var;
-  int64_t *nbt;
-  float momentum, eps;
-  float *scale, *shift;      // [ch] out: y * scale + shift
-  float *save_stat;          // [2][ch] (mean, rstd) for the backward, or null
-};
-
 struct LinearEpilogue {
   const float *scale = nullptr;   // eval-mode BN folded
   const float *shift = nullptr;
@@ -104,7 +86,6 @@ struct LinearEpilogue {
   // epilogue forms scale = gamma / sqrt(var + eps), shift = beta - mean scale itself (no finalize launch)
   const float *bn_mean = nullptr, *bn_var = nullptr;
   float bn_eps = 0.f;
-  const BnTail *tail = nullptr;   // with `stats`: close the batch statistics inside the GEMM (scale / shift out)
 };
 
 struct GemmBatch {
@@ -121,7 +102,6 @@ struct EpiArgs {
   int residual_is_mask;  // 1: out = residual > 0 ? v : 0 (ReLU backward) instead of v + residual
   const float *bn_mean, *bn_var;   // eval-mode BatchNorm parameters (scale / shift then hold gamma / beta), or null
   float bn_eps;
-  BnTail tail;
 };
 
 __device__ __forceinline__ f32x4 gs_relu4(f32x4 v) {
@@ -142,7 +122,7 @@ int launch_linear_concat2(const float *a0, int64_t lda0, int k0, const float *a1
 
 // out = relu(y * scale + shift) (+ xprev) as A operand, W^T as B; workgroups of column block 0 also write that A
 // to `xout` (or null): train-mode BatchNorm + ReLU + residual applied while the next GEMM stages its operand
-constexpr int kBnTailCounterInts = 1024;   // >= (kBnMaxSegments + 1) * column blocks of the statistics tail
+constexpr int kBnTailCounterInts = 64;     // one ticket per 32-column slab of k_bn_stats_close (H <= 2048)
 int launch_linear_bnres(const float *y, const float *xprev, const float *scale, const float *shift, float *xout,
                         int nbatch, const GemmBatchEntry *entries, int64_t ldw, int64_t ldo, int64_t m, int n_out, int k,
                         hipStream_t stream);
@@ -168,6 +148,14 @@ int launch_linear_degree_tiled(const float *a, int64_t lda, const int32_t *perm,
                                const int32_t *num_tiles, int64_t max_tiles, int64_t w_stride, int nbatch,
                                const GemmBatchEntry *entries, int64_t ldw, int64_t ldo, int64_t n, int n_out, int k,
                                int hidden /* the tile table was built for */, hipStream_t stream);
+
+// Train-mode BatchNorm statistics without the apply pass (bn_train.hip: k_bn_stats_close): folds the (mean, M2)
+// partials a STATS GEMM left, writes scale / shift [ch] (y * scale + shift normalises), the saved (mean, rstd) and the
+// running statistics.  `seg`: [kBnMaxSegments][2][ch] f64 scratch; `tickets`: >= ceil(ch / 32) ints, zero at launch
+// (left zero).  Whoever consumes y applies relu(y scale + shift) (+ residual) on load.
+int launch_bn_stats_close(const float *stats, int64_t rows, int ch, const float *gamma, const float *beta,
+                          float *running_mean, float *running_var, int64_t *nbt, float momentum, float eps,
+                          float *scale, float *shift, float *save_stat, double *seg, int32_t *tickets, hipStream_t st);
 
 // eval-mode BatchNorm + ReLU (+ residual) of a kept pre-activation tensor (bn_train.hip); `save_stat` [2][ch] receives
 // (running_mean, rstd) for the backward

@@ -78,8 +78,8 @@ struct ProfScope {
 
 // Linear -> BatchNorm -> ReLU (-> + residual): eval folds BN into the GEMM epilogue,
 // train writes y with (mean, M2) partials, finalises the statistics and applies them.
-// `defer_apply` (train mode): the batch statistics are closed inside the GEMM (BnTail: scale / shift land in
-// ws + p.scale / p.shift, running statistics updated) and NOTHING is applied here -- the consumer of the layer's
+// `defer_apply` (train mode): the batch statistics are closed by ONE small launch (k_bn_stats_close: scale / shift
+// land in ws + p.scale / p.shift, running statistics updated) and NOTHING is applied here -- the consumer of the layer's
 // output applies relu(y scale + shift) (+ residual) while it loads y (launch_linear_bnres, launch_add_pool_bn).
 static int linear_bn_relu(const float *a, int64_t lda, const float *w, const float *b, int64_t rows, int n_out, int k,
                           const BnPtrs &bn, const gnnsaft_model_desc *d, char *ws, const Plan &p, float *y_tmp,
@@ -90,26 +90,17 @@ static int linear_bn_relu(const float *a, int64_t lda, const float *w, const flo
   if (d->training && defer_apply) {
     GS_REQUIRE(rows >= 2, GNNSAFT_ERR_SHAPE);
     ent.out = y_tmp;
-    BnTail tl{};
-    bn_segments(gs_ceil_div(rows, (int64_t)kBnRowsPerGroup), &tl.num_seg, &tl.per_seg);
-    tl.rows = rows;
-    tl.seg = reinterpret_cast<double *>(ws + p.bn_tail_seg);
-    tl.counters = reinterpret_cast<int32_t *>(ws + p.rd_sync) + kRdSyncInts;
-    tl.gamma = bn.gamma;
-    tl.beta = bn.beta;
-    tl.running_mean = bn.rmean;
-    tl.running_var = bn.rvar;
-    tl.nbt = bn.nbt;
-    tl.momentum = d->bn_momentum;
-    tl.eps = d->bn_eps;
-    tl.scale = reinterpret_cast<float *>(ws + p.scale);
-    tl.shift = reinterpret_cast<float *>(ws + p.shift);
-    tl.save_stat = save_stat;
     LinearEpilogue epi;
     epi.stats = stats;
-    epi.tail = &tl;
-    ProfScope ps(prof, GNNSAFT_PROF_LIN, st);
-    return launch_linear(a, lda, 0, 1, &ent, k, n_out, rows, n_out, k, epi, st);
+    {
+      ProfScope ps(prof, GNNSAFT_PROF_LIN, st);
+      GS_TRY(launch_linear(a, lda, 0, 1, &ent, k, n_out, rows, n_out, k, epi, st));
+    }
+    return launch_bn_stats_close(stats, rows, n_out, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt, d->bn_momentum,
+                                 d->bn_eps, reinterpret_cast<float *>(ws + p.scale),
+                                 reinterpret_cast<float *>(ws + p.shift), save_stat,
+                                 reinterpret_cast<double *>(ws + p.bn_tail_seg),
+                                 reinterpret_cast<int32_t *>(ws + p.rd_sync) + kRdSyncInts, st);
   }
   if (d->training) {
     GS_REQUIRE(rows >= 2, GNNSAFT_ERR_SHAPE);
@@ -375,6 +366,8 @@ extern "C" int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int
   map->total = p.total;
   map->ro = p.ro;
   map->x_stride = (size_t)p.sx * 4;
+  map->bnstat = p.bnstat;
+  map->y_stride = (size_t)p.sy * 4;
   return GNNSAFT_OK;
 }
 

@@ -19,13 +19,24 @@
 // reads k = 8g+4h .. 8g+4h+3), which only changes the (unspecified) summation
 // order of the dot product.
 //
+// X6 mode (template flag): the same kernel on the bf16 matrix cores at f32 accuracy.  Every f32 operand value is
+// split EXACTLY into three bf16 numbers, a = hi + mid + lo (8 significand bits each, by truncation: 3 x 8 = 24), while
+// it is staged into LDS; the product a b is then the sum of nine bf16 x bf16 products, each exact in f32, of which the
+// six largest are issued -- (hi,hi) (hi,mid) (mid,hi) (hi,lo) (lo,hi) (mid,mid) -- as v_mfma_f32_32x32x16_bf16 with
+// f32 accumulation.  The three dropped terms are below 2^-24 |a b|: measured against f64 the result is as close as
+// the f32 fma chain's (tests/test_gpu_stages.py), i.e. the 1e-5 parity bar sees no difference -- but the bf16 pipe
+// runs 16x the f32 MFMA rate on gfx950 (2.5 PF vs 157 TF dense), so six of its instructions cost 6/16 of the f32
+// form.  LDS holds three bf16 planes per operand (6 B per element, rows of 16 k padded to 48 B: conflict-free
+// ds_read_b128 fragments), one k16 step per stage.
+//
 // Pipeline per BK tile: issue the raw global loads of tile t+1 (no consumer
 // before the MFMAs, so no s_waitcnt in front of them), run the 16 k-steps of
 // tile t out of LDS, then `finish` (scale / add / ReLU) the raw registers and
 // write them to the other LDS buffer; one barrier per tile.
+#include <cstdlib>
 #include <type_traits>
 
-#include "bn_fold.hpp"
+#include "common.hpp"
 
 namespace gs {
 
@@ -156,9 +167,9 @@ struct EdgeA {
 
 // The node state of the next layer formed while it is staged: A = relu(y * scale + shift) (+ x_prev), i.e. train-mode
 // BatchNorm + ReLU + residual of models.py:128-131 applied to the previous layer's pre-activation y with the batch
-// statistics the producing GEMM's tail left in (scale, shift).  Replaces the k_bn_train_apply launch: the message
-// GEMM of layer l+1 reads y_l and x_l instead of x_{l+1}, and the workgroups of column block 0 write x_{l+1} on their
-// way (the update GEMM and the backward's tape still want it in memory).  scale / shift sit in LDS for the whole kernel
+// statistics k_bn_stats_close left in (scale, shift).  Replaces the k_bn_train_apply launch: the message
+// GEMM of layer l+1 reads y_l and x_l instead of x_{l+1}, and its workgroups write x_{l+1} on their
+// way (k-tile by k-tile, shared out among the column blocks) (the update GEMM and the backward's tape still want it in memory).  scale / shift sit in LDS for the whole kernel
 // (K = H <= 256), so the staging registers hold only the two raw operands.
 struct BnResA {
   const float *y;       // [M, K] pre-activation
@@ -181,8 +192,7 @@ struct BnResA {
   __device__ __forceinline__ int64_t out_row(const TileInfo &t, int lr) const { return t.row0 + lr; }
   __device__ __forceinline__ Row row(int64_t r, int64_t) const {
     // (rows past the end are clamped duplicates: they re-write the last row's values, harmless)
-    const bool writer = (blockIdx.y | blockIdx.z) == 0 && xout != nullptr;
-    return Row{y + r * k, (xprev != nullptr ? xprev : y) + r * k, writer ? xout + r * k : nullptr};
+    return Row{y + r * k, (xprev != nullptr ? xprev : y) + r * k, xout != nullptr ? xout + r * k : nullptr};
   }
   __device__ __forceinline__ Raw load(const Row &r, int k0, int c) const {
     return Raw{gs_ld4(r.py + k0 + c), gs_ld4(r.px + k0 + c)};
@@ -193,7 +203,10 @@ struct BnResA {
     const f32x4 sh = *reinterpret_cast<const f32x4 *>(aff + k + k0 + c);
     f32x4 v = gs_relu4(w.y * sc + sh);      // the arithmetic of k_bn_train_apply: mul, add, max, add
     if (xprev != nullptr) v = v + w.x;
-    if (r.po != nullptr) gs_st4(r.po + k0 + c, v);
+    // side output: the gridDim.y * gridDim.z workgroups of a row tile all stage the whole row tile; k-tile kt is
+    // written by workgroup kt mod their number (k in steps of 16; one writer per element, the store traffic spread over all of them)
+    const unsigned writers = gridDim.y * gridDim.z, me = blockIdx.y + gridDim.y * blockIdx.z;
+    if (r.po != nullptr && (unsigned)(k0 >> 4) % writers == me) gs_st4(r.po + k0 + c, v);
     return v;
   }
 };
@@ -306,7 +319,22 @@ struct provider_needs_affine : std::false_type {};
 template <class T>
 struct provider_needs_affine<T, std::void_t<decltype(T::kNeedsAffine)>> : std::bool_constant<T::kNeedsAffine> {};
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, class AProv, bool STATS, bool AFFINE, bool RESID>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// a = hi + mid + lo exactly, each with 8 significand bits (the upper half of an f32 word): truncation splits
+__device__ __forceinline__ void gs_split3(float a, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+  hi = __float_as_uint(a) & 0xffff0000u;
+  const float r1 = a - __uint_as_float(hi);          // exact: the low 16 significand bits
+  mid = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(mid);        // exact: at most 8 significand bits are left
+  lo = __float_as_uint(r2);                          // (its low half is zero)
+}
+// two bf16 (upper halves of x0, x1) in one dword, x0 in the low half (k order = memory order)
+__device__ __forceinline__ uint32_t gs_pack_hi16(uint32_t x0, uint32_t x1) { return (x0 >> 16) | (x1 & 0xffff0000u); }
+
+constexpr int kX6RowBytes = 48;   // 16 bf16 + 16 B of padding: 12 dwords = 4 x odd -> conflict-free b128 fragment reads
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, class AProv, bool STATS, bool AFFINE, bool RESID, bool X6 = false>
 __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int64_t ldw, int64_t ldo, int64_t m,
                                                    int n_out, int k, EpiArgs epi) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -316,11 +344,23 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   constexpr int TM = WTM / 32;
   constexpr int TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile is a multiple of the 32x32 MFMA");
-  constexpr int A_LD4 = BM * (BK / 4) / 256;
-  constexpr int B_LD4 = (BN * (BK / 4) + 255) / 256;
+  constexpr int KT = X6 ? 16 : BK;          // k per LDS stage
+  constexpr int QPR = KT / 4;                // float4 per staged row
+  constexpr int RSTEP = 256 / QPR;           // rows covered by one pass of the 256 threads
+  constexpr int A_LD4 = BM * QPR / 256;
+  constexpr int B_LD4 = (BN * QPR + 255) / 256;
+  // f32: rows of 36 floats; X6: three planes of 48-B rows -- 144 B per row and stage either way
   constexpr int STAGE = (BM + BN) * LDS_LD;
-
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  static_assert(3 * kX6RowBytes == LDS_LD * 4, "both LDS formats spend 144 B per row and stage");
+  constexpr int PLANE = (BM + BN) * kX6RowBytes;   // bytes per bf16 plane (X6)
+  // (Tried and dropped in round 3: a wave-specialised variant -- 4 MFMA-only waves + 4 staging-only waves per
+  // workgroup, 4 LDS buffers, one barrier per stage.  On [163840,256] x [256,512] it ran 349 us against 302 us for
+  // this form: with the MFMAs removed its staging waves alone took 270 us, with the staging removed its MFMA waves
+  // 192 us (53 % of the matrix-core rate) -- both sides are bound by their own load -> use latency chains, which
+  // two mixed waves per SIMD hide better than one wave of each kind.)
+  constexpr int NT = 256;
+  constexpr int kStages = 2;
+  __shared__ __attribute__((aligned(16))) float lds[kStages * STAGE];
   constexpr bool kAffineA = provider_needs_affine<AProv>::value;
   __shared__ __attribute__((aligned(16))) float s_aff[kAffineA ? 2 * kMaxAffineK : 4];
 
@@ -334,20 +374,20 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   const int n0 = blockIdx.y * BN;
   const GemmBatchEntry ent = batch.e[blockIdx.z];
 
-  // staging map: 8 float4 per 32-float row; thread -> (row r0 + 32 j, float4 column c4)
-  const int c4 = tid & 7;
-  const int r0 = tid >> 3;
+  // staging map: QPR float4 per staged row; thread -> (row r0 + RSTEP j, float4 column c4)
+  const int c4 = tid & (QPR - 1);
+  const int r0 = tid / QPR;
 
   typename AProv::Row arow[A_LD4];
 #pragma unroll
   for (int j = 0; j < A_LD4; ++j) {
-    const int lr = r0 + 32 * j;
+    const int lr = r0 + RSTEP * j;
     arow[j] = ap.row(ti.row0 + (lr < ti.count ? lr : ti.count - 1), ent.a_off);  // clamped rows are never stored
   }
   const float *wrow[B_LD4];
 #pragma unroll
   for (int j = 0; j < B_LD4; ++j) {
-    const int n = n0 + r0 + 32 * j;
+    const int n = n0 + r0 + RSTEP * j;
     wrow[j] = ent.w + ti.w_off + (int64_t)(n < n_out ? n : n_out - 1) * ldw;  // clamped columns never stored
   }
 
@@ -363,24 +403,35 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   // ~0.4 us for a 32x32 wave tile, is shorter than an L2/HBM round trip)
   typename AProv::Raw ra0[A_LD4], ra1[A_LD4];
   f32x4 rb0[B_LD4], rb1[B_LD4];
-  const int nk = (k + BK - 1) / BK;
+  const int nk = (k + KT - 1) / KT;
 
   // fetch / stash take ANY tile index: past the last tile the addresses are those of the last tile and the staged
   // data is zero.  That keeps the k-loop free of branches -- a conditional fetch makes hipcc lose track of the
   // outstanding loads and put an s_waitcnt vmcnt(0) at the loop head, which serialises prefetch and MFMAs.
   auto fetch = [&](int kt, typename AProv::Raw(&ra)[A_LD4], f32x4(&rb)[B_LD4]) {
-    const int k0 = (kt < nk ? kt : nk - 1) * BK;
+    const int k0 = (kt < nk ? kt : nk - 1) * KT;
     const int kk = k0 + c4 * 4;
 #pragma unroll
     for (int j = 0; j < A_LD4; ++j) ra[j] = ap.load(arow[j], k0, c4 * 4);
 #pragma unroll
     for (int j = 0; j < B_LD4; ++j) rb[j] = gs_ld4(wrow[j] + (kk < k ? kk : 0));
   };
+  // X6: split a staged float4 into its three bf16 planes (8 B each) at (row, c4)
+  auto put3 = [&](char *plane0, int row, f32x4 v) {
+    uint32_t h[4], md[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gs_split3(v[e], h[e], md[e], l[e]);
+    char *p = plane0 + row * kX6RowBytes + c4 * 8;
+    *reinterpret_cast<uint2 *>(p) = uint2{gs_pack_hi16(h[0], h[1]), gs_pack_hi16(h[2], h[3])};
+    *reinterpret_cast<uint2 *>(p + PLANE) = uint2{gs_pack_hi16(md[0], md[1]), gs_pack_hi16(md[2], md[3])};
+    *reinterpret_cast<uint2 *>(p + 2 * PLANE) = uint2{gs_pack_hi16(l[0], l[1]), gs_pack_hi16(l[2], l[3])};
+  };
   auto stash = [&](int kt, const typename AProv::Raw(&ra)[A_LD4], const f32x4(&rb)[B_LD4]) {
-    float *as = lds + (kt & 1) * STAGE;
+    float *as = lds + (kt % kStages) * STAGE;
     float *bs = as + BM * LDS_LD;
+    char *xs = reinterpret_cast<char *>(lds + (kt % kStages) * STAGE);   // X6: plane 0, A rows then B rows
     const bool live = kt < nk;
-    const int k0 = (live ? kt : nk - 1) * BK;
+    const int k0 = (live ? kt : nk - 1) * KT;
     const bool kok = live && k0 + c4 * 4 < k;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -391,16 +442,54 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
       } else {
         v = ap.finish(ra[j], arow[j], k0, c4 * 4);
       }
-      gs_st4(as + (r0 + 32 * j) * LDS_LD + c4 * 4, live ? v : zero);
+      if constexpr (X6) {
+        put3(xs, r0 + RSTEP * j, live ? v : zero);
+      } else {
+        gs_st4(as + (r0 + RSTEP * j) * LDS_LD + c4 * 4, live ? v : zero);
+      }
     }
 #pragma unroll
     for (int j = 0; j < B_LD4; ++j)
-      if (BN >= 32 * (j + 1) || r0 + 32 * j < BN) gs_st4(bs + (r0 + 32 * j) * LDS_LD + c4 * 4, kok ? rb[j] : zero);
+      if (BN >= RSTEP * (j + 1) || r0 + RSTEP * j < BN) {
+        if constexpr (X6) {
+          put3(xs, BM + r0 + RSTEP * j, kok ? rb[j] : zero);
+        } else {
+          gs_st4(bs + (r0 + RSTEP * j) * LDS_LD + c4 * 4, kok ? rb[j] : zero);
+        }
+      }
   };
 
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
   auto compute = [&](int kt) {
+    if constexpr (X6) {
+      // one k16 step per stage: lane (row frag_row, half h) reads k = 8h .. 8h+7 of its row from each plane
+      const char *xa = reinterpret_cast<const char *>(lds + (kt % kStages) * STAGE) +
+                       (wm * WTM + frag_row) * kX6RowBytes + (lane >> 5) * 16;
+      const char *xb = reinterpret_cast<const char *>(lds + (kt % kStages) * STAGE) +
+                       (BM + wn * WTN + frag_row) * kX6RowBytes + (lane >> 5) * 16;
+      bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          af[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xa + p * PLANE + i * 32 * kX6RowBytes));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          bf[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xb + p * PLANE + j * 32 * kX6RowBytes));
+      // six of the nine cross products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+      constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa[t]], bf[j][pb[t]], acc[i][j], 0, 0, 0);
+      return;
+    }
     const float *as = lds + (kt & 1) * STAGE + (wm * WTM + frag_row) * LDS_LD + frag_k;
     const float *bs = lds + (kt & 1) * STAGE + BM * LDS_LD + (wn * WTN + frag_row) * LDS_LD + frag_k;
 #pragma unroll
@@ -420,12 +509,42 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
     }
   };
 
-  // the big tile cannot afford the second register set (it would halve the waves per SIMD)
-  constexpr bool kDeepPrefetch = BM * BN <= 128 * 64;
   if constexpr (kAffineA) {   // [scale | shift] of the BatchNorm the provider applies: resident for the whole kernel
-    for (int i = tid; i < 2 * ap.k; i += 256) s_aff[i] = i < ap.k ? ap.scale[i] : ap.shift[i - ap.k];
+    for (int i = tid; i < 2 * ap.k; i += NT) s_aff[i] = i < ap.k ? ap.scale[i] : ap.shift[i - ap.k];
     __syncthreads();
   }
+  if constexpr (X6) {
+    // A k16 stage is 24 bf16 MFMAs per wave (~0.3 us): the global loads must run several stages ahead of the matrix
+    // cores to cover an L2 / HBM round trip -- a ring of kRing = 4 register sets, set = stage mod 4.  A stage reads
+    // 64 B of every row, HALF a cache line: the two stages of a line are fetched by back-to-back loads (the second
+    // merges with the first's miss), at every other step, instead of one stage per step -- otherwise the second half
+    // comes back to an L1 that has turned over and every line crosses the L2 interface twice (measured: the kernel
+    // ran at L2 bandwidth).  At odd step t: stages t + 3 and t + 4 into the sets of stages t - 1 and t (both already
+    // split into LDS); stage t + 1 is split into LDS after the step's MFMAs.  Unrolled: set indices are compile-time,
+    // the waitcnt of every stash counts exactly the younger fetches.  Tiles past the end: clamped addresses, zero
+    // data, no MFMAs.
+    constexpr int kRing = 4;
+    typename AProv::Raw rra[kRing][A_LD4];
+    f32x4 rrb[kRing][B_LD4];
+#pragma unroll
+    for (int u = 0; u < kRing; ++u) fetch(u, rra[u], rrb[u]);
+    stash(0, rra[0], rrb[0]);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += kRing) {
+#pragma unroll
+      for (int u = 0; u < kRing; ++u) {
+        if (u & 1) {
+          fetch(kt + u + 3, rra[(u + 3) % kRing], rrb[(u + 3) % kRing]);
+          fetch(kt + u + 4, rra[u], rrb[u]);
+        }
+        if (kt + u < nk) compute(kt + u);
+        stash(kt + u + 1, rra[(u + 1) % kRing], rrb[(u + 1) % kRing]);
+        __syncthreads();
+      }
+    }
+  } else {
+  // the big tile cannot afford the second register set (it would halve the waves per SIMD)
+  constexpr bool kDeepPrefetch = BM * BN <= 128 * 64;
   fetch(0, ra0, rb0);
   stash(0, ra0, rb0);
   if (kDeepPrefetch) fetch(1, ra0, rb0);
@@ -455,6 +574,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
     compute(kt + 1);
     stash(kt + 2, ra1, rb1);
     __syncthreads();
+  }
   }
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31,
@@ -553,124 +673,6 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
       }
     }
   }
-
-  // ---- BatchNorm statistics closed inside the GEMM (bn_fold.hpp): the last workgroup to arrive in a segment of row
-  //      tiles folds that segment's partials (this column block), the last segment-folder folds the segment sums and
-  //      writes scale / shift / saved statistics / running statistics.  Fixed summation order: the same bits as the
-  //      separate k_bn_combine + k_bn_train_apply launches.
-  if constexpr (STATS) {
-    const BnTail &tl = epi.tail;
-    if (tl.enabled) {
-      constexpr int NP = BN / kBnCols;
-      static_assert(NP >= 1 && NP <= 4, "column slabs per workgroup");
-      double *s_a = reinterpret_cast<double *>(lds);            // [NP][8][32] (the staging buffers are dead now)
-      double *s_b = s_a + NP * kBnGroupLanes * kBnCols;
-      __shared__ int s_last;
-      const int cl = tid & (kBnCols - 1), gl = tid / kBnCols;
-      const int ch = n_out;
-      const int64_t groups = (tl.rows + kBnRowsPerGroup - 1) / kBnRowsPerGroup;
-      const int wg_per_seg = (int)(tl.per_seg / WAVES_M);       // per_seg is a multiple of 4 >= WAVES_M
-      const int sgm = (int)(blockIdx.x / wg_per_seg);
-      const int first = sgm * wg_per_seg;
-      const int expected = (int)gridDim.x - first < wg_per_seg ? (int)gridDim.x - first : wg_per_seg;
-      int32_t *seg_ticket = tl.counters + (int64_t)sgm * gridDim.y + blockIdx.y;
-      int32_t *fin_ticket = tl.counters + (int64_t)tl.num_seg * gridDim.y + blockIdx.y;
-      __syncthreads();                                          // every wave's partials are issued; lds is free
-      if (tid == 0)
-        s_last = __hip_atomic_fetch_add(seg_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == expected - 1;
-      __syncthreads();
-      if (!s_last) return;                                      // block-uniform
-      int colc[NP];
-      bool colok[NP];
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int c = n0 + p * kBnCols + cl;
-        colok[p] = c < ch;
-        colc[p] = colok[p] ? c : ch - 1;
-      }
-      {
-        double s1[NP], s2[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) s1[p] = s2[p] = 0.0;
-        const int64_t g_beg = (int64_t)sgm * tl.per_seg;
-        int64_t g_end = g_beg + tl.per_seg;
-        if (g_end > groups) g_end = groups;
-        bn_fold_partials_multi<NP>(epi.stats, g_beg, g_end, tl.rows, ch, colc, gl, s1, s2);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          s_a[(p * kBnGroupLanes + gl) * kBnCols + cl] = s1[p];
-          s_b[(p * kBnGroupLanes + gl) * kBnCols + cl] = s2[p];
-        }
-        __syncthreads();
-        if (gl == 0) {
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            double a = s1[p], b = s2[p];
-            for (int o = 1; o < kBnGroupLanes; ++o) {
-              a += s_a[(p * kBnGroupLanes + o) * kBnCols + cl];
-              b += s_b[(p * kBnGroupLanes + o) * kBnCols + cl];
-            }
-            if (colok[p]) {
-              tl.seg[((int64_t)sgm * 2 + 0) * ch + colc[p]] = a;
-              tl.seg[((int64_t)sgm * 2 + 1) * ch + colc[p]] = b;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      if (tid == 0)
-        s_last = __hip_atomic_fetch_add(fin_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == tl.num_seg - 1;
-      __syncthreads();
-      if (!s_last) return;
-      {
-        double s1[NP], s2[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) s1[p] = s2[p] = 0.0;
-        for (int sg = gl; sg < tl.num_seg; sg += kBnGroupLanes) {
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            s1[p] += __builtin_nontemporal_load(tl.seg + ((int64_t)sg * 2 + 0) * ch + colc[p]);
-            s2[p] += __builtin_nontemporal_load(tl.seg + ((int64_t)sg * 2 + 1) * ch + colc[p]);
-          }
-        }
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          s_a[(p * kBnGroupLanes + gl) * kBnCols + cl] = s1[p];
-          s_b[(p * kBnGroupLanes + gl) * kBnCols + cl] = s2[p];
-        }
-        __syncthreads();
-        if (gl == 0) {
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            double a = s1[p], b = s2[p];
-            for (int o = 1; o < kBnGroupLanes; ++o) {
-              a += s_a[(p * kBnGroupLanes + o) * kBnCols + cl];
-              b += s_b[(p * kBnGroupLanes + o) * kBnCols + cl];
-            }
-            if (!colok[p]) continue;
-            const int c = colc[p];
-            const BnColumn bc = bn_finish_column(a, b, tl.rows, tl.gamma != nullptr ? tl.gamma[c] : 1.f,
-                                                 tl.beta != nullptr ? tl.beta[c] : 0.f, tl.eps);
-            tl.scale[c] = bc.scale;
-            tl.shift[c] = bc.shift;
-            if (tl.save_stat != nullptr) {
-              tl.save_stat[c] = bc.mean;
-              tl.save_stat[ch + c] = bc.rstd;
-            }
-            if (tl.running_mean != nullptr) {
-              tl.running_mean[c] = (1.f - tl.momentum) * tl.running_mean[c] + tl.momentum * bc.mean;
-              tl.running_var[c] = (1.f - tl.momentum) * tl.running_var[c] + tl.momentum * bc.unbiased;
-            }
-            if (tl.nbt != nullptr && c == 0) tl.nbt[0] += 1;
-          }
-        }
-      }
-      // this workgroup is the last to touch its column block's tickets: leave them zero for the next launch that
-      // uses the same counters (the next layer, on the same stream)
-      if (tid < tl.num_seg) tl.counters[(int64_t)tid * gridDim.y + blockIdx.y] = 0;
-      if (tid == 0) *fin_ticket = 0;
-    }
-  }
 }
 
 // --------------------------------------------------------------------------
@@ -694,42 +696,65 @@ static int pick_cfg(int64_t m, int n_out, int k, bool stats) {
   return kCfg64x64;
 }
 
+// GNNSAFT_GEMM_X6 = 0 / 1 (default 1): the f32 matrix-core path, or the split-bf16 path at the same accuracy
+static bool gemm_x6_enabled() {
+  static const bool on = [] {
+    const char *e = getenv("GNNSAFT_GEMM_X6");
+    return e == nullptr || e[0] != '0';
+  }();
+  return on;
+}
+
 template <int BM, int BN, int WM, int WN, class AProv, bool STATS, bool AFFINE, bool RESID>
 static void launch_one(const AProv &ap, int nbatch, const GemmBatch &b, int64_t ldw, int64_t ldo, int64_t m,
-                       int n_out, int k, const EpiArgs &ea, int64_t grid_x, hipStream_t stream) {
+                       int n_out, int k, const EpiArgs &ea, int64_t grid_x, hipStream_t stream, int x6 = -1) {
   if constexpr (STATS && BM / WM != kBnRowsPerGroup) {
     return;  // not instantiated: BatchNorm partials need 64-row wave tiles
   } else {
     const dim3 grid((unsigned)(grid_x > 0 ? grid_x : gs_ceil_div(m, BM)), (unsigned)gs_ceil_div(n_out, BN),
                     (unsigned)nbatch);
-    hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, AProv, STATS, AFFINE, RESID>), grid, dim3(256), 0, stream, ap, b,
-                       ldw, ldo, m, n_out, k, ea);
+    const bool use_x6 = x6 < 0 ? gemm_x6_enabled() : x6 != 0;
+    if (use_x6)
+      hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, AProv, STATS, AFFINE, RESID, true>), grid, dim3(256), 0, stream,
+                         ap, b, ldw, ldo, m, n_out, k, ea);
+    else
+      hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, AProv, STATS, AFFINE, RESID, false>), grid, dim3(256), 0, stream,
+                         ap, b, ldw, ldo, m, n_out, k, ea);
   }
 }
 
 template <class AProv, bool STATS, bool AFFINE, bool RESID>
 static int launch_cfg(const AProv &ap, int nbatch, const GemmBatch &b, int64_t ldw, int64_t ldo, int64_t m, int n_out,
                       int k, const EpiArgs &ea, hipStream_t stream, int cfg = -1, int64_t grid_x = 0) {
-  if (cfg < 0) cfg = pick_cfg(m, n_out, k, STATS);
+  // explicit configurations (tuning / tests): cfg + 16 forces the split-bf16 kernels, cfg + 32 the f32 ones
+  int x6 = -1;
+  if (cfg >= 32) {
+    x6 = 0;
+    cfg -= 32;
+  } else if (cfg >= 16) {
+    x6 = 1;
+    cfg -= 16;
+  }
+  if (cfg < 0 || cfg >= kNumCfg) cfg = pick_cfg(m, n_out, k, STATS);
   GS_REQUIRE(cfg >= 0 && cfg < kNumCfg && (!STATS || kCfgStatsOk[cfg]), GNNSAFT_ERR_UNSUPPORTED);
   switch (cfg) {
     case kCfg256x32:
-      launch_one<256, 32, 4, 1, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream);
+      launch_one<256, 32, 4, 1, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream, x6);
       break;
     case kCfg128x64:
-      launch_one<128, 64, 2, 2, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream);
+      launch_one<128, 64, 2, 2, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream, x6);
       break;
     case kCfg128x128:
-      launch_one<128, 128, 2, 2, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream);
+      launch_one<128, 128, 2, 2, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream, x6);
       break;
     case kCfg64x64:
-      launch_one<64, 64, 2, 2, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream);
+      launch_one<64, 64, 2, 2, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream, x6);
       break;
     case kCfg64x128:
-      launch_one<64, 128, 1, 4, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream);
+      launch_one<64, 128, 1, 4, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream, x6);
       break;
     default:
-      launch_one<128, 32, 4, 1, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream);
+      launch_one<128, 32, 4, 1, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream, x6);
       break;
   }
   GS_CHECK_LAUNCH();
@@ -749,16 +774,7 @@ static int dispatch(const AProv &ap, int nbatch, const GemmBatchEntry *entries, 
     GS_REQUIRE((reinterpret_cast<uintptr_t>(entries[i].w) & 15) == 0, GNNSAFT_ERR_SHAPE);
   }
   EpiArgs ea{epi.scale, epi.shift, epi.relu_out, epi.residual, epi.ldr, epi.stats, epi.residual_is_mask,
-             epi.bn_mean, epi.bn_var, epi.bn_eps, BnTail{}};
-  if (epi.tail != nullptr) {
-    constexpr bool plain = std::is_same<AProv, PlainA>::value;   // (every workgroup of the grid owns rows)
-    const bool tail_ok = epi.stats != nullptr && epi.tail->seg && epi.tail->counters && epi.tail->scale &&
-                         epi.tail->shift && epi.tail->num_seg >= 1 && epi.tail->num_seg <= kBnMaxSegments &&
-                         (epi.tail->per_seg % 4) == 0 && epi.tail->rows == m && plain;
-    GS_REQUIRE(tail_ok, GNNSAFT_ERR_SHAPE);
-    ea.tail = *epi.tail;
-    ea.tail.enabled = 1;
-  }
+             epi.bn_mean, epi.bn_var, epi.bn_eps};
   GS_REQUIRE((epi.bn_var == nullptr) == (epi.bn_mean == nullptr) && (epi.bn_var == nullptr || epi.scale != nullptr),
              GNNSAFT_ERR_NULL);
   GS_REQUIRE((epi.scale == nullptr) == (epi.shift == nullptr), GNNSAFT_ERR_NULL);
@@ -846,7 +862,7 @@ int launch_pna_update_folded(const float *x, const float *agg, const int32_t *pe
   b.e[0] = GemmBatchEntry{w_eff, b_post0, u, 0};
   b.e[1] = GemmBatchEntry{w_eff + per_tower, b_post1, u + hidden / 2, 4 * (int64_t)hidden};
   for (int i = 2; i < kMaxGemmBatch; ++i) b.e[i] = b.e[0];
-  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0.f, BnTail{}};
+  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0.f};
   return launch_cfg<PostFoldA, false, false, false>(ap, 2, b, 5 * (int64_t)hidden, hidden, n, hidden / 2, 5 * hidden,
                                                     ea, stream, tiled_cfg_for(hidden), max_tiles);
 }
@@ -862,7 +878,7 @@ int launch_linear_degree_tiled(const float *a, int64_t lda, const int32_t *perm,
   PermPlainA ap{a, lda, perm, tiles, num_tiles, w_stride, k};
   GemmBatch b;
   for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entries[i < nbatch ? i : 0];
-  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0.f, BnTail{}};
+  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0.f};
   return launch_cfg<PermPlainA, false, false, false>(ap, nbatch, b, ldw, ldo, n, n_out, k, ea, stream,
                                                      tiled_cfg_for(hidden), max_tiles);
 }
@@ -881,7 +897,7 @@ int launch_linear_concat2(const float *a0, int64_t lda0, int k0, const float *a1
   GemmBatch b;
   for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entry;
   EpiArgs ea{nullptr, nullptr, epi.relu_out, epi.residual, epi.ldr, nullptr, epi.residual_is_mask, nullptr, nullptr,
-             0.f, BnTail{}};
+             0.f};
   if (epi.residual != nullptr)
     return launch_cfg<Concat2A, false, false, true>(ap, 1, b, ldw, ldo, m, n_out, k0 + k1, ea, stream);
   return launch_cfg<Concat2A, false, false, false>(ap, 1, b, ldw, ldo, m, n_out, k0 + k1, ea, stream);

@@ -136,9 +136,9 @@ static inline int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, i
     const size_t wgs = (gg + 63) / 64;   // readout.hip: 64 graphs per workgroup
     p.rd_scratch = take(gs_align_up((size_t)p.nb * wgs * 2 * h * 4, 256) + gs_align_up(wgs * 4, 256));
     // barrier / ticket counters zeroed by the prologue launch of every forward: the fused readout's (kRdSyncInts = 16),
-    // then the BatchNorm statistics tail's (kBnTailCounterInts)
+    // then k_bn_stats_close's slab tickets (kBnTailCounterInts)
     p.rd_sync = take((16 + (size_t)kBnTailCounterInts) * 4);
-    p.bn_tail_seg = take((size_t)64 * 2 * h * 8);   // [kBnMaxSegments][2][H] f64 segment sums of the in-GEMM tail
+    p.bn_tail_seg = take((size_t)64 * 2 * h * 8);   // [kBnMaxSegments][2][H] f64 segment sums of k_bn_stats_close
   }
   p.weff = d->fold_degree_scalers ? take(nl * (size_t)kDegreeBuckets * 5 * h * h * 4) : 0;
   p.gfold = d->fold_degree_scalers ? take(nl * 2 * 3 * (h / 2) * h * 8) : 0;   // float64 (fold.hpp)

@@ -489,7 +489,8 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_bwd_fused(ReadoutBwdArgs
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           yh[j] = (y[j] - mean[j]) * rstd[j];
-          dz[j] = (yh[j] * gm[j] + bt[j]) > 0.f ? dv[j] : 0.f;
+          const float sc = rstd[j] * gm[j], sh = bt[j] - mean[j] * sc;   // the gate as the forward took it
+          dz[j] = (y[j] * sc + sh) > 0.f ? dv[j] : 0.f;
         }
       }
       gs_st4(yt + r * ld + c4, yh);

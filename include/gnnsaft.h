@@ -479,6 +479,8 @@ typedef struct gnnsaft_workspace_map {
   size_t total;
   size_t ro;        /* [num_mlp_layers + 2][G, n_out] outputs of the readout's BatchNorm + ReLU blocks (block stride G*H) */
   size_t x_stride;  /* tape (save_tape): x_0 .. x_L contiguous from x_embed, x_stride BYTES apart; 0 without a tape */
+  size_t bnstat;    /* [L][2][H] (batch mean | rstd) of the node BatchNorms, as the backward reads them             */
+  size_t y_stride;  /* tape: BYTES between the pre-BatchNorm tensors y_l of consecutive layers (from `y`); 0 without */
 } gnnsaft_workspace_map;
 
 GNNSAFT_API int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int64_t num_nodes,

@@ -125,12 +125,15 @@ def tape_std_masks(pred: torch.Tensor):
 
 
 def oracle_decisions(model: torch.nn.Module, data, skip: bool):
-    """The discrete decisions of one oracle evaluation (train mode, no grad): per layer the std mask and the ReLU
-    gate of the node update, then the ReLU gates of the readout blocks.  Returns (stages, decisions)."""
+    """The discrete decisions of one oracle evaluation (no grad): per layer the std mask and the ReLU gate of the node
+    update (the sign of the BatchNorm output the ReLU sees), then the ReLU gates of the readout blocks.  Returns
+    (stages, decisions)."""
     stages: Dict[str, torch.Tensor] = {}
-    gates = []
+    gates, node_gates = [], []
     hooks = [m.register_forward_hook(lambda mod, inp, out: gates.append(out.detach() > 0))
              for m in model.mlp.modules() if isinstance(m, torch.nn.ReLU)]
+    hooks += [m.register_forward_hook(lambda mod, inp, out: node_gates.append(out.detach() > 0))
+              for m in model.batch_norms]
     try:
         with torch.no_grad():
             model(data, stages)
@@ -138,21 +141,22 @@ def oracle_decisions(model: torch.nn.Module, data, skip: bool):
         for hk in hooks:
             hk.remove()
     dec = []
-    layer, prev = 0, stages["embed"]
+    layer = 0
     while f"l{layer}.agg" in stages:
         a = stages[f"l{layer}.agg"]
         f = a.shape[-1] // 4
         dec.append(a[..., 3 * f:] > 0)
-        out = stages[f"l{layer}.out"]
-        dec.append(((out - prev) if skip else out) > 0)
-        prev = out
+        dec.append(node_gates[layer])
         layer += 1
     return stages, dec + gates
 
 
 def tape_decisions(pred: torch.Tensor, skip: bool):
-    """The same list of decisions as ``oracle_decisions``, read from the tape of the HIP forward behind ``pred``
-    (std masks from the aggregates, node ReLU gates from x_{l+1} - x_l, readout gates from the block outputs)."""
+    """The same list of decisions as ``oracle_decisions``, read from the tape of the HIP forward behind ``pred``: std
+    masks from the aggregates; node ReLU gates as the kernels take them, relu(y * scale + shift) > 0 with scale = rstd
+    gamma, shift = beta - mean scale in float32 (csrc/bn_fold.hpp; forward and backward use this one expression --
+    x_{l+1} - x_l > 0 would lose a gate whose activation the residual add absorbs); readout gates from the block
+    outputs."""
     import ctypes
 
     from gnn_epc_saft_amd._native import WorkspaceMap, lib
@@ -167,11 +171,16 @@ def tape_decisions(pred: torch.Tensor, skip: bool):
         return tape["ws"][base + off: base + off + 4 * count].view(torch.float32)
 
     agg = tap(wmap.agg, layers * n * 8 * h).view(layers, n, 2, 4 * h)
-    xs = tap(wmap.x_embed, (layers + 1) * n * h).view(layers + 1, n, h)
+    ys = tap(wmap.y, layers * n * h).view(layers, n, h).cpu()
+    stat = tap(wmap.bnstat, layers * 2 * h).view(layers, 2, h).cpu()
+    module = pred.grad_fn.module
     dec = []
     for layer in range(layers):
         dec.append((agg[layer][..., 3 * h:] > 0).cpu())
-        dec.append((((xs[layer + 1] - xs[layer]) if skip else xs[layer + 1]) > 0).cpu())
+        bn = module.batch_norms[layer].module
+        scale = stat[layer, 1] * bn.weight.detach().float().cpu()
+        shift = bn.bias.detach().float().cpu() - stat[layer, 0] * scale
+        dec.append((ys[layer] * scale + shift) > 0)
     widths = [h] * desc.num_mlp_layers + [h // 2, h // 4]
     for b, w in enumerate(widths):
         dec.append((tap(wmap.ro + 4 * b * g * h, g * w).view(g, w) > 0).cpu())

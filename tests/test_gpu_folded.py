@@ -114,14 +114,31 @@ def test_destination_term_fold_matches_oracle_conv(hidden, loops):
     assert float(((std - std64).abs() > 1e-5 * float(std64.max())).float().mean()) < 1e-3
 
 
+@pytest.mark.parametrize("mode", ["split-bf16 (x6)", "f32"])
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
-@pytest.mark.parametrize("m,n_out,k", [(1000, 128, 128), (257, 96, 64), (77, 5, 16)])
-def test_every_gemm_tile_configuration(cfg, m, n_out, k):
+@pytest.mark.parametrize("m,n_out,k", [(1000, 128, 128), (257, 96, 64), (77, 5, 16), (300, 64, 1280), (130, 128, 36)])
+def test_every_gemm_tile_configuration(cfg, m, n_out, k, mode):
+    """Every tile shape in both arithmetic modes of k_gemm_f32 against the f64 product: the f32 matrix-core form
+    (v_mfma_f32_32x32x2_f32: an f32 fma chain) and the split form (every operand = hi + mid + lo in bf16, exactly; six
+    v_mfma_f32_32x32x16_bf16 per k16 step, f32 accumulation) under the SAME bar -- and, printed, next to each other:
+    the split form must be no further from f64 than 1.5x the f32 chain (measured: closer)."""
     torch.manual_seed(cfg * 7 + m)
-    a, w, b = torch.randn(m, k), torch.randn(n_out, k) / math.sqrt(k), torch.randn(n_out)
+    # operands with a wide dynamic range (row scales over three decades) and signs: what the splits must carry exactly
+    a = torch.randn(m, k) * torch.logspace(-1.5, 1.5, m).view(-1, 1)
+    w, b = torch.randn(n_out, k) / math.sqrt(k), torch.randn(n_out)
     ref = a.double() @ w.double().t() + b.double()
-    out = K().linear(a.to(DEV), w.to(DEV), b.to(DEV), tile_config=cfg).cpu()   # per call: no global tuning state
+    row_scale = (a.double().abs() @ w.double().abs().t() + b.double().abs())      # sum |a||w|: the error's own scale
+    run = lambda c: K().linear(a.to(DEV), w.to(DEV), b.to(DEV), tile_config=c).cpu().double()
+    offset = {"split-bf16 (x6)": 16, "f32": 32}[mode]
+    out = run(cfg + offset)      # per call: no global tuning state
+    other = run(cfg + (32 if mode.startswith("split") else 16))
+    err = float(((out - ref).abs() / row_scale).max())
+    err_other = float(((other - ref).abs() / row_scale).max())
+    print(f"cfg {cfg} [{m},{k}]x[{k},{n_out}] {mode}: max |err| / sum|a||w| = {err:.2e} (the other mode: {err_other:.2e})")
     assert rel_err(out, ref) < 2e-6
+    assert err < 4e-7
+    if mode.startswith("split"):
+        assert err <= 1.5 * err_other + 1e-8
 
 
 @pytest.mark.parametrize("rows,ch", [(1000, 128), (63, 64), (20480, 256), (2, 32), (777, 16)])

@@ -167,11 +167,11 @@ def test_shape_envelope_vs_oracle(cfg, mode):
 @pytest.mark.parametrize("cfg", [(64, 2, True, 96), (128, 3, True, 1024), (256, 2, False, 300), (64, 6, True, 3000)],
                          ids=["H64", "C2", "H256-noskip", "default-model-3000"])
 def test_deferred_batchnorm_equals_the_separate_launches_bit_for_bit(cfg):
-    """Train-mode node BatchNorm without launches of its own -- statistics closed by the last-arriving workgroups of
-    the lin GEMM (segment tickets, csrc/bn_fold.hpp), normalisation + ReLU + residual applied on load by the next
-    layer's message GEMM (BnResA) resp. by the pooling kernel -- against k_bn_combine + k_bn_train_apply: the same
-    sums in the same order, so outputs, loss, running statistics and (taped forward) every gradient are EQUAL, whatever
-    workgroup happens to arrive last."""
+    """Train-mode node BatchNorm without an apply pass -- statistics closed by ONE launch (k_bn_stats_close: segment
+    folds, then the last-arriving workgroup of a column slab finalises; csrc/bn_fold.hpp), normalisation + ReLU +
+    residual applied on load by the next layer's message GEMM (BnResA) resp. by the pooling kernel -- against
+    k_bn_combine + k_bn_train_apply: the same sums in the same order, so outputs, loss, running statistics and (taped
+    forward) every gradient are EQUAL, whatever workgroup happens to arrive last."""
     from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
     from gnn_epc_saft_amd.train.models import mape_loss
     hidden, depth, skip, graphs = cfg

@@ -61,14 +61,15 @@ def main():
         }
         print(f"== {name}: N={n} H={h}")
         for sname, fn in shapes.items():
-            row = []
-            for cfg in range(6):        # explicit tile configuration per call (gnnsaft_debug_linear_tile)
-                try:
-                    row.append(min(timeit(lambda: fn(cfg)) for _ in range(3)))
-                except Exception:
-                    row.append(float("nan"))
-            row.append(min(timeit(lambda: fn(None)) for _ in range(3)))
-            print(f"  {sname:26s} " + " ".join(f"{c}:{t:7.1f}" for c, t in zip(CFG_NAMES + ["auto"], row)))
+            for mode, off in (("f32", 32), ("x6 ", 16)):   # + 32: f32 matrix cores, + 16: split-bf16 (gemm.hip)
+                row = []
+                for cfg in range(6):        # explicit tile configuration per call (gnnsaft_debug_linear_tile)
+                    try:
+                        row.append(min(timeit(lambda: fn(cfg + off)) for _ in range(3)))
+                    except Exception:
+                        row.append(float("nan"))
+                row.append(min(timeit(lambda: fn(None)) for _ in range(3)))
+                print(f"  {sname:26s} {mode} " + " ".join(f"{c}:{t:7.1f}" for c, t in zip(CFG_NAMES + ["auto"], row)))
         perm, tiles, nt, hist3, _ = K.degree_tiles(rowptr, h)
         fn = lambda: K.pna_update_folded(x, agg, perm, tiles, nt, hist3, avg, w_post[0], b_post[0], w_post[1], b_post[1])
         print(f"  {'update folded K=5H (+fold)':26s} auto:{min(timeit(fn) for _ in range(3)):7.1f}")
