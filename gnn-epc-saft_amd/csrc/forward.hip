@@ -616,8 +616,13 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
 
   const bool tape = d->save_tape != 0;
   float *xc = F(p.x0), *xn = tape ? F(p.x0) + p.sx : F(p.x1);
-  // train-mode node BatchNorm without launches of its own (linear_bn_relu / NodeState)
-  const bool bn_deferred = d->training && !d->unfused_bn_apply && h <= 256 && (h % 32) == 0;
+  // train-mode node BatchNorm applied by whoever reads the layer's output (linear_bn_relu / NodeState).
+  // desc->unfused_bn_apply: 0 = the LAST layer only (applied by the pooling kernel on load: one pass over y instead of
+  // an apply pass writing x_L and a pooling pass reading it -- measured faster at every size); 2 = every layer (the
+  // next layer's message GEMM applies it on load: measured SLOWER than the apply launch it saves once the GEMMs run
+  // on the bf16 pipe, +8 us per layer at C2, +50 us at C3: the GEMM's operand path is its bottleneck); 1 = never.
+  const bool bn_all = d->training && d->unfused_bn_apply == 2 && h <= 256 && (h % 32) == 0;
+  const bool bn_last = d->training && d->unfused_bn_apply != 1;
   NodeState state;
   for (int l = 0; l < d->num_layers; ++l) {
     if (state.y == nullptr) state.x = xc;   // (otherwise x_l is still pending: formed by this layer's message GEMM)
@@ -701,6 +706,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
       ub = t;
     }
     // lin -> BatchNorm -> ReLU -> (+ x)
+    const bool bn_deferred = bn_all || (bn_last && l == d->num_layers - 1);
     GS_TRY(linear_bn_relu(ua, h, wlin, blin, n, h, h, bn, d, ws, p, y_l, d->skip_connections ? xc : nullptr, xn, st,
                           prof, F(p.bnstat) + (int64_t)l * 2 * h, bn_deferred));
     if (bn_deferred) {   // x_{l+1} = relu(y_l scale + shift) (+ x_l): formed by whoever reads it next

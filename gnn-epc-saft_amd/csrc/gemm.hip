@@ -96,6 +96,10 @@ struct PlainA {
     v.w = (r & (v.w < 0.f)) ? 0.f : v.w;
     return (k0 + c < k) ? v : zero;
   }
+  // K % 16 == 0: no tail to zero; the ReLU-on-load select only when asked for (wave-uniform branch)
+  __device__ __forceinline__ f32x4 finish_full(const Raw &w, const Row &, int, int) const {
+    return relu != 0 ? gs_relu4(w.v) : w.v;
+  }
 };
 
 struct PostA {
@@ -132,6 +136,9 @@ struct PostA {
     const float s = j < 4 * f ? 1.f : (j < 8 * f ? r.amp : r.att);  // identity | amplification | attenuation
     return w.v * s;                                                 // x * 1.0f is exact
   }
+  __device__ __forceinline__ f32x4 finish_full(const Raw &w, const Row &r, int k0, int c) const {
+    return finish(w, r, k0, c);
+  }
 };
 
 struct EdgeA {
@@ -162,6 +169,9 @@ struct EdgeA {
   }
   __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &, int, int) const {
     return gs_relu4((w.a + w.b) + w.t);
+  }
+  __device__ __forceinline__ f32x4 finish_full(const Raw &w, const Row &r, int k0, int c) const {
+    return finish(w, r, k0, c);
   }
 };
 
@@ -204,9 +214,9 @@ struct BnResA {
     f32x4 v = gs_relu4(w.y * sc + sh);      // the arithmetic of k_bn_train_apply: mul, add, max, add
     if (xprev != nullptr) v = v + w.x;
     // side output: the gridDim.y * gridDim.z workgroups of a row tile all stage the whole row tile; k-tile kt is
-    // written by workgroup kt mod their number (k in steps of 16; one writer per element, the store traffic spread over all of them)
+    // written by workgroup kt mod their number (k in steps of 32: a full 128-B line per row and writer; one writer per element, the stores spread over all)
     const unsigned writers = gridDim.y * gridDim.z, me = blockIdx.y + gridDim.y * blockIdx.z;
-    if (r.po != nullptr && (unsigned)(k0 >> 4) % writers == me) gs_st4(r.po + k0 + c, v);
+    if (r.po != nullptr && (unsigned)(k0 >> 5) % writers == me) gs_st4(r.po + k0 + c, v);
     return v;
   }
 };
@@ -238,6 +248,7 @@ struct Concat2A {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     return (kt0 + c < k) ? w.v : zero;
   }
+  __device__ __forceinline__ f32x4 finish_full(const Raw &w, const Row &, int, int) const { return w.v; }
 };
 
 // Degree-folded PNAConv update: rows are grouped by in-degree (tile table from csr.hip), so
@@ -274,6 +285,7 @@ struct PostFoldA {
     return Raw{gs_ld4(p + c)};
   }
   __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &, int, int) const { return w.v; }
+  __device__ __forceinline__ f32x4 finish_full(const Raw &w, const Row &, int, int) const { return w.v; }
 };
 
 // Plain rows addressed through the degree permutation, weights selected per degree tile (backward of
@@ -309,6 +321,7 @@ struct PermPlainA {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     return (k0 + c < k) ? w.v : zero;
   }
+  __device__ __forceinline__ f32x4 finish_full(const Raw &w, const Row &, int, int) const { return w.v; }
 };
 
 // --------------------------------------------------------------------------
@@ -426,19 +439,24 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
     *reinterpret_cast<uint2 *>(p + PLANE) = uint2{gs_pack_hi16(md[0], md[1]), gs_pack_hi16(md[2], md[3])};
     *reinterpret_cast<uint2 *>(p + 2 * PLANE) = uint2{gs_pack_hi16(l[0], l[1]), gs_pack_hi16(l[2], l[3])};
   };
-  auto stash = [&](int kt, const typename AProv::Raw(&ra)[A_LD4], const f32x4(&rb)[B_LD4]) {
+  // `fast` (a std::bool_constant): the caller guarantees a live tile and K % KT == 0 -- no zero-fill selects
+  auto stash_impl = [&](auto fast, int kt, const typename AProv::Raw(&ra)[A_LD4], const f32x4(&rb)[B_LD4]) {
+    constexpr bool kFast = decltype(fast)::value;
     float *as = lds + (kt % kStages) * STAGE;
     float *bs = as + BM * LDS_LD;
     char *xs = reinterpret_cast<char *>(lds + (kt % kStages) * STAGE);   // X6: plane 0, A rows then B rows
-    const bool live = kt < nk;
+    // (a provider with a side output -- BnResA writes x_{l+1} -- must not run on the tile one past the end)
+    const bool live = (kFast && !kAffineA) || kt < nk;
     const int k0 = (live ? kt : nk - 1) * KT;
-    const bool kok = live && k0 + c4 * 4 < k;
+    const bool kok = kFast || (live && k0 + c4 * 4 < k);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < A_LD4; ++j) {
       f32x4 v;
       if constexpr (kAffineA) {
         v = live ? ap.finish(ra[j], arow[j], k0, c4 * 4, s_aff) : zero;   // (side output only for real tiles)
+      } else if constexpr (kFast) {
+        v = ap.finish_full(ra[j], arow[j], k0, c4 * 4);                     // no K tail to zero
       } else {
         v = ap.finish(ra[j], arow[j], k0, c4 * 4);
       }
@@ -457,6 +475,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
           gs_st4(bs + (r0 + RSTEP * j) * LDS_LD + c4 * 4, kok ? rb[j] : zero);
         }
       }
+  };
+  auto stash = [&](int kt, const typename AProv::Raw(&ra)[A_LD4], const f32x4(&rb)[B_LD4]) {
+    stash_impl(std::false_type{}, kt, ra, rb);
   };
 
   const int frag_row = lane & 31;
@@ -524,13 +545,42 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
     // the waitcnt of every stash counts exactly the younger fetches.  Tiles past the end: clamped addresses, zero
     // data, no MFMAs.
     constexpr int kRing = 4;
+    constexpr int kValuPerMfma = (32 * (A_LD4 + B_LD4) + 6 * TM * TN - 1) / (6 * TM * TN);   // ~32 VALU per staged float4
     typename AProv::Raw rra[kRing][A_LD4];
     f32x4 rrb[kRing][B_LD4];
 #pragma unroll
     for (int u = 0; u < kRing; ++u) fetch(u, rra[u], rrb[u]);
     stash(0, rra[0], rrb[0]);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += kRing) {
+    // Inside a step the wave's own MFMAs (24 per k16 stage at a 64 x 64 wave tile, 32 cycles each, only 8 of which
+    // hold the vector issue port) and its staging work for the next stage (~100 VALU, the LDS writes) are independent:
+    // asked to (sched_group_barrier), the scheduler interleaves them -- one MFMA, a handful of VALU -- instead of 24
+    // MFMAs with an idle VALU followed by the split with an idle matrix core.
+    // full ring trips: every tile live, no branch inside the step; with K % 16 == 0 (every op of the network) also
+    // no zero-fill selects in the staging path -- the split's VALU work is what paces this kernel (measured: 225 VALU
+    // per wave and stage against 24 MFMAs; 2 waves per SIMD issue-bound at 46 % matrix-core occupancy)
+    const int nk_main = (k % KT) == 0 ? nk - nk % kRing : 0;
+    for (int kt = 0; kt < nk_main; kt += kRing) {
+#pragma unroll
+      for (int u = 0; u < kRing; ++u) {
+        if (u & 1) {
+          fetch(kt + u + 3, rra[(u + 3) % kRing], rrb[(u + 3) % kRing]);
+          fetch(kt + u + 4, rra[u], rrb[u]);
+        }
+        compute(kt + u);
+        // (the tile one past the end is "staged" too: finite garbage in an LDS buffer nobody reads)
+        stash_impl(std::true_type{}, kt + u + 1, rra[(u + 1) % kRing], rrb[(u + 1) % kRing]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);        // fragment reads first
+#pragma unroll
+        for (int q = 0; q < 6 * TM * TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA ...
+          __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);       // ... then a share of the split
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 3 * (A_LD4 + B_LD4), 0);  // LDS writes of the next stage
+        __syncthreads();
+      }
+    }
+    for (int kt = nk_main; kt < nk; kt += kRing) {   // (K not a multiple of 64: at most one trip, guarded)
 #pragma unroll
       for (int u = 0; u < kRing; ++u) {
         if (u & 1) {

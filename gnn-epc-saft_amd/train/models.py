@@ -180,10 +180,11 @@ class PNAPCSAFT(nn.Module):
         # add-pool -> readout MLP (train-mode BatchNorm across the batch through a grid barrier) -> MAPE in ONE launch
         # (csrc/readout.hip) for up to 16 384 graphs; False restores the nine per-op launches
         self.fused_readout = True
-        # train-mode node BatchNorm without its own launches: statistics closed by the last-arriving workgroups of the
-        # lin GEMM, normalisation + ReLU + residual applied while the next layer's message GEMM (resp. the pooling)
-        # stages its operand; False restores k_bn_combine + k_bn_train_apply (same bits)
-        self.fused_batchnorm = True
+        # train-mode node BatchNorm: "pool" (default) = combine + apply launches, but the LAST layer's normalisation +
+        # ReLU + residual is applied by the pooling kernel while it loads y (no x_L round trip); True = every layer's
+        # applied on load by the next layer's message GEMM (measured slower: the GEMM's operand path is its
+        # bottleneck); False = combine + apply everywhere.  All three give the same bits.
+        self.fused_batchnorm = "pool"
         self._debug_barrier_extra = 0   # tests only: make the fused readout's grid barriers time out
         # Per-graph fused kernel (csrc/graph_eval.hip: one workgroup per molecule, whole network in one launch):
         # always for float64 modules; for float32 in eval mode without autograd when the input has at most this many
@@ -270,7 +271,7 @@ class PNAPCSAFT(nn.Module):
         d.fold_dst_term = int(self.fold_dst_term)
         d.unfused_readout = int(not self.fused_readout)
         d.debug_barrier_extra = int(self._debug_barrier_extra)
-        d.unfused_bn_apply = int(not self.fused_batchnorm)
+        d.unfused_bn_apply = {"pool": 0, True: 2, False: 1}[self.fused_batchnorm]
         return d
 
     def _check_mode(self, x: torch.Tensor) -> None:

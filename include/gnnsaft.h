@@ -320,8 +320,9 @@ typedef struct gnnsaft_model_desc {
                                /* more than there are workgroups, i.e. time out (flag + NaN outputs)                */
   float readout_dropout;       /* p of the readout MLP's Dropout layers (models.py:88,95,99); applied in training  */
   uint64_t dropout_seed;       /* Philox key of this call's dropout masks (the backward regenerates them from it)   */
-  int32_t unfused_bn_apply;    /* 1: train-mode node BatchNorm as separate combine / apply launches instead of the   */
-                               /* statistics tail inside the lin GEMM + apply-on-load in the next message GEMM      */
+  int32_t unfused_bn_apply;    /* train-mode node BatchNorm: 0 = combine + apply launches, except the LAST layer, whose */
+                               /* normalisation the pooling kernel applies on load; 1 = combine + apply everywhere; */
+                               /* 2 = statistics closed in one launch and applied on load by the next message GEMM  */
   int32_t reserved0;
 } gnnsaft_model_desc;
 

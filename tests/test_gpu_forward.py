@@ -179,7 +179,7 @@ def test_deferred_batchnorm_equals_the_separate_launches_bit_for_bit(cfg):
     oracle = oracle_model(hidden, depth, 1, 1, 1, 3, skip, True, degree_histogram(data), seed=4).train()
     dd, tgt = data.to(DEV), data.para.view(-1, 3).to(DEV)
     res = {}
-    for fused in (True, False):
+    for fused in (True, False, "pool"):
         hip = hip_twin(copy.deepcopy(oracle))
         hip.fused_batchnorm = fused
         with torch.no_grad():
@@ -192,12 +192,13 @@ def test_deferred_batchnorm_equals_the_separate_launches_bit_for_bit(cfg):
         res[fused] = (pred.clone(), loss3.clone(), out.detach().clone(),
                       {k: v.detach().clone() for k, v in hip.state_dict().items()},
                       {k: p.grad.detach().clone() for k, p in hip.named_parameters()})
-    a, b = res[True], res[False]
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
-    for k in a[3]:
-        assert torch.equal(a[3][k], b[3][k]), k
-    for k in a[4]:
-        assert torch.equal(a[4][k], b[4][k]), k
+    for other in (False, "pool"):
+        a, b = res[True], res[other]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        for k in a[3]:
+            assert torch.equal(a[3][k], b[3][k]), (other, k)
+        for k in a[4]:
+            assert torch.equal(a[4][k], b[4][k]), (other, k)
 
 
 def test_zero_crossing_case_behind_the_coarse_gate():
