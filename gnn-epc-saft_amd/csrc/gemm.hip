@@ -65,10 +65,10 @@ __device__ __forceinline__ TileInfo gs_plain_tile(int bx, int bm, int64_t m) {
   return TileInfo{row0, (int)(left < bm ? left : bm), 0};
 }
 
-struct PlainA {
+template <bool RELU>
+struct PlainAT {
   const float *a;
   int64_t lda;
-  int relu;
   int64_t m;
   int k;
   struct Row {
@@ -86,21 +86,16 @@ struct PlainA {
   }
   __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &, int k0, int c) const {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    // per-lane select, not `relu ? f(v) : v`: a wave-uniform condition becomes a scalar branch, and a branch in
-    // the staging path hides the outstanding-load count from the s_waitcnt insertion
-    const bool r = relu != 0;
-    f32x4 v = w.v;
-    v.x = (r & (v.x < 0.f)) ? 0.f : v.x;
-    v.y = (r & (v.y < 0.f)) ? 0.f : v.y;
-    v.z = (r & (v.z < 0.f)) ? 0.f : v.z;
-    v.w = (r & (v.w < 0.f)) ? 0.f : v.w;
+    const f32x4 v = RELU ? gs_relu4(w.v) : w.v;
     return (k0 + c < k) ? v : zero;
   }
-  // K % 16 == 0: no tail to zero; the ReLU-on-load select only when asked for (wave-uniform branch)
+  // K % 16 == 0: no tail to zero
   __device__ __forceinline__ f32x4 finish_full(const Raw &w, const Row &, int, int) const {
-    return relu != 0 ? gs_relu4(w.v) : w.v;
+    return RELU ? gs_relu4(w.v) : w.v;
   }
 };
+using PlainA = PlainAT<false>;       // a row-major matrix
+using PlainReluA = PlainAT<true>;    // ... with ReLU on load (the extra pre / post layers' inputs)
 
 struct PostA {
   const float *x;        // [N,F]
@@ -347,10 +342,11 @@ __device__ __forceinline__ uint32_t gs_pack_hi16(uint32_t x0, uint32_t x1) { ret
 
 constexpr int kX6RowBytes = 48;   // 16 bf16 + 16 B of padding: 12 dwords = 4 x odd -> conflict-free b128 fragment reads
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, class AProv, bool STATS, bool AFFINE, bool RESID, bool X6 = false>
-__global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int64_t ldw, int64_t ldo, int64_t m,
+template <int BM, int BN, int WAVES_M, int WAVES_N, class AProv, bool STATS, bool AFFINE, bool RESID, bool X6 = false,
+          int NT = 256>
+__global__ __launch_bounds__(NT) void k_gemm_f32(AProv ap, GemmBatch batch, int64_t ldw, int64_t ldo, int64_t m,
                                                    int n_out, int k, EpiArgs epi) {
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(WAVES_M * WAVES_N * 64 == NT, "one wave per 64 threads");
   constexpr int WTM = BM / WAVES_M;
   constexpr int WTN = BN / WAVES_N;
   static_assert(!STATS || WTM == kBnRowsPerGroup, "BatchNorm partials assume 64 rows per wave");
@@ -359,9 +355,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   static_assert(TM >= 1 && TN >= 1, "wave tile is a multiple of the 32x32 MFMA");
   constexpr int KT = X6 ? 16 : BK;          // k per LDS stage
   constexpr int QPR = KT / 4;                // float4 per staged row
-  constexpr int RSTEP = 256 / QPR;           // rows covered by one pass of the 256 threads
-  constexpr int A_LD4 = BM * QPR / 256;
-  constexpr int B_LD4 = (BN * QPR + 255) / 256;
+  constexpr int RSTEP = NT / QPR;            // rows covered by one pass of the NT threads
+  constexpr int A_LD4 = BM * QPR / NT;
+  constexpr int B_LD4 = (BN * QPR + NT - 1) / NT;
+  static_assert(A_LD4 >= 1 && (BM * QPR) % NT == 0, "the A tile is a whole number of passes");
   // f32: rows of 36 floats; X6: three planes of 48-B rows -- 144 B per row and stage either way
   constexpr int STAGE = (BM + BN) * LDS_LD;
   static_assert(3 * kX6RowBytes == LDS_LD * 4, "both LDS formats spend 144 B per row and stage");
@@ -371,7 +368,6 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
   // this form: with the MFMAs removed its staging waves alone took 270 us, with the staging removed its MFMA waves
   // 192 us (53 % of the matrix-core rate) -- both sides are bound by their own load -> use latency chains, which
   // two mixed waves per SIMD hide better than one wave of each kind.)
-  constexpr int NT = 256;
   constexpr int kStages = 2;
   __shared__ __attribute__((aligned(16))) float lds[kStages * STAGE];
   constexpr bool kAffineA = provider_needs_affine<AProv>::value;
@@ -689,16 +685,18 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      int64_t grow[16];
+      // element indices in 32 bits (the launcher checks rows * ld < 2^31): a 64-bit multiply per stored element was
+      // a third of this kernel's VALU instructions at K = 256, and VALU issue time adds to the matrix cores' here
+      uint32_t grow[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int lr = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        grow[r] = ap.out_row(ti, lr < ti.count ? lr : ti.count - 1);
+        grow[r] = (uint32_t)ap.out_row(ti, lr < ti.count ? lr : ti.count - 1);
       }
       float res[16];
       if (RESID) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) res[r] = epi.residual[grow[r] * epi.ldr + colc];
+        for (int r = 0; r < 16; ++r) res[r] = epi.residual[grow[r] * (uint32_t)epi.ldr + (uint32_t)colc];
       }
       float v[16];
 #pragma unroll
@@ -713,12 +711,12 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
       // tiles (all but the last row / column tile) take the unguarded path: 16 stores issued back to back.
       if (full_tile) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ent.out[grow[r] * ldo + col] = v[r];
+        for (int r = 0; r < 16; ++r) ent.out[grow[r] * (uint32_t)ldo + (uint32_t)col] = v[r];
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int lr = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (lr < ti.count && col_ok) ent.out[grow[r] * ldo + col] = v[r];
+          if (lr < ti.count && col_ok) ent.out[grow[r] * (uint32_t)ldo + (uint32_t)col] = v[r];
         }
       }
     }
@@ -732,17 +730,22 @@ __global__ __launch_bounds__(256) void k_gemm_f32(AProv ap, GemmBatch batch, int
 // latency- and quantisation-bound rather than operand-bandwidth-bound (f32 MFMA is 16x slower
 // than bf16 per FLOP), so small tiles with more resident waves win; see DESIGN.md.
 enum GemmCfg { kCfg256x32 = 0, kCfg128x64 = 1, kCfg128x128 = 2, kCfg64x64 = 3, kCfg64x128 = 4, kCfg128x32 = 5,
-               kNumCfg = 6 };
-static const int kCfgBM[kNumCfg] = {256, 128, 128, 64, 64, 128};
-static const bool kCfgStatsOk[kNumCfg] = {true, true, true, false, true, false};
+               kCfg128x128w8 = 6 /* 8 waves of 64 x 32: split-bf16 mode only */, kNumCfg = 7 };
+static const int kCfgBM[kNumCfg] = {256, 128, 128, 64, 64, 128, 128};
+static const bool kCfgStatsOk[kNumCfg] = {true, true, true, false, true, false, true};
+
+static bool gemm_x6_enabled();
 
 static int pick_cfg(int64_t m, int n_out, int k, bool stats) {
-  // measured on MI355X (tools/gemm_tune.py, profiles/r01_gemm_tile_sweep.txt)
+  // measured on MI355X (tools/gemm_tune.py, tools/gemm_one.py; profiles/r01_gemm_tile_sweep.txt, r03_gemm_*)
   if (n_out <= 32) return stats ? kCfg256x32 : kCfg128x32;
+  // enough rows that the big tile's lower operand traffic wins (C3: 164 k rows); in split-bf16 mode with 8 waves of
+  // 64 x 32 (four waves per SIMD hide more of the staging latency than two: 3-9 % on the C3 shapes)
+  const int big = gemm_x6_enabled() ? kCfg128x128w8 : kCfg128x128;
   // stats tiles have 64-row waves; up to ~40k rows the 64-row workgroups of 64x128 spread over more CUs than 128x128
-  if (stats) return n_out <= 64 ? kCfg128x64 : (m < 40000 ? kCfg64x128 : kCfg128x128);
-  // long-K update at H = 256, or enough rows that the big tile's lower launch count wins (C3: 164 k rows)
-  if (n_out >= 128 && (k >= 1024 || m >= 65536)) return kCfg128x128;
+  if (stats) return n_out <= 64 ? kCfg128x64 : (m < 40000 ? kCfg64x128 : big);
+  // long-K update at H = 256, or many rows
+  if (n_out >= 128 && (k >= 1024 || m >= 65536)) return big;
   return kCfg64x64;
 }
 
@@ -755,7 +758,7 @@ static bool gemm_x6_enabled() {
   return on;
 }
 
-template <int BM, int BN, int WM, int WN, class AProv, bool STATS, bool AFFINE, bool RESID>
+template <int BM, int BN, int WM, int WN, class AProv, bool STATS, bool AFFINE, bool RESID, int NT = 256>
 static void launch_one(const AProv &ap, int nbatch, const GemmBatch &b, int64_t ldw, int64_t ldo, int64_t m,
                        int n_out, int k, const EpiArgs &ea, int64_t grid_x, hipStream_t stream, int x6 = -1) {
   if constexpr (STATS && BM / WM != kBnRowsPerGroup) {
@@ -764,7 +767,10 @@ static void launch_one(const AProv &ap, int nbatch, const GemmBatch &b, int64_t 
     const dim3 grid((unsigned)(grid_x > 0 ? grid_x : gs_ceil_div(m, BM)), (unsigned)gs_ceil_div(n_out, BN),
                     (unsigned)nbatch);
     const bool use_x6 = x6 < 0 ? gemm_x6_enabled() : x6 != 0;
-    if (use_x6)
+    if constexpr (NT != 256) {
+      hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, AProv, STATS, AFFINE, RESID, true, NT>), grid, dim3(NT), 0, stream,
+                         ap, b, ldw, ldo, m, n_out, k, ea);
+    } else if (use_x6)
       hipLaunchKernelGGL((k_gemm_f32<BM, BN, WM, WN, AProv, STATS, AFFINE, RESID, true>), grid, dim3(256), 0, stream,
                          ap, b, ldw, ldo, m, n_out, k, ea);
     else
@@ -803,6 +809,10 @@ static int launch_cfg(const AProv &ap, int nbatch, const GemmBatch &b, int64_t l
     case kCfg64x128:
       launch_one<64, 128, 1, 4, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream, x6);
       break;
+    case kCfg128x128w8:
+      launch_one<128, 128, 2, 4, AProv, STATS, AFFINE, RESID, 512>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x,
+                                                                   stream, x6);
+      break;
     default:
       launch_one<128, 32, 4, 1, AProv, STATS, AFFINE, RESID>(ap, nbatch, b, ldw, ldo, m, n_out, k, ea, grid_x, stream, x6);
       break;
@@ -816,6 +826,8 @@ static int dispatch(const AProv &ap, int nbatch, const GemmBatchEntry *entries, 
                     int n_out, int k, const LinearEpilogue &epi, hipStream_t stream, int cfg = -1) {
   GS_REQUIRE(nbatch >= 1 && nbatch <= kMaxGemmBatch, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(m >= 0 && n_out >= 1 && k >= 4 && (k % 4) == 0 && (ldw % 4) == 0, GNNSAFT_ERR_SHAPE);
+  // the epilogue indexes `out` / `residual` with 32-bit element offsets (row * ld + column)
+  GS_REQUIRE(ldo >= 0 && epi.ldr >= 0 && (m + 1) * (ldo > epi.ldr ? ldo : epi.ldr) < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);
   if (m == 0) return GNNSAFT_OK;
   GemmBatch b;
   for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entries[i < nbatch ? i : 0];
@@ -849,7 +861,12 @@ int launch_linear(const float *a, int64_t lda, int relu_in, int nbatch, const Ge
                   int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi, hipStream_t stream, int cfg) {
   GS_REQUIRE(a != nullptr, GNNSAFT_ERR_NULL);
   GS_REQUIRE((lda % 4) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0, GNNSAFT_ERR_SHAPE);
-  PlainA ap{a, lda, relu_in, m, k};
+  if (relu_in) {
+    PlainReluA ap{a, lda, m, k};
+    GS_REQUIRE(epi.stats == nullptr && epi.scale == nullptr && epi.residual == nullptr, GNNSAFT_ERR_UNSUPPORTED);
+    return dispatch<PlainReluA, false>(ap, nbatch, entries, ldw, ldo, m, n_out, k, epi, stream, cfg);
+  }
+  PlainA ap{a, lda, m, k};
   return dispatch<PlainA, true>(ap, nbatch, entries, ldw, ldo, m, n_out, k, epi, stream, cfg);
 }
 
@@ -906,6 +923,7 @@ int launch_pna_update_folded(const float *x, const float *agg, const int32_t *pe
   GS_REQUIRE(x && agg && perm && tiles && num_tiles && w_eff && u, GNNSAFT_ERR_NULL);
   GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
   if (n == 0) return GNNSAFT_OK;
+  GS_REQUIRE((n + 1) * (int64_t)hidden < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);   // 32-bit epilogue offsets
   const int64_t per_tower = (int64_t)(hidden / 2) * 5 * hidden;
   PostFoldA ap{x, agg, perm, tiles, num_tiles, 2 * per_tower, hidden};
   GemmBatch b;
@@ -925,6 +943,7 @@ int launch_linear_degree_tiled(const float *a, int64_t lda, const int32_t *perm,
   GS_REQUIRE(nbatch >= 1 && nbatch <= kMaxGemmBatch && (k % 4) == 0 && (ldw % 4) == 0 && (lda % 4) == 0,
              GNNSAFT_ERR_SHAPE);
   if (n == 0) return GNNSAFT_OK;
+  GS_REQUIRE((n + 1) * ldo < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);   // 32-bit epilogue offsets
   PermPlainA ap{a, lda, perm, tiles, num_tiles, w_stride, k};
   GemmBatch b;
   for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entries[i < nbatch ? i : 0];
@@ -944,6 +963,7 @@ int launch_linear_concat2(const float *a0, int64_t lda0, int k0, const float *a1
   GS_REQUIRE(epi.stats == nullptr && epi.scale == nullptr, GNNSAFT_ERR_UNSUPPORTED);
   GS_REQUIRE(entry.w != nullptr && entry.out != nullptr && (ldw % 4) == 0 && m >= 0 && n_out >= 1, GNNSAFT_ERR_SHAPE);
   if (m == 0) return GNNSAFT_OK;
+  GS_REQUIRE((m + 1) * (ldo > epi.ldr ? ldo : epi.ldr) < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);   // 32-bit epilogue offsets
   GemmBatch b;
   for (int i = 0; i < kMaxGemmBatch; ++i) b.e[i] = entry;
   EpiArgs ea{nullptr, nullptr, epi.relu_out, epi.residual, epi.ldr, nullptr, epi.residual_is_mask, nullptr, nullptr,

@@ -115,7 +115,7 @@ def test_destination_term_fold_matches_oracle_conv(hidden, loops):
 
 
 @pytest.mark.parametrize("mode", ["split-bf16 (x6)", "f32"])
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("m,n_out,k", [(1000, 128, 128), (257, 96, 64), (77, 5, 16), (300, 64, 1280), (130, 128, 36)])
 def test_every_gemm_tile_configuration(cfg, m, n_out, k, mode):
     """Every tile shape in both arithmetic modes of k_gemm_f32 against the f64 product: the f32 matrix-core form
