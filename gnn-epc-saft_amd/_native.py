@@ -45,7 +45,7 @@ class WorkspaceMap(ctypes.Structure):
 
     _fields_ = [(n, c_size_t) for n in (
         "rowptr", "src", "dst", "combo", "log_amp", "log_att", "graph_ptr", "x_embed", "x_final", "pq", "agg", "u",
-        "y", "rtab", "pooled", "total", "ro", "x_stride", "bnstat", "y_stride")]
+        "y", "rtab", "pooled", "total", "ro", "x_stride", "bnstat", "y_stride", "ry", "rstat")]
 
 
 P = c_void_p

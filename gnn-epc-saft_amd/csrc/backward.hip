@@ -857,6 +857,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     GS_TRY(push({pw.readout[nb].w, w3T, pw.readout[nb].n_in, 8, P, pw.readout[nb].n_in}));  // W3^T, 8 columns
     GS_TRY(flush());
   }
+  GS_REQUIRE(rb_fused || !(d->training && d->readout_dropout > 0.f), GNNSAFT_ERR_UNSUPPORTED);   // dropout: fused only
   if (rb_fused) {
     // one launch for the whole readout (readout.hip: k_readout_bwd_fused) + one reduction of its per-workgroup partial
     // weight gradients
@@ -889,6 +890,8 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     rp.sync = rb_sync;
     rp.err = err_flag;   // a lost barrier raises GNNSAFT_FLAG_BARRIER_TIMEOUT and poisons the gradients with NaN
     rp.barrier_extra = d->debug_barrier_extra;
+    rp.dropout_p = d->training ? d->readout_dropout : 0.f;
+    rp.dropout_seed = d->dropout_seed;
     GS_TRY(launch_readout_bwd_fused(rp, sq, st));
     GS_TRY(launch_slab_queue_flush(sq, st));
   } else {

@@ -368,6 +368,8 @@ extern "C" int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int
   map->x_stride = (size_t)p.sx * 4;
   map->bnstat = p.bnstat;
   map->y_stride = (size_t)p.sy * 4;
+  map->ry = p.ry;
+  map->rstat = p.rstat;
   return GNNSAFT_OK;
 }
 
@@ -767,9 +769,12 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     rp.sync = I(p.rd_sync);
     rp.err = err_flag;
     rp.barrier_extra = d->debug_barrier_extra;
+    rp.dropout_p = d->readout_dropout;
+    rp.dropout_seed = d->dropout_seed;
     return launch_readout_fused(rp, st);
   }
-  // ---- readout
+  // ---- readout (per-op: no dropout kernel here -- the one-launch readout carries it)
+  GS_REQUIRE(!(d->training && d->readout_dropout > 0.f), GNNSAFT_ERR_UNSUPPORTED);
   GS_TRY(pool(st));
   const float *cur = F(p.pooled);
   int width = h, bi = 0;

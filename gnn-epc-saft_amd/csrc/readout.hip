@@ -61,6 +61,8 @@ struct ReadoutArgs {
   int32_t *sync;             // [nb + 1] counters, zero at launch
   int32_t *err;
   int barrier_extra;         // 0; > 0 (test hook): the barriers expect that many arrivals more than there are workgroups
+  float dropout_p;           // 0: no dropout (or eval mode)
+  uint64_t dropout_seed;
 };
 
 // all workgroups of the grid meet here; returns true after every one of them has arrived, false when the spin bound
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_fused(ReadoutArgs a) {
       v.y = fmaxf(v.y, 0.f);
       v.z = fmaxf(v.z, 0.f);
       v.w = fmaxf(v.w, 0.f);
+      if (a.dropout_p > 0.f) v = v * dropout_scale4(a.dropout_seed, row0 + r, b, c4, a.dropout_p);   // block-uniform
       gs_st4(at + r * ld + c4, v);
       if (a.ro != nullptr && r < rows) gs_st4(a.ro + b * rs + (row0 + r) * n_out + c4, v);
     }
@@ -367,6 +370,8 @@ struct ReadoutBwdArgs {
   int32_t *sync;                               // [nb + 1] counters, zero at launch
   int32_t *err;
   int barrier_extra;
+  float dropout_p;
+  uint64_t dropout_seed;
 };
 
 // slab[n][k] = sum over this workgroup's 64 rows of dy[r][n] * in[r][k]: 32 x 32 output tiles round-robin over the
@@ -485,7 +490,8 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_bwd_fused(ReadoutBwdArgs
         const f32x4 y = gs_ld4(a.ry + b * rs + (row0 + r) * n_out + c4);
         const f32x4 mean = gs_ld4(stat + c4), rstd = gs_ld4(stat + n_out + c4);
         const f32x4 gm = gs_ld4(a.gamma[b] + c4), bt = gs_ld4(a.beta[b] + c4);
-        const f32x4 dv = gs_ld4(dt + r * ld + c4);
+        f32x4 dv = gs_ld4(dt + r * ld + c4);
+        if (a.dropout_p > 0.f) dv = dv * dropout_scale4(a.dropout_seed, row0 + r, b, c4, a.dropout_p);   // the forward's mask
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           yh[j] = (y[j] - mean[j]) * rstd[j];
@@ -715,6 +721,9 @@ int launch_readout_fused(const ReadoutFusedParams &p, hipStream_t st) {
   a.sync = p.sync;
   a.err = p.err;
   a.barrier_extra = p.barrier_extra > 0 ? p.barrier_extra : 0;
+  GS_REQUIRE(p.dropout_p >= 0.f && p.dropout_p < 1.f, GNNSAFT_ERR_SHAPE);
+  a.dropout_p = p.training ? p.dropout_p : 0.f;
+  a.dropout_seed = p.dropout_seed;
   const size_t lds = rd_fwd_lds(p.h);   // (the dynamic-LDS limit of this device was raised by the residency query)
   hipLaunchKernelGGL(k_readout_fused, dim3((unsigned)wgs), dim3(kRdThreads), lds, st, a);
   GS_CHECK_LAUNCH();
@@ -766,6 +775,8 @@ int launch_readout_bwd_fused(const ReadoutBwdParams &p, SlabQueue &q, hipStream_
   a.sync = p.sync;
   a.err = p.err;
   a.barrier_extra = p.barrier_extra > 0 ? p.barrier_extra : 0;
+  a.dropout_p = p.dropout_p;
+  a.dropout_seed = p.dropout_seed;
   a.part = p.scratch;
   a.bias_part = p.scratch + (size_t)p.nblocks * wgs * 2 * p.h;
   GS_REQUIRE(a.w_final != nullptr && a.dbias_final != nullptr, GNNSAFT_ERR_NULL);

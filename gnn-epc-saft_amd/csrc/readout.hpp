@@ -24,6 +24,8 @@ struct ReadoutFusedParams {
   int32_t *sync;                          // kRdSyncInts ints, zero at launch
   int32_t *err;
   int barrier_extra;                      // test hook (desc->debug_barrier_extra): arrivals the barriers wait for in vain
+  float dropout_p;                        // Dropout behind every ReLU of the readout (models.py:88,95,99); training only
+  uint64_t dropout_seed;                  // Philox key of this call's masks
 };
 
 // Backward of the readout in one launch (k_readout_bwd_fused): per-workgroup partial weight gradients go to `q`'s
@@ -44,7 +46,42 @@ struct ReadoutBwdParams {
   int32_t *sync;                             // kRdSyncInts ints, zero at launch
   int32_t *err;                              // or null
   int barrier_extra;                         // test hook, as in the forward
+  float dropout_p;                           // the forward's Dropout: the masks are regenerated from the same key
+  uint64_t dropout_seed;
 };
+
+// Dropout masks of the readout: Philox4x32-10 keyed by the call's seed, counter = (graph row, block, column / 4):
+// four keep decisions for four consecutive columns of one row of one block -- a pure function of (seed, position), so
+// forward and backward agree without storing a mask, whatever workgroup evaluates it.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+// keep-scale factors (0 or 1 / (1 - p)) of columns c4 .. c4 + 3 of (row, block)
+__device__ __forceinline__ f32x4 dropout_scale4(uint64_t seed, int64_t row, int block, int c4, float p) {
+  uint32_t r[4];
+  philox4x32_10((uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)block, (uint32_t)(c4 >> 2), (uint32_t)seed,
+                (uint32_t)(seed >> 32), r);
+  const float keep = 1.f / (1.f - p);
+  f32x4 m;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) m[j] = (float)(r[j] >> 8) * (1.f / 16777216.f) >= p ? keep : 0.f;   // uniform [0,1) >= p
+  return m;
+}
 size_t readout_bwd_scratch_floats(int64_t g, int h, int nblocks);
 size_t readout_bwd_slab_floats(int64_t g, int h, int num_para, int nblocks);
 bool readout_bwd_fused_supported(int64_t g, int h, int num_para, int nblocks);

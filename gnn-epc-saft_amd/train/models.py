@@ -272,15 +272,29 @@ class PNAPCSAFT(nn.Module):
         d.unfused_readout = int(not self.fused_readout)
         d.debug_barrier_extra = int(self._debug_barrier_extra)
         d.unfused_bn_apply = {"pool": 0, True: 2, False: 1}[self.fused_batchnorm]
+        # Dropout of the readout MLP (models.py:88,95,99; config.dropout_rate through train/utils.py:66-70): a fresh
+        # Philox key per training forward, drawn from torch's CPU generator (torch.manual_seed makes runs repeatable);
+        # the backward regenerates the masks from the key kept in the tape's descriptor
+        d.readout_dropout = float(self.mlp_params.dropout) if self.training else 0.0
+        if d.readout_dropout > 0.0:
+            if not 0.0 <= d.readout_dropout < 1.0:
+                raise ValueError("dropout must be in [0, 1)")
+            if torch.cuda.is_current_stream_capturing():
+                raise NotImplementedError("readout dropout under hipGraph capture would replay ONE mask for ever (the "
+                                          "Philox key is a kernel argument): train with dropout eagerly")
+            d.dropout_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         return d
 
     def _check_mode(self, x: torch.Tensor) -> None:
         if not x.is_cuda:
             raise RuntimeError("PNAPCSAFT (MI355X build) has no CPU path: move the module and the batch to a HIP "
                                "device (`.to('cuda')`)")
-        if self.training and (self.pna_params.dropout > 0 or self.mlp_params.dropout > 0):
-            raise NotImplementedError("dropout > 0 in training mode is not implemented (the reference always "
-                                      "trains with dropout 0.0: train/utils.py:57-69, configs/default.py:41)")
+        if self.training and self.pna_params.dropout > 0:
+            raise NotImplementedError("dropout on the node states (PnaconvsParams.dropout) is not implemented: the "
+                                      "reference's factory never sets it (train/utils.py:57-63 leaves the default "
+                                      "0.0); config.dropout_rate reaches the readout MLP only, which is implemented")
+        if self.training and self.mlp_params.dropout > 0 and not self.fused_readout:
+            raise NotImplementedError("readout dropout runs in the one-launch readout only: leave fused_readout on")
 
     def _trainable(self, weights: List[torch.Tensor]) -> List[torch.Tensor]:
         """Parameters of the weight table that require a gradient (every parameter of the module is in the table;

@@ -482,6 +482,8 @@ typedef struct gnnsaft_workspace_map {
   size_t x_stride;  /* tape (save_tape): x_0 .. x_L contiguous from x_embed, x_stride BYTES apart; 0 without a tape */
   size_t bnstat;    /* [L][2][H] (batch mean | rstd) of the node BatchNorms, as the backward reads them             */
   size_t y_stride;  /* tape: BYTES between the pre-BatchNorm tensors y_l of consecutive layers (from `y`); 0 without */
+  size_t ry;        /* [num_mlp_layers + 2][G, n_out] pre-BatchNorm outputs of the readout blocks (block stride G*H)  */
+  size_t rstat;     /* [num_mlp_layers + 2][2][H]: per block (batch mean at [c], rstd at [n_out + c])                   */
 } gnnsaft_workspace_map;
 
 GNNSAFT_API int gnnsaft_forward_workspace_map(const gnnsaft_model_desc *desc, int64_t num_nodes,

@@ -182,9 +182,37 @@ def tape_decisions(pred: torch.Tensor, skip: bool):
         shift = bn.bias.detach().float().cpu() - stat[layer, 0] * scale
         dec.append((ys[layer] * scale + shift) > 0)
     widths = [h] * desc.num_mlp_layers + [h // 2, h // 4]
-    for b, w in enumerate(widths):
-        dec.append((tap(wmap.ro + 4 * b * g * h, g * w).view(g, w) > 0).cpu())
+    bns = [m for m in module.mlp.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+    rstat = tap(wmap.rstat, len(widths) * 2 * h).view(len(widths), 2 * h).cpu()
+    for b, w in enumerate(widths):     # readout gates: the same expression on the blocks' pre-BatchNorm tensors
+        y = tap(wmap.ry + 4 * b * g * h, g * w).view(g, w).cpu()
+        scale = rstat[b, w:2 * w] * bns[b].weight.detach().float().cpu()
+        shift = bns[b].bias.detach().float().cpu() - rstat[b, :w] * scale
+        dec.append((y * scale + shift) > 0)
     return dec
+
+
+def tape_dropout_masks(pred: torch.Tensor):
+    """Keep-masks of the readout's Dropout layers as the taped HIP forward behind ``pred`` drew them: block outputs that
+    are exactly zero although their ReLU gate is open were dropped (a closed gate's mask is unobservable and
+    irrelevant: value and gradient are zero either way -- reported as kept)."""
+    import ctypes
+
+    from gnn_epc_saft_amd._native import WorkspaceMap, lib
+    tape = pred.grad_fn.tape
+    desc, n, e, g = tape["desc"], tape["n"], tape["e"], tape["g"]
+    wmap = WorkspaceMap()
+    assert lib.gnnsaft_forward_workspace_map(ctypes.byref(desc), n, e, g, ctypes.byref(wmap)) == 0
+    base = tape["ws_ptr"] - tape["ws"].data_ptr()
+    h = desc.hidden
+    widths = [h] * desc.num_mlp_layers + [h // 2, h // 4]
+    gates = tape_decisions(pred, True)[-len(widths):]
+    masks = []
+    for b, w in enumerate(widths):
+        off = base + wmap.ro + 4 * b * g * h
+        ro = tape["ws"][off: off + 4 * g * w].view(torch.float32).view(g, w).cpu()
+        masks.append((ro != 0) | ~gates[b])
+    return masks
 
 
 def _csr_order(data, loops: bool):
@@ -362,7 +390,7 @@ def branch_differences(a, b) -> Dict[str, int]:
     return out
 
 
-def forced_forward(model: torch.nn.Module, data, branch) -> torch.Tensor:
+def forced_forward(model: torch.nn.Module, data, branch, dropout_masks=None) -> torch.Tensor:
     """The oracle's forward (oracle/pna_torch.py ``OraclePNAPCSAFT.forward``, same modules, same op order) with every
     discrete decision taken from ``branch`` instead of from the data: differentiable, float32 or float64."""
     from oracle.pna_torch import add_self_loops, global_add_pool, pna_scale, scatter_mean
@@ -398,6 +426,7 @@ def forced_forward(model: torch.nn.Module, data, branch) -> torch.Tensor:
             x = x + x_prev
     g = global_add_pool(x, batch)
     gates = iter(branch["ro"])
+    drops = iter(dropout_masks) if dropout_masks is not None else None
 
     def run(seq, v):
         for mod in seq:
@@ -406,7 +435,11 @@ def forced_forward(model: torch.nn.Module, data, branch) -> torch.Tensor:
             elif isinstance(mod, torch.nn.ReLU):
                 v = v * next(gates).to(v.dtype)
             elif isinstance(mod, torch.nn.Dropout):
-                assert mod.p == 0.0
+                if drops is None:
+                    assert mod.p == 0.0
+                else:     # the masks the HIP forward drew, scaled as torch's Dropout scales: x * mask / (1 - p)
+                    keep = torch.tensor(1.0, dtype=torch.float32) / (torch.tensor(1.0, dtype=torch.float32) - mod.p)
+                    v = v * next(drops).to(v.dtype) * keep.to(v.dtype)
             else:
                 v = mod(v)
         return v

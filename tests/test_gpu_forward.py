@@ -37,7 +37,7 @@ def hip_twin(oracle: OraclePNAPCSAFT):
     hidden = oracle.node_embed.atom_embedding_list[0].weight.shape[1]
     m = G.PNAPCSAFT(hidden, G.PnaconvsParams(p.propagation_depth, p.pre_layers, p.post_layers, p.deg,
                                              skip_connections=p.skip_connections, self_loops=p.self_loops),
-                    G.ReadoutMLPParams(q.num_mlp_layers, q.num_para))
+                    G.ReadoutMLPParams(q.num_mlp_layers, q.num_para, dropout=q.dropout))
     missing = m.load_state_dict({k: v.float() for k, v in oracle.state_dict().items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return m.to(DEV).train(oracle.training)

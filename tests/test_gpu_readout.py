@@ -156,3 +156,82 @@ def test_a_lost_grid_barrier_raises_the_flag_and_poisons_the_results():
     grads = dict(m.named_parameters())
     assert bool(torch.isnan(grads["convs.0.lin.weight"].grad).all())
     assert bool(torch.isnan(grads["node_embed.atom_embedding_list.0.weight"].grad).any())
+
+
+def _with_dropout(oracle, p):
+    oracle.mlp_params.dropout = p
+    for mod in oracle.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = p
+    return oracle
+
+
+def test_readout_dropout_masks_statistics_and_gradients():
+    """Dropout of the readout MLP in training (models.py:88,95,99; config.dropout_rate through train/utils.py:66-70):
+    Philox-keyed masks inside the one-launch readout, regenerated by its backward.  Checked by
+      * statistics: of the open ReLU gates of every block a fraction 1 - p survives (binomial bound), survivors are
+        scaled by 1 / (1 - p);
+      * repeatability: the same torch seed gives the same bits, another seed another mask; p = 0 and eval mode are the
+        dropout-free path bit for bit, and p = 1e-12 (mask all ones, scale exactly 1) equals it too;
+      * exactness: the f64 oracle evaluated with the SAME masks (read off the tape) and on the same branch reproduces
+        the prediction and, through autograd, every gradient -- the backward applies the forward's masks."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    from gnn_epc_saft_amd.train.models import mape_loss
+    from helpers import branch_of_tape, forced_forward, tape_decisions, tape_dropout_masks
+    p_drop = 0.3
+    data = make_synthetic_batch(300, 41)
+    oracle = _with_dropout(oracle_model(64, 2, 1, 1, 1, 3, True, True, degree_histogram(data), seed=6), p_drop).train()
+    dd, tgt = data.to(DEV), data.para.view(-1, 3).to(DEV)
+    hip = hip_twin(copy.deepcopy(oracle))
+    assert hip.mlp_params.dropout == p_drop
+    torch.manual_seed(123)
+    pred = hip(dd)
+    masks = tape_dropout_masks(pred)
+    gates = tape_decisions(pred, True)[-3:]
+    for b, (m, gte) in enumerate(zip(masks, gates)):
+        open_gates = int(gte.sum())
+        kept = int((m & gte).sum())
+        sigma = (open_gates * p_drop * (1 - p_drop)) ** 0.5
+        print(f"block {b}: {kept} of {open_gates} open gates kept ({kept / open_gates:.4f}, expected {1 - p_drop})")
+        assert abs(kept - open_gates * (1 - p_drop)) <= 4.5 * sigma + 1
+    branch = branch_of_tape(pred, data, True, True)          # (the tape is released by the backward)
+    loss = mape_loss(pred, tgt)
+    loss.backward()
+    grads = {k: p.grad.detach().double().cpu() for k, p in hip.named_parameters()}
+    # the exact function on the same branch with the same masks
+    o64 = copy.deepcopy(oracle).double().train()
+    out64 = forced_forward(o64, data, branch, dropout_masks=masks)
+    mape(out64, data.para.view(-1, 3).double()).backward()
+    assert rel_err(pred.detach(), out64.detach()) < 1e-5
+    o32 = copy.deepcopy(oracle).train()
+    mape(forced_forward(o32, data, branch, dropout_masks=masks), data.para.view(-1, 3)).backward()
+    gscale = max(float(p.grad.abs().max()) for p in o64.parameters())
+    g32 = dict(o32.named_parameters())
+    for k, p64 in o64.named_parameters():
+        scale = max(float(p64.grad.abs().max()), 1e-4 * gscale)
+        if float(p64.grad.abs().max()) < 1e-6 * gscale:
+            continue                                        # exactly-zero gradients (biases in front of a BatchNorm)
+        e_hip = float((grads[k] - p64.grad).abs().max()) / scale
+        e_f32 = float((g32[k].grad.double() - p64.grad).abs().max()) / scale
+        assert e_hip <= max(3 * e_f32, 2e-5), (k, e_hip, e_f32)
+    # repeatability / other seed / the dropout-free path
+    twin = hip_twin(copy.deepcopy(oracle))       # (constructing a module draws from torch's generator: seed after it)
+    torch.manual_seed(123)
+    again = twin(dd)
+    assert torch.equal(again, pred)
+    twin.load_state_dict(hip.state_dict())       # (same weights; the running statistics moved, the output does not care)
+    torch.manual_seed(124)
+    other = twin(dd)
+    assert not torch.equal(other, pred)
+    plain = hip_twin(_with_dropout(copy.deepcopy(oracle), 0.0))
+    tiny = hip_twin(_with_dropout(copy.deepcopy(oracle), 1e-12))
+    with torch.no_grad():
+        a, b = plain(dd), tiny(dd)
+        assert torch.equal(a, b)
+        ev = hip_twin(copy.deepcopy(oracle)).eval()
+        ev0 = hip_twin(_with_dropout(copy.deepcopy(oracle), 0.0)).eval()
+        assert torch.equal(ev(dd), ev0(dd))                 # eval mode: Dropout is the identity
+    hip.fused_readout = False
+    with pytest.raises(NotImplementedError):
+        hip(dd)
+    assert hip.input_error_flags() == 0
