@@ -233,6 +233,7 @@ def roofline_blocks(wl: Workload, times, event_overhead_ms=None):
         # every f32 operand is split exactly into three bf16 numbers while it is staged; six of the nine cross products
         # are issued as v_mfma_f32_32x32x16_bf16 with f32 accumulation: 6 bf16-MFMA FLOPs per f32-equivalent FLOP
         for v in per_kernel.values():
+            v["f32_equivalent_vs_f32_mfma_peak"] = v.pop("frac_of_f32_mfma_peak")   # a speed ratio, not a roofline fraction
             v["bf16_mfma_tflops_issued"] = 6.0 * v["executed_tflops"]
             v["frac_of_bf16_mfma_peak"] = 6.0 * v["executed_tflops"] / MFMA_BF16_PEAK_TF
         gemm = {
