@@ -307,7 +307,8 @@ int launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_
                      int32_t num_bond_cols, const int32_t *bond_dims_host, int32_t self_loops, int32_t *rowptr,
                      int32_t *src, int32_t *dst, int32_t *combo, float *log_amp, float *log_att, int32_t *err_flag,
                      void *workspace, size_t workspace_bytes, const int64_t *batch, int64_t num_graphs,
-                     int32_t *graph_ptr, int32_t *degree_block_hist, bool counts_zeroed, hipStream_t st);
+                     int32_t *graph_ptr, int32_t *degree_block_hist, bool counts_zeroed, hipStream_t st,
+                     bool bounded_degree = false /* in-degree < kDegreeBuckets: the slotted chain (csr.hip) */);
 // optional rider of launch_degree_tiles: fold the update weights of all layers in the launch that fills the
 // permutation (both need only the degree plan)
 struct DegreeFoldRequest {

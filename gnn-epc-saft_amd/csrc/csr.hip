@@ -79,7 +79,8 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *lds, int &total)
 
 __global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const int32_t *__restrict__ counts, int64_t n, int extra,
                                                            int32_t *__restrict__ rowptr,
-                                                           int32_t *__restrict__ tile_sums) {
+                                                           int32_t *__restrict__ tile_sums,
+                                                           int clamp = 0x7fffffff) {
   __shared__ int lds[kScanBlock / 64];
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
   int v[kScanItems];
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const int32_t *__rest
 #pragma unroll
   for (int j = 0; j < kScanItems; ++j) {
     const int64_t i = base + j;
-    v[j] = i < n ? counts[i] + extra : 0;
+    v[j] = i < n ? (counts[i] < clamp ? counts[i] : clamp) + extra : 0;
     local += v[j];
   }
   int total;
@@ -251,6 +252,174 @@ __global__ void k_finish_rows(const int64_t *__restrict__ edge_index, const int6
   if (block_hist != nullptr) block_degree_hist(live ? clamp_degree(deg, err) : 0, live, block_hist);
 }
 
+// ---- bounded in-degree (the folded update: every in-degree < kDegreeBuckets, anything above is an input error that
+// the degree bucketing flags): the edge ids go to a fixed row of kCsrSlots slots per destination node in ONE pass
+// over the edge list -- no histogram pass before the fill -- and the row offsets are completed by the kernel that
+// orders and emits the rows.  prologue (zero) -> k_fill_slots -> k_scan_tiles -> k_finish_rows_slots: two launches
+// fewer than the general chain, and the per-node sort runs in registers instead of through memory.
+constexpr int kCsrSlots = kDegreeBuckets;
+
+__global__ void k_fill_slots(const int64_t *__restrict__ edge_index, int64_t n, int64_t e,
+                             int32_t *__restrict__ cursor, int32_t *__restrict__ slots, int32_t *err,
+                             const int64_t *__restrict__ batch, int64_t g, int32_t *__restrict__ graph_ptr) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (graph_ptr != nullptr) {
+    if (batch != nullptr) {
+      batch_to_ptr_slot(batch, n, g, graph_ptr, err, i);
+    } else if (i == 0) {  // un-batched Data: one graph spanning all nodes
+      graph_ptr[0] = 0;
+      graph_ptr[1] = (int32_t)n;
+    }
+  }
+  if (i >= e) return;
+  const int64_t s = edge_index[i];
+  const int64_t d = edge_index[e + i];
+  if (s < 0 || s >= n || d < 0 || d >= n) {
+    if (err) atomicOr(err, GNNSAFT_FLAG_BAD_EDGE);
+    return;  // dropped
+  }
+  const int pos = atomicAdd(&cursor[d], 1);
+  if (pos < kCsrSlots) {
+    slots[d * kCsrSlots + pos] = (int32_t)i;
+  } else if (err) {
+    atomicOr(err, GNNSAFT_FLAG_BAD_DEGREE);  // (the edge is dropped; the row keeps kCsrSlots edges)
+  }
+}
+
+__device__ __forceinline__ void sort_exchange(int &a, int &b) {
+  const int lo = a < b ? a : b, hi = a < b ? b : a;
+  a = lo;
+  b = hi;
+}
+
+// one thread per node: final row offset (tile-local scan value + the totals of the tiles in front), the node's edge
+// ids in ascending order (8 or fewer: a sorting network in registers), src / dst / combo rows, degree scaler logs,
+// first pass of the degree bucketing.  blockDim.x divides kScanTile.
+__global__ void k_finish_rows_slots(const int64_t *__restrict__ edge_index, const int64_t *__restrict__ edge_attr,
+                                    int64_t n, int64_t e, BondDims bd, int self_loops,
+                                    int32_t *__restrict__ rowptr, const int32_t *__restrict__ tile_sums,
+                                    int64_t num_tiles, const int32_t *__restrict__ cursor,
+                                    int32_t *__restrict__ slots, int32_t *__restrict__ src,
+                                    int32_t *__restrict__ dst, int32_t *__restrict__ combo,
+                                    float *__restrict__ log_amp, float *__restrict__ log_att, int32_t *err,
+                                    int32_t *__restrict__ block_hist) {
+  __shared__ int s_before[16], s_all[16];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  // loads that do not depend on the row offset first
+  int cnt = live ? cursor[i] : 0;
+  cnt = cnt < kCsrSlots ? cnt : kCsrSlots;
+  int32_t *row = slots + (live ? i : 0) * kCsrSlots;
+  int key[8];
+  if (cnt <= 8) {
+    const int4 lo = cnt > 0 ? *reinterpret_cast<const int4 *>(row) : int4{0, 0, 0, 0};
+    const int4 hi = cnt > 4 ? *reinterpret_cast<const int4 *>(row + 4) : int4{0, 0, 0, 0};
+    const int raw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int a = 0; a < 8; ++a) key[a] = a < cnt ? raw[a] : 0x7fffffff;
+  }
+  // tile totals in front of this workgroup's tile (the last workgroup also sums all of them: rowptr[n])
+  const int64_t tile = ((int64_t)blockIdx.x * blockDim.x) / kScanTile;
+  const bool last = blockIdx.x == gridDim.x - 1;
+  const int64_t upto = last ? num_tiles : tile;
+  int before = 0, all = 0;
+  for (int64_t t = threadIdx.x; t < upto; t += blockDim.x) {
+    const int v = tile_sums[t];
+    all += v;
+    if (t < tile) before += v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    before += __shfl_xor(before, o);
+    all += __shfl_xor(all, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_before[threadIdx.x >> 6] = before;
+    s_all[threadIdx.x >> 6] = all;
+  }
+  __syncthreads();
+  before = 0;
+  all = 0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+    before += s_before[w];
+    all += s_all[w];
+  }
+  if (last && threadIdx.x == 0) rowptr[n] = all;
+  int deg = 0;
+  if (live) {
+    const int beg = rowptr[i] + before;
+    rowptr[i] = beg;
+    if (cnt <= 8) {
+      // Batcher odd-even merge sort, 8 keys, 19 exchanges
+      sort_exchange(key[0], key[1]); sort_exchange(key[2], key[3]); sort_exchange(key[4], key[5]); sort_exchange(key[6], key[7]);
+      sort_exchange(key[0], key[2]); sort_exchange(key[1], key[3]); sort_exchange(key[4], key[6]); sort_exchange(key[5], key[7]);
+      sort_exchange(key[1], key[2]); sort_exchange(key[5], key[6]);
+      sort_exchange(key[0], key[4]); sort_exchange(key[1], key[5]); sort_exchange(key[2], key[6]); sort_exchange(key[3], key[7]);
+      sort_exchange(key[2], key[4]); sort_exchange(key[3], key[5]);
+      sort_exchange(key[1], key[2]); sort_exchange(key[3], key[4]); sort_exchange(key[5], key[6]);
+      int64_t sv[8];
+      int cid[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {   // every row's loads are independent: all in flight together
+        const int64_t id = a < cnt ? key[a] : 0;
+        sv[a] = a < cnt ? edge_index[id] : 0;
+        int c = 0;
+        for (int k = 0; k < bd.n; ++k) {
+          int64_t v = a < cnt ? edge_attr[id * bd.n + k] : 0;
+          if (v < 0 || v >= bd.dims[k]) {
+            if (err) atomicOr(err, GNNSAFT_FLAG_BAD_ATTR);
+            v = 0;
+          }
+          c = c * bd.dims[k] + (int)v;
+        }
+        cid[a] = c;
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+        if (a < cnt) {
+          src[beg + a] = (int32_t)sv[a];
+          dst[beg + a] = (int32_t)i;
+          combo[beg + a] = cid[a];
+        }
+    } else {
+      for (int a = 1; a < cnt; ++a) {   // insertion sort in the slot row, ascending edge id
+        const int k2 = row[a];
+        int b = a - 1;
+        while (b >= 0 && row[b] > k2) {
+          row[b + 1] = row[b];
+          --b;
+        }
+        row[b + 1] = k2;
+      }
+      for (int a = 0; a < cnt; ++a) {
+        const int64_t id = row[a];
+        int c = 0;
+        for (int k = 0; k < bd.n; ++k) {
+          int64_t v = edge_attr[id * bd.n + k];
+          if (v < 0 || v >= bd.dims[k]) {
+            if (err) atomicOr(err, GNNSAFT_FLAG_BAD_ATTR);
+            v = 0;
+          }
+          c = c * bd.dims[k] + (int)v;
+        }
+        src[beg + a] = (int32_t)edge_index[id];
+        dst[beg + a] = (int32_t)i;
+        combo[beg + a] = c;
+      }
+    }
+    deg = cnt;
+    if (self_loops) {
+      src[beg + cnt] = (int32_t)i;
+      dst[beg + cnt] = (int32_t)i;
+      combo[beg + cnt] = 0;
+      deg += 1;
+    }
+    log_amp[i] = degree_log_amp(deg);
+    log_att[i] = degree_log_att(deg);
+  }
+  if (block_hist != nullptr) block_degree_hist(live ? clamp_degree(deg, err) : 0, live, block_hist);
+}
+
 __device__ __forceinline__ void batch_to_ptr_slot(const int64_t *__restrict__ batch, int64_t n, int64_t g,
                                                   int32_t *__restrict__ ptr, int32_t *err, int64_t i) {
   if (i > n) return;
@@ -364,10 +533,11 @@ __global__ void k_single_graph_ptr(int32_t *ptr, int32_t n) {
 }  // namespace gs
 
 extern "C" size_t gnnsaft_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges) {
-  // counts[N] + cursor[N] + tile_sums[tiles] + eid[E + N]
+  // counts[N] + cursor[N] + tile_sums[tiles] + eid[E + N] (general chain) or slots[N][kCsrSlots] (bounded in-degree)
   const size_t tiles = (size_t)gs_ceil_div(num_nodes > 0 ? num_nodes : 1, gs::kScanTile);
+  const size_t eid = (size_t)(num_edges + num_nodes + 1), slots = (size_t)num_nodes * gs::kCsrSlots;
   return gs_align_up((size_t)num_nodes * 4, 256) * 2 + gs_align_up(tiles * 4, 256) +
-         gs_align_up((size_t)(num_edges + num_nodes + 1) * 4, 256);  // eid lives in the loop-padded row space
+         gs_align_up((eid > slots ? eid : slots) * 4, 256);
 }
 
 // the int32 region launch_csr_build expects zeroed (in-degree counts + fill cursors) when told `counts_zeroed`
@@ -381,7 +551,7 @@ int gs::launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, in
                          int32_t *src, int32_t *dst, int32_t *combo, float *log_amp, float *log_att,
                          int32_t *err_flag, void *workspace, size_t workspace_bytes, const int64_t *batch,
                          int64_t num_graphs, int32_t *graph_ptr, int32_t *degree_block_hist, bool counts_zeroed,
-                         hipStream_t st) {
+                         hipStream_t st, bool bounded_degree) {
   GS_REQUIRE(rowptr && src && dst && combo && log_amp && log_att && workspace, GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_edges == 0 || (edge_index != nullptr && edge_attr != nullptr), GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_nodes >= 0 && num_edges >= 0, GNNSAFT_ERR_SHAPE);
@@ -416,8 +586,22 @@ int gs::launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, in
     hipLaunchKernelGGL(gs::k_zero_i32, dim3((unsigned)gs_ceil_div(2 * (int64_t)gs_align_up((size_t)n * 4, 256) / 4, tb)),
                        dim3(tb), 0, st, counts, 2 * (int64_t)gs_align_up((size_t)n * 4, 256) / 4, nullptr);
   }
-  // in-degree histogram (+ graph offsets from `batch` in the same launch when asked for)
   const int64_t count_threads = graph_ptr != nullptr ? (e > n + 1 ? e : n + 1) : e;
+  if (bounded_degree && n > 0) {
+    // in-degree < kDegreeBuckets promised (violations are flagged, the surplus edges dropped): slotted chain
+    if (count_threads > 0)
+      hipLaunchKernelGGL(gs::k_fill_slots, dim3((unsigned)gs_ceil_div(count_threads, tb)), dim3(tb), 0, st, edge_index,
+                         n, e, cursor, eid, err_flag, batch, num_graphs, graph_ptr);
+    hipLaunchKernelGGL(gs::k_scan_tiles, dim3((unsigned)tiles), dim3(gs::kScanBlock), 0, st, cursor, n,
+                       self_loops ? 1 : 0, rowptr, tile_sums, gs::kCsrSlots);
+    const int fb = degree_block_hist != nullptr ? gs::kDegBlock : tb;
+    hipLaunchKernelGGL(gs::k_finish_rows_slots, dim3((unsigned)gs_ceil_div(n, fb)), dim3(fb), 0, st, edge_index,
+                       edge_attr, n, e, bd, self_loops ? 1 : 0, rowptr, tile_sums, tiles, cursor, eid, src, dst, combo,
+                       log_amp, log_att, err_flag, degree_block_hist);
+    GS_CHECK_LAUNCH();
+    return GNNSAFT_OK;
+  }
+  // in-degree histogram (+ graph offsets from `batch` in the same launch when asked for)
   if (n > 0 && count_threads > 0)
     hipLaunchKernelGGL(gs::k_count_in_degree, dim3((unsigned)gs_ceil_div(count_threads, tb)), dim3(tb), 0, st,
                        edge_index, n, e, counts, err_flag, batch, num_graphs, graph_ptr);

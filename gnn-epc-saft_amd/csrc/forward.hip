@@ -432,7 +432,8 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     GS_TRY(launch_csr_build(edge_index, edge_attr, num_nodes, num_edges, d->num_bond_cols, d->bond_dims, d->self_loops,
                             I(p.rowptr), I(p.src), I(p.dst), I(p.combo), F(p.log_amp), F(p.log_att), err_flag,
                             ws + p.csr_ws, gnnsaft_csr_workspace_bytes(num_nodes, num_edges), batch, num_graphs,
-                            I(p.graph_ptr), I(p.hist3) + 2 * kDegreeBuckets, false, st));
+                            I(p.graph_ptr), I(p.hist3) + 2 * kDegreeBuckets, false, st,
+                            d->fold_degree_scalers != 0));
     GS_TRY(launch_degree_tiles(I(p.rowptr), num_nodes, d->hidden, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3),
                                err_flag, true, st));
     GS_HIP(hipMemcpyAsync(structure_out, ws + p.struct_begin, p.struct_bytes, hipMemcpyDeviceToDevice, st));
@@ -569,7 +570,8 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
   GS_TRY(launch_csr_build(edge_index, edge_attr, n, num_edges, d->num_bond_cols, d->bond_dims, d->self_loops,
                           I(p.rowptr), I(p.src), I(p.dst), I(p.combo), F(p.log_amp), F(p.log_att), err_flag,
                           ws + p.csr_ws, gnnsaft_csr_workspace_bytes(n, num_edges), batch, g, I(p.graph_ptr),
-                          d->fold_degree_scalers ? I(p.hist3) + 2 * kDegreeBuckets : nullptr, true, sa));
+                          d->fold_degree_scalers ? I(p.hist3) + 2 * kDegreeBuckets : nullptr, true, sa,
+                          d->fold_degree_scalers != 0));
   if (d->fold_degree_scalers) {
     if (d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS) {  // weight fold rides along with the permutation fill
       const float *w0[GNNSAFT_MAX_FOLD_LAYERS], *w1[GNNSAFT_MAX_FOLD_LAYERS], *av[GNNSAFT_MAX_FOLD_LAYERS];

@@ -501,3 +501,62 @@ def test_hip_path_properties_node_relabelling_explicit_loops_isolated_nodes():
         got = h2(sparse.to(DEV)).cpu()
         assert h2.input_error_flags() == 0
         assert rel_err(got, want) < max(TOL, 3 * rel_err(copy.deepcopy(o2)(sparse), want))
+
+
+@pytest.mark.parametrize("loops", [True, False])
+def test_the_forward_builds_the_csr_of_the_general_chain(loops):
+    """gnnsaft_forward builds its CSR with the slotted chain (csr.hip: in-degree < 32 promised by the folded update,
+    one pass over the edge list, per-node sort in registers); gnnsaft_csr_build keeps the general
+    histogram / scan / fill chain.  Same rows bit for bit, on an edge list in RANDOM order (the per-node sort has
+    work to do) with a hub of 13 in-edges (more than the 8 the register sort takes: the in-memory path) and the edge
+    list's order kept inside every row (stable: the float sums downstream depend on it)."""
+    import ctypes
+
+    import gnn_epc_saft_amd.kernels as K
+    from gnn_epc_saft_amd._native import WorkspaceMap, lib
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    data = make_synthetic_batch(150, 31)
+    n = data.x.shape[0]
+    g = torch.Generator().manual_seed(5)
+    hub = torch.stack([torch.arange(1, 14), torch.zeros(13, dtype=torch.int64)])
+    ei = torch.cat([data.edge_index, hub], dim=1)
+    ea = torch.cat([data.edge_attr, torch.randint(0, 2, (13, 3), generator=g)])
+    order = torch.randperm(ei.shape[1], generator=g)
+    data.edge_index, data.edge_attr = ei[:, order].contiguous(), ea[order].contiguous()
+    oracle = oracle_model(64, 2, 1, 1, 1, 3, True, loops, degree_histogram(data), seed=2).train()
+    m = hip_twin(copy.deepcopy(oracle))
+    assert m.fold_degree_scalers
+    pred = m(data.to(DEV))
+    assert m.input_error_flags() == 0
+    tape = pred.grad_fn.tape
+    desc, e, gg = tape["desc"], tape["e"], tape["g"]
+    wmap = WorkspaceMap()
+    assert lib.gnnsaft_forward_workspace_map(ctypes.byref(desc), n, e, gg, ctypes.byref(wmap)) == 0
+    base = tape["ws_ptr"] - tape["ws"].data_ptr()
+    ep = e + (n if loops else 0)
+    view = lambda off, count: tape["ws"][base + off: base + off + 4 * count].view(torch.int32)
+    want = K.csr_build(data.edge_index.to(DEV), data.edge_attr.to(DEV), n, (5, 6, 2), loops)
+    assert int(want[-1].item()) == 0
+    assert torch.equal(view(wmap.rowptr, n + 1), want[0])
+    assert int((want[0][1:] - want[0][:-1]).max()) >= 13
+    for name, got, ref in (("src", view(wmap.src, ep), want[1]), ("dst", view(wmap.dst, ep), want[2]),
+                           ("combo", view(wmap.combo, ep), want[3])):
+        assert torch.equal(got, ref), name
+    la = tape["ws"][base + wmap.log_amp: base + wmap.log_amp + 4 * n].view(torch.float32)
+    assert torch.equal(la, want[4])
+
+
+def test_an_in_degree_beyond_the_buckets_is_flagged_by_the_forward():
+    """A hub with 40 in-edges: the slotted chain keeps 32 of them, drops the rest and raises
+    GNNSAFT_FLAG_BAD_DEGREE (8) -- no fault, no silent wrong answer."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    data = make_synthetic_batch(20, 3)
+    deg = degree_histogram(data)
+    hub = torch.stack([torch.arange(1, 41), torch.zeros(40, dtype=torch.int64)])
+    data.edge_index = torch.cat([data.edge_index, hub], dim=1).contiguous()
+    data.edge_attr = torch.cat([data.edge_attr, torch.zeros((40, 3), dtype=torch.int64)]).contiguous()
+    m = hip_twin(oracle_model(64, 1, 1, 1, 1, 3, True, True, deg, seed=2).eval())
+    with torch.no_grad():
+        out = m(data.to(DEV))
+    torch.cuda.synchronize()
+    assert m.input_error_flags() & 8 and out.shape[0] == 20
