@@ -37,6 +37,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "x6.hpp"
 
 namespace gs {
 
@@ -326,21 +327,6 @@ template <class T, class = void>
 struct provider_needs_affine : std::false_type {};
 template <class T>
 struct provider_needs_affine<T, std::void_t<decltype(T::kNeedsAffine)>> : std::bool_constant<T::kNeedsAffine> {};
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// a = hi + mid + lo exactly, each with 8 significand bits (the upper half of an f32 word): truncation splits
-__device__ __forceinline__ void gs_split3(float a, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
-  hi = __float_as_uint(a) & 0xffff0000u;
-  const float r1 = a - __uint_as_float(hi);          // exact: the low 16 significand bits
-  mid = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(mid);        // exact: at most 8 significand bits are left
-  lo = __float_as_uint(r2);                          // (its low half is zero)
-}
-// two bf16 (upper halves of x0, x1) in one dword, x0 in the low half (k order = memory order)
-__device__ __forceinline__ uint32_t gs_pack_hi16(uint32_t x0, uint32_t x1) { return (x0 >> 16) | (x1 & 0xffff0000u); }
-
-constexpr int kX6RowBytes = 48;   // 16 bf16 + 16 B of padding: 12 dwords = 4 x odd -> conflict-free b128 fragment reads
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, class AProv, bool STATS, bool AFFINE, bool RESID, bool X6 = false,
           int NT = 256>
@@ -734,7 +720,6 @@ enum GemmCfg { kCfg256x32 = 0, kCfg128x64 = 1, kCfg128x128 = 2, kCfg64x64 = 3, k
 static const int kCfgBM[kNumCfg] = {256, 128, 128, 64, 64, 128, 128};
 static const bool kCfgStatsOk[kNumCfg] = {true, true, true, false, true, false, true};
 
-static bool gemm_x6_enabled();
 
 static int pick_cfg(int64_t m, int n_out, int k, bool stats) {
   // measured on MI355X (tools/gemm_tune.py, tools/gemm_one.py; profiles/r01_gemm_tile_sweep.txt, r03_gemm_*)
@@ -750,7 +735,7 @@ static int pick_cfg(int64_t m, int n_out, int k, bool stats) {
 }
 
 // GNNSAFT_GEMM_X6 = 0 / 1 (default 1): the f32 matrix-core path, or the split-bf16 path at the same accuracy
-static bool gemm_x6_enabled() {
+bool gemm_x6_enabled() {
   static const bool on = [] {
     const char *e = getenv("GNNSAFT_GEMM_X6");
     return e == nullptr || e[0] != '0';

@@ -13,7 +13,10 @@
 //   TnPlain  : a row-major matrix (optionally ReLU'd: extra pre/post layers)
 //   (the PNAConv update input cat[x_i, A, A*amp_i, A*att_i] has its own kernel, k_gemm_tn_postfold)
 //   TnOneHot : concatenated one-hot rows of categorical columns (embedding tables: dE = OneHot^T dX)
+#include <type_traits>
+
 #include "common.hpp"
+#include "x6.hpp"
 
 namespace gs {
 
@@ -270,6 +273,154 @@ __global__ __launch_bounds__(64 * WN * WK) void k_gemm_tn_wide(const float *__re
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int nr = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (direct.on) {
+          if (nr < n_out && kc < k) {
+            const int64_t blk = nr / direct.so.rows_per_block;
+            float *o = direct.so.base[blk] + (nr - blk * direct.so.rows_per_block) * direct.ld_out + kc;
+            *o = direct.accumulate ? *o + acc[i][j][r] : acc[i][j][r];
+          }
+        } else if (full) {
+          slab[(int64_t)nr * k + kc] = acc[i][j][r];
+        } else if (nr < n_out && kc < k) {
+          slab[(int64_t)nr * k + kc] = acc[i][j][r];
+        }
+      }
+    }
+}
+
+// ---- split-bf16 variant (x6.hpp): the contraction runs over the ROWS, so the bf16 fragments of both operands are
+// k-strided in the row-major matrices.  The staging pass transposes in registers: a staging thread loads the SAME
+// float4 column group of FOUR consecutive rows, splits the 16 values into (hi, mid, lo) and writes, per column and
+// plane, the four rows' bf16 as one 8-byte word into an LDS image [column][16 rows] (48-byte rows as in gemm.hip, so
+// the fragments are plain ds_read_b128).  A stage is 16 rows (one MFMA k step), double-buffered.  4 x 4 waves of
+// 64 x 64 (the 256 x 256 tile of the wide f32 kernel): the first TN_ threads stage dY, the next TK_ the operand (waves
+// 0-7; two of the four waves of every SIMD).  Per 32 rows and 64 x 64 of output a wave issues 48 bf16 MFMAs of 8
+// passes where the f32 kernel issues 64 of 16 passes.
+// Measured (tools/tn_tune.py, C3: [163 907, 256]^T [., 256] and [., 1024]^T [., 256]): f32 230 / 793 us, this kernel
+// 180 / 567 us.  16 waves leave 128 registers per lane (64 of them accumulators).  Tried and dropped: the two halves
+// of the workgroup staging alternate stages (loads two stages ahead of their use) -- 196 / 650 us with the turn taken
+// under a condition inside one loop, 214 / 710 us with one straight-line loop per half; a second register set for the
+// same two-stage distance -- spills, 228 / 760 us; 8 waves of 64 x 128 (no spills, every thread stages) --
+// 234 / 706 us; a 64 x 64-tile variant (six MFMAs per barrier) -- slower than the f32 64 x 64 kernel.
+constexpr int kTnX6BK = 16;
+template <int WN, int WK, int TIN, int TIK, class AProv, bool Y_CLASS>
+__global__ __launch_bounds__(64 * WN * WK) void k_gemm_tn_x6(const float *__restrict__ dy, int64_t ldy, AProv ap,
+                                                             int64_t m, int n_out, int k, float *__restrict__ slabs,
+                                                             int64_t rows_per_z, TnDirect direct) {
+  constexpr int NT = 64 * WN * WK;
+  constexpr int TN_ = 32 * TIN * WN, TK_ = 32 * TIK * WK;
+  constexpr int PLANE = (TN_ + TK_) * kX6RowBytes;   // bytes per bf16 plane: dY columns, then operand columns
+  constexpr int STAGE = 3 * PLANE;
+  static_assert(TN_ + TK_ <= NT && (TN_ % 64) == 0 && (TK_ % 64) == 0, "one staging thread per 4 columns x 4 rows");
+  extern __shared__ __attribute__((aligned(16))) char lds_x6[];   // [2][3 planes][TN_ + TK_][48 B]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / WK, wk = wave % WK;
+  const int n0 = blockIdx.y * TN_, k0 = blockIdx.x * TK_;
+  const int64_t m_beg = (int64_t)blockIdx.z * rows_per_z;
+  int64_t m_end = m_beg + rows_per_z;
+  if (m_end > m) m_end = m;
+
+  // staging role (wave-uniform): 0 = dY, 1 = operand, 2 = none
+  const int role = tid < TN_ ? 0 : (tid < TN_ + TK_ ? 1 : 2);
+  const int su = role == 0 ? tid : tid - TN_;
+  const int sq = su & 3;          // rows 4 sq .. 4 sq + 3 of the stage
+  const int sc4 = su >> 2;        // float4 column group of the tile
+  f32x4 rr[4];
+  auto fetch = [&](int64_t mrow0) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (role == 0) {
+      const int nn = n0 + sc4 * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int64_t mm = mrow0 + 4 * sq + j;
+        const bool ok = mm < m_end;
+        mm = ok ? mm : m_end - 1;
+        f32x4 vy;
+        if (Y_CLASS) {
+          const int c = reinterpret_cast<const int32_t *>(dy)[mm] - nn;
+          vy = f32x4{c == 0 ? 1.f : 0.f, c == 1 ? 1.f : 0.f, c == 2 ? 1.f : 0.f, c == 3 ? 1.f : 0.f};
+        } else {
+          vy = gs_ld4(dy + mm * ldy + (nn < n_out ? nn : 0));
+        }
+        rr[j] = (ok && nn < n_out) ? vy : zero;   // rows past the chunk contribute nothing
+      }
+    } else if (role == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int64_t mm = mrow0 + 4 * sq + j;
+        const bool ok = mm < m_end;
+        mm = ok ? mm : m_end - 1;
+        const f32x4 va = ap.load(mm, k0 + sc4 * 4);
+        rr[j] = ok ? va : zero;
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    if (role == 2) return;
+    char *base = lds_x6 + buf * STAGE + ((role == 0 ? 0 : TN_) + sc4 * 4) * kX6RowBytes + sq * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {   // column 4 sc4 + e: its four rows as one 8-byte word per plane
+      uint32_t h[4], md[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gs_split3(rr[j][e], h[j], md[j], l[j]);
+      char *p = base + e * kX6RowBytes;
+      *reinterpret_cast<uint2 *>(p) = uint2{gs_pack_hi16(h[0], h[1]), gs_pack_hi16(h[2], h[3])};
+      *reinterpret_cast<uint2 *>(p + PLANE) = uint2{gs_pack_hi16(md[0], md[1]), gs_pack_hi16(md[2], md[3])};
+      *reinterpret_cast<uint2 *>(p + 2 * PLANE) = uint2{gs_pack_hi16(l[0], l[1]), gs_pack_hi16(l[2], l[3])};
+    }
+  };
+
+  f32x16 acc[TIN][TIK];
+#pragma unroll
+  for (int i = 0; i < TIN; ++i)
+#pragma unroll
+    for (int j = 0; j < TIK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int64_t steps = (m_end - m_beg + kTnX6BK - 1) / kTnX6BK;
+  fetch(m_beg);
+  stash(0);
+  __syncthreads();
+  const int frag = (lane & 31) * kX6RowBytes + (lane >> 5) * 16;
+  for (int64_t s = 0; s < steps; ++s) {
+    fetch(m_beg + (s + 1) * kTnX6BK);  // unconditional: rows past the slab come back as zeros
+    const char *xs = lds_x6 + (s & 1) * STAGE;
+    const char *ya = xs + (wn * 32 * TIN) * kX6RowBytes + frag;
+    const char *aa = xs + (TN_ + wk * 32 * TIK) * kX6RowBytes + frag;
+    bf16x8 yf[TIN][3], af[TIK][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TIN; ++i)
+        yf[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(ya + p * PLANE + i * 32 * kX6RowBytes));
+#pragma unroll
+      for (int j = 0; j < TIK; ++j)
+        af[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(aa + p * PLANE + j * 32 * kX6RowBytes));
+    }
+    constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < TIN; ++i)
+#pragma unroll
+        for (int j = 0; j < TIK; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i][pa[t]], af[j][pb[t]], acc[i][j], 0, 0, 0);
+    stash((s + 1) & 1);
+    __syncthreads();
+  }
+  // C/D: col = lane & 31 (k), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (n)
+  float *slab = slabs + (int64_t)blockIdx.z * n_out * (int64_t)k;
+  const bool full = n0 + TN_ <= n_out && k0 + TK_ <= k;  // block-uniform: unguarded stores, issued back to back
+#pragma unroll
+  for (int i = 0; i < TIN; ++i)
+#pragma unroll
+    for (int j = 0; j < TIK; ++j) {
+      const int kc = k0 + wk * 32 * TIK + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nr = n0 + wn * 32 * TIN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (direct.on) {
           if (nr < n_out && kc < k) {
             const int64_t blk = nr / direct.so.rows_per_block;
@@ -607,6 +758,22 @@ static void launch_tn_wide(const float *dy, int64_t ldy, const AProv &ap, int64_
                      n_out, k, slabs, rows_per_z, direct);
 }
 
+template <int WN, int WK, int TIN, int TIK, class AProv, bool Y_CLASS>
+static void launch_tn_x6(const float *dy, int64_t ldy, const AProv &ap, int64_t m, int n_out, int k, float *slabs,
+                         int64_t rows_per_z, int64_t chunks, const TnDirect &direct, hipStream_t st) {
+  constexpr int TN_ = 32 * TIN * WN, TK_ = 32 * TIK * WK;
+  constexpr size_t lds_bytes = 2 * 3 * (size_t)(TN_ + TK_) * kX6RowBytes;
+  static_assert(lds_bytes <= 160 * 1024, "two stages of three planes");
+  static const bool attr = [] {   // > 64 KB of dynamic LDS has to be requested once per kernel
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_x6<WN, WK, TIN, TIK, AProv, Y_CLASS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+  }();
+  (void)attr;
+  const dim3 grid((unsigned)gs_ceil_div(k, TK_), (unsigned)gs_ceil_div(n_out, TN_), (unsigned)chunks);
+  hipLaunchKernelGGL((k_gemm_tn_x6<WN, WK, TIN, TIK, AProv, Y_CLASS>), grid, dim3(64 * WN * WK), lds_bytes, st, dy, ldy, ap,
+                     m, n_out, k, slabs, rows_per_z, direct);
+}
+
 // rows per slab and slab count: ~one resident set of workgroups, at least two 32-row stages each
 static inline void tn_chunking(int64_t m, int64_t tiles, int64_t resident, int64_t &rows_per_z, int64_t &chunks) {
   chunks = gs_ceil_div(resident, tiles);
@@ -621,7 +788,7 @@ template <class AProv, bool Y_CLASS = false>
 static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, int n_out, int k, float *out,
                      int64_t ld_out, int accumulate, float *slabs, size_t slab_bytes, hipStream_t st,
                      const SlabOut *scatter = nullptr, int force_wn = 0, int force_wk = 0, int64_t force_chunks = 0,
-                     SlabQueue *defer = nullptr) {
+                     SlabQueue *defer = nullptr, int force_x6 = -1) {
   GS_REQUIRE(dy && (out || scatter) && (slabs || defer), GNNSAFT_ERR_NULL);
   GS_REQUIRE(m >= 1 && n_out >= 1 && k >= 4 && (k % 4) == 0 && (Y_CLASS || (ldy % 4) == 0) && (ld_out % 4) == 0,
              GNNSAFT_ERR_SHAPE);
@@ -649,6 +816,16 @@ static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, i
   SlabOut so{{out, out, out, out}, (int64_t)1 << 40};
   if (scatter != nullptr) so = *scatter;
   TnDirect direct{so, ld_out, chunks == 1 ? 1 : 0, accumulate};
+  // split-bf16 kernel for the 4 x 4 grid; the 64 x 64 kernel and the 2 x 2 / 4 x 2 grids stay f32
+  const bool x6 = force_x6 < 0 ? gemm_x6_enabled() : force_x6 != 0;
+  constexpr bool kHasX6 = std::is_same_v<AProv, TnPlain> && !Y_CLASS;   // (the one-hot providers spill in it)
+  if constexpr (kHasX6) {
+    if (x6 && wn == 4 && wk == 4) {
+      launch_tn_x6<4, 4, 2, 2, AProv, Y_CLASS>(dy, ldy, ap, m, n_out, k, slabs, rows_per_z, chunks, direct, st);
+      wn = wk = -1;   // done
+    }
+  }
+  if (wn > 0)
   switch (wn * 8 + wk) {
 #define GS_TN_CASE(WN_, WK_)                                                                                  \
   case WN_ * 8 + WK_:                                                                                         \
@@ -871,15 +1048,24 @@ int launch_colsum_blocks(const float *a, int64_t lda, int64_t m, int num_blocks,
 }  // namespace gs
 
 // tuning aid (tools/tn_tune.py): the weight-gradient GEMM with an explicit wave grid (wn x wk waves of 64 x 64 each;
-// 1 x 1 = the 64 x 64 four-wave kernel) and slab count; 0 = the library's own choice.  No global state.
+// 1 x 1 = the 64 x 64 four-wave kernel) and slab count; 0 = the library's own choice; wn + 16 / wn + 32 force the
+// split-bf16 / the f32 kernel (the 4 x 4 grid exists in both).  No global state.
 extern "C" int gnnsaft_debug_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t lda, int64_t m,
                                           int32_t n_out, int32_t k, float *dw, int64_t ld_dw, void *scratch,
                                           size_t scratch_bytes, int32_t wn, int32_t wk, int64_t chunks,
                                           gnnsaft_stream_t stream) {
   GS_REQUIRE(a != nullptr && (lda % 4) == 0, GNNSAFT_ERR_SHAPE);
   gs::TnPlain ap{a, lda, 0, k};
+  int force_x6 = -1;   // wn + 16: the split-bf16 kernel, wn + 32: the f32 kernel, else the library's mode
+  if (wn >= 32) {
+    force_x6 = 0;
+    wn -= 32;
+  } else if (wn >= 16) {
+    force_x6 = 1;
+    wn -= 16;
+  }
   return gs::launch_tn(dy, ldy, ap, m, n_out, k, dw, ld_dw, 0, static_cast<float *>(scratch), scratch_bytes,
-                       static_cast<hipStream_t>(stream), nullptr, wn, wk, chunks);
+                       static_cast<hipStream_t>(stream), nullptr, wn, wk, chunks, nullptr, force_x6);
 }
 
 extern "C" size_t gnnsaft_wgrad_scratch_bytes(int64_t m, int32_t n_out, int32_t k) {

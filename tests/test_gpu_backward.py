@@ -47,7 +47,8 @@ def test_wgrad_tn_kernel_matches_f64():
         if n_out >= 100 and ld == n_out:   # every wave grid of the wide kernel on the same operands (tools/tn_tune.py)
             need2 = max(need, 1024 * n_out * k * 4)
             scratch2 = torch.empty(need2 + 256, dtype=torch.uint8, device=DEV)
-            for wn, wk in ((2, 2), (4, 2), (4, 4)):
+            # (+ 16: the split-bf16 kernel, + 32: the f32 kernel -- the 4 x 4 grid exists in both)
+            for wn, wk in ((2, 2), (4, 2), (4 + 16, 4), (4 + 32, 4), (1, 1)):
                 dw2 = torch.full((n_out, k), float("nan"), device=DEV)
                 check(lib.gnnsaft_debug_linear_wgrad(dyd.data_ptr(), ld, ad.data_ptr(), k, m, n_out, k, dw2.data_ptr(), k,
                                                      scratch2.data_ptr(), need2, wn, wk, 0, stream),

@@ -49,9 +49,10 @@ def main():
         dw = torch.empty(n_out, k, device=DEV)
         gflop = 2.0 * m * n_out * k / 1e9
         print(f"== {name}: m={m} n_out={n_out} k={k} ({gflop:.2f} GFLOP)")
-        grids = [(0, 0), (1, 1), (2, 2), (4, 2), (4, 4)]   # 0x0: the library's choice
+        # 0x0: the library's choice; + 16 / + 32 on wn: split-bf16 / f32 kernel
+        grids = [(0, 0), (1, 1), (2, 2), (4, 2), (4 + 32, 4), (4 + 16, 4)]
         for wn, wk in grids:
-            line = f"  {wn}x{wk}:"
+            line = f"  {wn % 16}x{wk}{' x6 ' if 16 <= wn < 32 else (' f32' if wn >= 32 else '    ')}:"
             for chunks in ((0,) if wn == 0 else (0, 64, 128, 256, 512)):
                 if chunks and chunks * 64 > m:
                     continue
@@ -62,7 +63,7 @@ def main():
                                                          torch.cuda.current_stream().cuda_stream), "wgrad")
                 us = timeit(fn)
                 err = float((dw.double() - ref).abs().max() / ref.abs().max())
-                line += f"  z={chunks or 'auto'}: {us:7.1f} us {gflop / us * 1e-3:5.1f} TF" + ("" if err < 3e-6 else f" ERR {err:.1e}")
+                line += f"  z={chunks or 'auto'}: {us:7.1f} us {gflop / us * 1e3:5.1f} TF" + ("" if err < 3e-6 else f" ERR {err:.1e}")
             print(line, flush=True)
 
 
