@@ -1005,7 +1005,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     // update weight / bias gradients (side; du is final: with extra post layers everything is on one stream)
     GS_TRY(launch_wgrad_post_folded(du, x_l, agg_l, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap,
                                     pna_fold_tile_rows(h), w.avg, h, G(i_post0), G(i_post1), slabs, slab_bytes, sa,
-                                    dq));
+                                    dq, I(p.hist3), n));
     {  // both towers' bias gradients: column sums of du, halves to two tensors
       float *outs[2] = {G(i_post0 + 1), G(i_post1 + 1)};
       GS_TRY(launch_colsum_blocks(du, h, n, 2, h / 2, outs, slabs, slab_bytes, sa, dq));

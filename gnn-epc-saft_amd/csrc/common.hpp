@@ -209,7 +209,9 @@ int launch_wgrad_plain_blocks(const float *dy, int64_t ldy, const float *a, int6
 int launch_wgrad_post_folded(const float *du, const float *x, const float *agg, const int32_t *perm,
                              const int32_t *tiles, const int32_t *num_tiles, int64_t tile_cap, int tile_rows,
                              const float *avg, int hidden, float *dw0, float *dw1, float *slabs, size_t slab_bytes,
-                             hipStream_t st, SlabQueue *defer = nullptr);
+                             hipStream_t st, SlabQueue *defer = nullptr,
+                             const int32_t *hist = nullptr /* nodes per in-degree: enables the wide kernel */,
+                             int64_t num_nodes = 0);
 size_t wgrad_post_folded_slab_bytes(int64_t tile_cap, int tile_rows, int hidden);
 // out[c, :] = sum of the rows of `a` whose class id is c (one-hot TN GEMM: deterministic, no atomics)
 int launch_sum_rows_by_class(const int32_t *cls, int num_classes, const float *a, int64_t lda, int64_t m, int k,

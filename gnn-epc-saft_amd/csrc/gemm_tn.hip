@@ -566,6 +566,224 @@ __global__ __launch_bounds__(256) void k_gemm_tn_postfold(TnFoldArgs a, float *_
   }
 }
 
+// ---- the same gradient for LARGE batches, split-bf16 and wide (x6.hpp, k_gemm_tn_x6): a workgroup owns ONE chunk of
+// rows of ONE in-degree (the permutation is sorted by degree; chunk z -> (degree, first slot, rows) is derived from
+// the degree histogram by every workgroup itself) and writes the chunk's plain partial product S_z = du_t^T [x | A_t]
+// ([F/2, 5F] per tower) to its slab.  The degree scalers are applied when the slabs are summed (k_sum_slabs_fold):
+// id += S_z, amp += amp(d_z) S_z, att += att(d_z) S_z -- no fold accumulators in the GEMM, 5 F^2 floats per slab
+// instead of 13 F^2 and ~100 slabs instead of ~330 at C3.
+struct TnFoldWideArgs {
+  const float *du;        // [N, F]
+  const float *x;         // [N, F]
+  const float *agg;       // [N, 2, 4F]
+  const int32_t *perm;    // slot -> node, sorted by in-degree
+  const int32_t *hist;    // [kDegreeBuckets] nodes per in-degree
+  const float *avg;       // device [1]
+  int f;
+  int chunk_rows;
+};
+
+// chunk z -> its degree, first slot of the permutation and row count; false past the last chunk
+__device__ __forceinline__ bool fold_chunk(const int32_t *__restrict__ hist, int chunk_rows, int z, int &deg,
+                                           int &slot0, int &count) {
+  int slot = 0;
+  for (int d = 0; d < kDegreeBuckets; ++d) {
+    const int c = hist[d];
+    const int nc = (c + chunk_rows - 1) / chunk_rows;
+    if (z < nc) {
+      deg = d;
+      slot0 = slot + z * chunk_rows;
+      const int left = c - z * chunk_rows;
+      count = left < chunk_rows ? left : chunk_rows;
+      return true;
+    }
+    z -= nc;
+    slot += c;
+  }
+  return false;
+}
+
+template <int WN, int WK, int TIN, int TIK>
+__global__ __launch_bounds__(64 * WN * WK) void k_gemm_tn_postfold_x6(TnFoldWideArgs a, float *__restrict__ slabs) {
+  constexpr int NT = 64 * WN * WK;
+  constexpr int TN_ = 32 * TIN * WN, TK_ = 32 * TIK * WK;
+  constexpr int PLANE = (TN_ + TK_) * kX6RowBytes;
+  constexpr int STAGE = 3 * PLANE;
+  static_assert(TN_ + TK_ <= NT && (TN_ % 64) == 0 && (TK_ % 64) == 0, "one staging thread per 4 columns x 4 rows");
+  extern __shared__ __attribute__((aligned(16))) char lds_x6[];   // [2][3 planes][TN_ + TK_][48 B]
+  int deg, slot0, count;
+  if (!fold_chunk(a.hist, a.chunk_rows, (int)blockIdx.z, deg, slot0, count)) return;   // (block-uniform)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / WK, wk = wave % WK;
+  const int f = a.f, n_out = f / 2, kfold = 5 * f;
+  const int n_tiles_n = n_out / TN_;
+  const int tower = blockIdx.y / n_tiles_n;
+  const int n0 = (blockIdx.y - tower * n_tiles_n) * TN_, k0 = blockIdx.x * TK_;
+  const bool agg_part = k0 >= f;   // a k tile lies wholly in the x block or in the aggregate block (F % TK_ == 0)
+
+  const int role = tid < TN_ ? 0 : (tid < TN_ + TK_ ? 1 : 2);   // wave-uniform: dY | operand | none
+  const int su = role == 0 ? tid : tid - TN_;
+  const int sq = su & 3;
+  const int sc4 = su >> 2;
+  const float *col = role == 0 ? a.du + tower * n_out + n0 + sc4 * 4
+                               : (agg_part ? a.agg + tower * 4 * f + (k0 - f) + sc4 * 4 : a.x + k0 + sc4 * 4);
+  const int64_t ld = role == 0 ? f : (agg_part ? 8 * (int64_t)f : f);
+  const int32_t *perm = a.perm + slot0;
+  int nid[4];   // the nodes of this thread's four rows of the NEXT stage to fetch
+  auto fetch_ids = [&](int row0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = row0 + 4 * sq + j;
+      nid[j] = perm[r < count ? r : count - 1];
+    }
+  };
+  f32x4 rr[4];
+  auto fetch = [&](int row0) {   // rows row0 .. row0 + 15 of the chunk (their node ids are in nid)
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (role != 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 v = gs_ld4(col + (int64_t)nid[j] * ld);
+        rr[j] = row0 + 4 * sq + j < count ? v : zero;
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    if (role == 2) return;
+    char *base = lds_x6 + buf * STAGE + ((role == 0 ? 0 : TN_) + sc4 * 4) * kX6RowBytes + sq * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t h[4], md[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gs_split3(rr[j][e], h[j], md[j], l[j]);
+      char *p = base + e * kX6RowBytes;
+      *reinterpret_cast<uint2 *>(p) = uint2{gs_pack_hi16(h[0], h[1]), gs_pack_hi16(h[2], h[3])};
+      *reinterpret_cast<uint2 *>(p + PLANE) = uint2{gs_pack_hi16(md[0], md[1]), gs_pack_hi16(md[2], md[3])};
+      *reinterpret_cast<uint2 *>(p + 2 * PLANE) = uint2{gs_pack_hi16(l[0], l[1]), gs_pack_hi16(l[2], l[3])};
+    }
+  };
+
+  f32x16 acc[TIN][TIK];
+#pragma unroll
+  for (int i = 0; i < TIN; ++i)
+#pragma unroll
+    for (int j = 0; j < TIK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int steps = (count + kTnX6BK - 1) / kTnX6BK;
+  fetch_ids(0);
+  fetch(0);
+  fetch_ids(kTnX6BK);
+  stash(0);
+  __syncthreads();
+  const int frag = (lane & 31) * kX6RowBytes + (lane >> 5) * 16;
+  for (int s = 0; s < steps; ++s) {
+    fetch((s + 1) * kTnX6BK);        // (node ids loaded one stage earlier; rows past the chunk come back as zeros)
+    fetch_ids((s + 2) * kTnX6BK);
+    const char *xs = lds_x6 + (s & 1) * STAGE;
+    const char *ya = xs + (wn * 32 * TIN) * kX6RowBytes + frag;
+    const char *aa = xs + (TN_ + wk * 32 * TIK) * kX6RowBytes + frag;
+    bf16x8 yf[TIN][3], af[TIK][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TIN; ++i)
+        yf[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(ya + p * PLANE + i * 32 * kX6RowBytes));
+#pragma unroll
+      for (int j = 0; j < TIK; ++j)
+        af[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(aa + p * PLANE + j * 32 * kX6RowBytes));
+    }
+    constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};   // smallest products first
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < TIN; ++i)
+#pragma unroll
+        for (int j = 0; j < TIK; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i][pa[t]], af[j][pb[t]], acc[i][j], 0, 0, 0);
+    stash((s + 1) & 1);
+    __syncthreads();
+  }
+  // slab z: [2 towers][F/2][5F].  C/D: col = lane & 31 (k), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (n)
+  float *slab = slabs + ((int64_t)blockIdx.z * 2 + tower) * n_out * (int64_t)kfold;
+#pragma unroll
+  for (int i = 0; i < TIN; ++i)
+#pragma unroll
+    for (int j = 0; j < TIK; ++j) {
+      const int kc = k0 + wk * 32 * TIK + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nr = n0 + wn * 32 * TIN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        slab[(int64_t)nr * kfold + kc] = acc[i][j][r];   // (tiles are full: F/2 % TN_ == 0, 5F % TK_ == 0)
+      }
+    }
+}
+
+// dW_t[n][0:F] = sum_z S_z[.][0:F];  dW_t[n][F + j | 5F + j | 9F + j] = sum_z (1 | amp(d_z) | att(d_z)) S_z[.][F + j]
+// over the chunks in ascending order (fixed: bitwise reproducible).  One thread per float4 of the folded [2][F/2][5F].
+constexpr int kFoldSumMaxChunks = 1024;
+__global__ __launch_bounds__(256) void k_sum_slabs_fold(const float *__restrict__ slabs, const int32_t *__restrict__ hist,
+                                                        const float *__restrict__ avg, int chunk_rows, int f,
+                                                        float *__restrict__ dw0, float *__restrict__ dw1) {
+  __shared__ float s_amp[kFoldSumMaxChunks], s_att[kFoldSumMaxChunks];
+  __shared__ int s_total;
+  if (threadIdx.x == 0) {
+    const float avgv = avg[0];
+    int z = 0;
+    for (int d = 0; d < kDegreeBuckets; ++d) {
+      const int nc = (hist[d] + chunk_rows - 1) / chunk_rows;
+      float amp, att;
+      degree_scalers(d, avgv, amp, att);
+      for (int c = 0; c < nc && z < kFoldSumMaxChunks; ++c, ++z) {
+        s_amp[z] = amp;
+        s_att[z] = att;
+      }
+    }
+    s_total = z;
+  }
+  __syncthreads();
+  const int total = s_total;
+  const int n_out = f / 2, kfold = 5 * f, per_row4 = kfold / 4;
+  const int64_t per_slab = 2 * (int64_t)n_out * kfold;
+  const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 >= per_slab / 4) return;
+  const int64_t row = i4 / per_row4;            // tower * n_out + n
+  const int k = (int)(i4 - row * per_row4) * 4;
+  const float *src = slabs + i4 * 4;
+  f32x4 sid = {0.f, 0.f, 0.f, 0.f}, samp = sid, satt = sid;
+  const bool agg_part = k >= f;
+  for (int z0 = 0; z0 < total; z0 += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int z = z0 + u < total ? z0 + u : total - 1;
+      v[u] = gs_ld4(src + (int64_t)z * per_slab);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (z0 + u < total) {
+        sid += v[u];
+        if (agg_part) {
+          const float wa = s_amp[z0 + u], wt = s_att[z0 + u];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            samp[e] = fmaf(wa, v[u][e], samp[e]);
+            satt[e] = fmaf(wt, v[u][e], satt[e]);
+          }
+        }
+      }
+  }
+  const int tower = (int)(row / n_out);
+  float *o = (tower == 0 ? dw0 : dw1) + (row - (int64_t)tower * n_out) * (13 * (int64_t)f) + k;
+  gs_st4(o, sid);
+  if (agg_part) {
+    gs_st4(o + 4 * f, samp);
+    gs_st4(o + 8 * f, satt);
+  }
+}
+
 // out[i] (+)= sum over the slabs; 8 slab lanes per output float4, combined in a fixed order
 // The dense result [rows, cols] may be scattered by row blocks: block b = row / rows_per_block goes to base[b]
 // (several weight gradients that share one TN GEMM, e.g. the four [F,F] blocks of the message weights).
@@ -904,10 +1122,43 @@ int launch_wgrad_plain_blocks(const float *dy, int64_t ldy, const float *a, int6
 int launch_wgrad_post_folded(const float *du, const float *x, const float *agg, const int32_t *perm,
                              const int32_t *tiles, const int32_t *num_tiles, int64_t tile_cap, int tile_rows,
                              const float *avg, int hidden, float *dw0, float *dw1 /* [F/2,13F] each */, float *slabs,
-                             size_t slab_bytes, hipStream_t st, SlabQueue *defer) {
+                             size_t slab_bytes, hipStream_t st, SlabQueue *defer, const int32_t *hist,
+                             int64_t num_nodes) {
   GS_REQUIRE(du && x && agg && perm && tiles && num_tiles && avg && dw0 && dw1 && (slabs || defer), GNNSAFT_ERR_NULL);
   GS_REQUIRE((hidden % 64) == 0 && tile_rows >= kTnBK && (tile_rows % kTnBK) == 0 && tile_cap >= 1,
              GNNSAFT_ERR_UNSUPPORTED);
+  // large batches, F a multiple of 256: the wide split-bf16 kernel over single-degree chunks (see above)
+  if (hist != nullptr && gemm_x6_enabled() && (hidden % 256) == 0 && num_nodes >= 32768) {
+    int64_t chunk_rows = gs_ceil_div(gs_ceil_div(num_nodes, (int64_t)64), (int64_t)kTnX6BK) * kTnX6BK;
+    const int64_t zcap = num_nodes / chunk_rows + 1 + kDegreeBuckets;
+    const size_t need = (size_t)zcap * 2 * (hidden / 2) * 5 * hidden;   // floats
+    float *sl = slabs;
+    bool ok = zcap <= kFoldSumMaxChunks;
+    if (defer != nullptr) {
+      sl = ok ? defer->take(need) : nullptr;
+      ok = sl != nullptr;
+    } else {
+      ok = ok && slab_bytes >= need * 4;
+    }
+    if (ok) {
+      TnFoldWideArgs a{du, x, agg, perm, hist, avg, hidden, (int)chunk_rows};
+      constexpr int WN = 4, WK = 4, TIN = 1, TIK = 2;   // 128 x 256 tile, 16 waves of 32 x 64
+      constexpr int TN_ = 32 * TIN * WN, TK_ = 32 * TIK * WK;
+      constexpr size_t lds_bytes = 2 * 3 * (size_t)(TN_ + TK_) * kX6RowBytes;
+      static const bool attr = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_postfold_x6<WN, WK, TIN, TIK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+      }();
+      (void)attr;
+      const dim3 grid((unsigned)(5 * hidden / TK_), (unsigned)(2 * (hidden / 2 / TN_)), (unsigned)zcap);
+      hipLaunchKernelGGL((k_gemm_tn_postfold_x6<WN, WK, TIN, TIK>), grid, dim3(64 * WN * WK), lds_bytes, st, a, sl);
+      const int64_t out4 = 2 * (int64_t)(hidden / 2) * 5 * hidden / 4;
+      hipLaunchKernelGGL(k_sum_slabs_fold, dim3((unsigned)gs_ceil_div(out4, 256)), dim3(256), 0, st, sl, hist, avg,
+                         (int)chunk_rows, hidden, dw0, dw1);
+      GS_CHECK_LAUNCH();
+      return GNNSAFT_OK;
+    }
+  }
   // ~256 rows per workgroup along the contraction, as launch_tn does
   const int tiles_per_z = tile_rows >= 2 * kTnChunk ? 1 : 2 * kTnChunk / tile_rows;
   const int64_t chunks = gs_ceil_div(tile_cap, (int64_t)tiles_per_z);

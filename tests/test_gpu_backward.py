@@ -156,6 +156,7 @@ FULL_SIZE = [
     # (the f64 oracle's forward + backward on the CPU is what bounds the size: ~30 s resp. ~50 s)
     (1024, 128, 3, 3),
     (512, 256, 5, 3),
+    (1700, 256, 1, 3),   # 34 k nodes: the wide split-bf16 weight-gradient kernels (gemm_tn.hip: rows >= 32768)
 ]
 
 
