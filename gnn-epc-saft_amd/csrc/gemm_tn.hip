@@ -13,6 +13,7 @@
 //   TnPlain  : a row-major matrix (optionally ReLU'd: extra pre/post layers)
 //   (the PNAConv update input cat[x_i, A, A*amp_i, A*att_i] has its own kernel, k_gemm_tn_postfold)
 //   TnOneHot : concatenated one-hot rows of categorical columns (embedding tables: dE = OneHot^T dX)
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.hpp"
@@ -1127,8 +1128,14 @@ int launch_wgrad_post_folded(const float *du, const float *x, const float *agg, 
   GS_REQUIRE(du && x && agg && perm && tiles && num_tiles && avg && dw0 && dw1 && (slabs || defer), GNNSAFT_ERR_NULL);
   GS_REQUIRE((hidden % 64) == 0 && tile_rows >= kTnBK && (tile_rows % kTnBK) == 0 && tile_cap >= 1,
              GNNSAFT_ERR_UNSUPPORTED);
-  // large batches, F a multiple of 256: the wide split-bf16 kernel over single-degree chunks (see above)
-  if (hist != nullptr && gemm_x6_enabled() && (hidden % 256) == 0 && num_nodes >= 32768) {
+  // large batches, F a multiple of 128: the split-bf16 kernel over single-degree chunks (see above) -- 128 x 256 tiles
+  // of 16 waves for F % 256 == 0, 64 x 128 tiles of 4 waves otherwise.  (At C2, 20 k rows, it is no faster than the
+  // tile-table kernel -- 68 vs 75 us, both bound by load latency -- and its slab sum costs 16 us: not used there.)
+  const char *pf_env = getenv("GNNSAFT_POSTFOLD_X6");   // tuning aid: 0 = the f32 tile-table kernel everywhere
+  const bool pf_on = pf_env == nullptr || pf_env[0] != '0';
+  if (hist != nullptr && gemm_x6_enabled() && pf_on && (hidden % 128) == 0 && num_nodes >= 32768) {
+    const bool big = (hidden % 256) == 0;
+    // ~64 chunks: with 10 (k tile, tower) workgroups per chunk that is 2-3 resident sets of workgroups
     int64_t chunk_rows = gs_ceil_div(gs_ceil_div(num_nodes, (int64_t)64), (int64_t)kTnX6BK) * kTnX6BK;
     const int64_t zcap = num_nodes / chunk_rows + 1 + kDegreeBuckets;
     const size_t need = (size_t)zcap * 2 * (hidden / 2) * 5 * hidden;   // floats
@@ -1142,16 +1149,26 @@ int launch_wgrad_post_folded(const float *du, const float *x, const float *agg, 
     }
     if (ok) {
       TnFoldWideArgs a{du, x, agg, perm, hist, avg, hidden, (int)chunk_rows};
-      constexpr int WN = 4, WK = 4, TIN = 1, TIK = 2;   // 128 x 256 tile, 16 waves of 32 x 64
-      constexpr int TN_ = 32 * TIN * WN, TK_ = 32 * TIK * WK;
-      constexpr size_t lds_bytes = 2 * 3 * (size_t)(TN_ + TK_) * kX6RowBytes;
-      static const bool attr = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_postfold_x6<WN, WK, TIN, TIK>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
-      }();
-      (void)attr;
-      const dim3 grid((unsigned)(5 * hidden / TK_), (unsigned)(2 * (hidden / 2 / TN_)), (unsigned)zcap);
-      hipLaunchKernelGGL((k_gemm_tn_postfold_x6<WN, WK, TIN, TIK>), grid, dim3(64 * WN * WK), lds_bytes, st, a, sl);
+      auto run = [&](auto wn_, auto wk_, auto tin_, auto tik_) {
+        constexpr int WN = decltype(wn_)::value, WK = decltype(wk_)::value, TIN = decltype(tin_)::value,
+                      TIK = decltype(tik_)::value;
+        constexpr int TN_ = 32 * TIN * WN, TK_ = 32 * TIK * WK;
+        constexpr size_t lds_bytes = 2 * 3 * (size_t)(TN_ + TK_) * kX6RowBytes;
+        static const bool attr = [] {
+          return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_postfold_x6<WN, WK, TIN, TIK>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+        }();
+        (void)attr;
+        const dim3 grid((unsigned)(5 * hidden / TK_), (unsigned)(2 * (hidden / 2 / TN_)), (unsigned)zcap);
+        hipLaunchKernelGGL((k_gemm_tn_postfold_x6<WN, WK, TIN, TIK>), grid, dim3(64 * WN * WK), lds_bytes, st, a, sl);
+      };
+      using std::integral_constant;
+      if (big)
+        run(integral_constant<int, 4>{}, integral_constant<int, 4>{}, integral_constant<int, 1>{},
+            integral_constant<int, 2>{});   // 128 x 256, 16 waves of 32 x 64
+      else
+        run(integral_constant<int, 2>{}, integral_constant<int, 2>{}, integral_constant<int, 1>{},
+            integral_constant<int, 2>{});   // 64 x 128, 4 waves of 32 x 64
       const int64_t out4 = 2 * (int64_t)(hidden / 2) * 5 * hidden / 4;
       hipLaunchKernelGGL(k_sum_slabs_fold, dim3((unsigned)gs_ceil_div(out4, 256)), dim3(256), 0, st, sl, hist, avg,
                          (int)chunk_rows, hidden, dw0, dw1);
