@@ -477,7 +477,7 @@ def main() -> None:
     c3_block = None
     if rank == 0 and world == 1 and args.config == 2 and not args.no_c3:
         try:
-            c3_block = measure_c3(dev, stream, event_overhead_ms)
+            c3_block = measure_c3(dev, stream, event_overhead_ms, train_steps=5 if args.train_steps > 0 else 0)
         except Exception as exc:  # noqa: BLE001
             c3_block = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
@@ -676,7 +676,7 @@ def measure_c4(dev, rank, world, stream, steps: int = 10, warmup: int = 3, train
     return (block if rank == 0 else None), flags
 
 
-def measure_c3(dev, stream, event_overhead_ms, steps: int = 10, warmup: int = 3):
+def measure_c3(dev, stream, event_overhead_ms, steps: int = 10, warmup: int = 3, train_steps: int = 5):
     """10 eager steps of BASELINE.json configs[2] on this GPU: graphs/s plus the K4 / GEMM rooflines."""
     wl = Workload(CONFIGS[3], dev, 0, 3)
 
@@ -697,7 +697,34 @@ def measure_c3(dev, stream, event_overhead_ms, steps: int = 10, warmup: int = 3)
     out = {"workload": wl.describe() + ", train-mode BatchNorm forward + MAPE loss, eager", "steps": steps,
            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "graphs_per_s": wl.cfg["graphs"] * steps / elapsed,
            "nodes": wl.n, "edges_with_self_loops": wl.e_prime, "final_loss": float(parts[0]),
-           "roofline": roof, "roofline_gemm": gemm, "_flags": wl.model.model.input_error_flags()}
+           "roofline": roof, "roofline_gemm": gemm}
+    if train_steps > 0:
+        # the training step on the same batch: forward (tape) + MAPE + backward + fused AdamW + schedule, eager
+        conf = wl.model.configure_optimizers()
+        opt, sched = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+
+        def train_step():
+            opt.zero_grad(set_to_none=True)
+            wl.model.training_step(wl.ddev).backward()
+            opt.step()
+            sched.step()
+
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                train_step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(train_steps):
+                train_step()
+            barrier()
+            el = time.perf_counter() - t1
+        out["train_step"] = {"what": "forward + MAPE + backward (all parameter gradients) + fused AdamW(amsgrad) step "
+                                     "+ LR schedule step, eager", "steps": train_steps,
+                             "ms_per_step": el / train_steps * 1e3,
+                             "graphs_per_s": wl.cfg["graphs"] * train_steps / el,
+                             "vs_forward_loss": (el / train_steps) / (elapsed / steps)}
+        del opt, sched, conf
+    out["_flags"] = wl.model.model.input_error_flags()
     del wl
     torch.cuda.empty_cache()
     return out

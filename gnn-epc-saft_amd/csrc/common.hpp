@@ -60,6 +60,21 @@ __device__ __forceinline__ void gs_split(const RowSplit rs, int64_t slot, int64_
 __device__ __forceinline__ f32x4 gs_ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void gs_st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
+// The dynamic-LDS limit above 64 KB is a property of (kernel, DEVICE): raise it once per device this process drives
+// (`devices`: one static bitmask per kernel instantiation; bit d = done on device d; devices >= 64: every launch).
+// Safe from several host threads.
+#include <atomic>
+static inline hipError_t gs_raise_dynamic_lds(const void *kernel, size_t bytes, std::atomic<unsigned long long> &devices) {
+  int dev = 0;
+  hipError_t rc = hipGetDevice(&dev);
+  if (rc != hipSuccess) return rc;
+  const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+  if ((devices.load(std::memory_order_acquire) & bit) != 0ull) return hipSuccess;
+  rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (rc == hipSuccess) devices.fetch_or(bit, std::memory_order_release);
+  return rc;
+}
+
 namespace gs {
 
 // ---- internal launchers shared between the C ABI wrappers and gnnsaft_forward

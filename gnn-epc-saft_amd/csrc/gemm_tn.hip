@@ -967,11 +967,9 @@ static void launch_tn_wide(const float *dy, int64_t ldy, const AProv &ap, int64_
                            int64_t rows_per_z, int64_t chunks, const TnDirect &direct, hipStream_t st) {
   constexpr int TN_ = 64 * WN, TK_ = 64 * WK;
   constexpr size_t lds_bytes = 2 * (size_t)kTnBK * (TN_ + TK_ + 8) * 4;
-  static const bool attr = [] {   // > 64 KB of dynamic LDS has to be requested once per kernel
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_wide<WN, WK, AProv, Y_CLASS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
-  }();
-  (void)attr;
+  static std::atomic<unsigned long long> lds_raised{0};   // > 64 KB of dynamic LDS: once per kernel and device
+  (void)gs_raise_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_tn_wide<WN, WK, AProv, Y_CLASS>), lds_bytes,
+                             lds_raised);
   const dim3 grid((unsigned)gs_ceil_div(k, TK_), (unsigned)gs_ceil_div(n_out, TN_), (unsigned)chunks);
   hipLaunchKernelGGL((k_gemm_tn_wide<WN, WK, AProv, Y_CLASS>), grid, dim3(64 * WN * WK), lds_bytes, st, dy, ldy, ap, m,
                      n_out, k, slabs, rows_per_z, direct);
@@ -983,11 +981,9 @@ static void launch_tn_x6(const float *dy, int64_t ldy, const AProv &ap, int64_t 
   constexpr int TN_ = 32 * TIN * WN, TK_ = 32 * TIK * WK;
   constexpr size_t lds_bytes = 2 * 3 * (size_t)(TN_ + TK_) * kX6RowBytes;
   static_assert(lds_bytes <= 160 * 1024, "two stages of three planes");
-  static const bool attr = [] {   // > 64 KB of dynamic LDS has to be requested once per kernel
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_x6<WN, WK, TIN, TIK, AProv, Y_CLASS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
-  }();
-  (void)attr;
+  static std::atomic<unsigned long long> lds_raised{0};   // > 64 KB of dynamic LDS: once per kernel and device
+  (void)gs_raise_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_tn_x6<WN, WK, TIN, TIK, AProv, Y_CLASS>), lds_bytes,
+                             lds_raised);
   const dim3 grid((unsigned)gs_ceil_div(k, TK_), (unsigned)gs_ceil_div(n_out, TN_), (unsigned)chunks);
   hipLaunchKernelGGL((k_gemm_tn_x6<WN, WK, TIN, TIK, AProv, Y_CLASS>), grid, dim3(64 * WN * WK), lds_bytes, st, dy, ldy, ap,
                      m, n_out, k, slabs, rows_per_z, direct);
@@ -1154,11 +1150,9 @@ int launch_wgrad_post_folded(const float *du, const float *x, const float *agg, 
                       TIK = decltype(tik_)::value;
         constexpr int TN_ = 32 * TIN * WN, TK_ = 32 * TIK * WK;
         constexpr size_t lds_bytes = 2 * 3 * (size_t)(TN_ + TK_) * kX6RowBytes;
-        static const bool attr = [] {
-          return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_tn_postfold_x6<WN, WK, TIN, TIK>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
-        }();
-        (void)attr;
+        static std::atomic<unsigned long long> lds_raised{0};
+        (void)gs_raise_dynamic_lds(reinterpret_cast<const void *>(&k_gemm_tn_postfold_x6<WN, WK, TIN, TIK>), lds_bytes,
+                                   lds_raised);
         const dim3 grid((unsigned)(5 * hidden / TK_), (unsigned)(2 * (hidden / 2 / TN_)), (unsigned)zcap);
         hipLaunchKernelGGL((k_gemm_tn_postfold_x6<WN, WK, TIN, TIK>), grid, dim3(64 * WN * WK), lds_bytes, st, a, sl);
       };

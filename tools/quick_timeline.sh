@@ -16,6 +16,7 @@ print("train", d["train_step"])
 if "c3" in d:
     c = d["c3"]
     print("C3 ms/step", round(c["ms_per_step"], 3), "graphs/s", round(c["graphs_per_s"]), "K4 frac", round(c["roofline"]["frac"], 3))
+    print("C3 train", c.get("train_step"))
     print("C3 gemm", {k: (round(v["avg_ms"] * 1e3, 1), round(v["executed_tflops"], 1)) for k, v in c["roofline_gemm"]["per_kernel"].items()}, "frac", round(c["roofline_gemm"]["frac"], 3))
 print("flags", d.get("input_error_flags"))
 PY
