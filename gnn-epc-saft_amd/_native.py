@@ -36,7 +36,7 @@ class ModelDesc(ctypes.Structure):
         ("bn_eps", c_float), ("bn_momentum", c_float), ("fold_degree_scalers", c_int32),
         ("fold_dst_term", c_int32), ("save_tape", c_int32), ("unfused_readout", c_int32), ("bn_eps_f64", ctypes.c_double),
         ("debug_barrier_extra", c_int32), ("readout_dropout", c_float), ("dropout_seed", ctypes.c_uint64),
-        ("unfused_bn_apply", c_int32), ("reserved0", c_int32),
+        ("unfused_bn_apply", c_int32), ("persistent_sync_words", c_int32),
     ]
 
 

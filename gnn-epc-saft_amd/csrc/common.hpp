@@ -305,6 +305,27 @@ __device__ __forceinline__ void block_degree_hist(int d, bool live, int32_t *__r
   }
 }
 
+// The K0 chain run by cooperating workgroups of the prologue launch (elementwise.hip: k0_chain_body)
+constexpr int kK0MaxWgs = 128;        // co-resident by construction: the first workgroups of the launch
+constexpr int kK0SyncInts = 5;        // four barriers + the exit count (<= GNNSAFT_K0_SYNC_WORDS)
+struct BondDims {                     // vocabulary sizes of the bond attribute columns (edge class = mixed radix)
+  int32_t n;
+  int32_t dims[GNNSAFT_MAX_TABLES];
+};
+struct K0ChainArgs {
+  int wgs = 0;                        // 0 = off
+  int self_loops = 0, tile_rows = 0, barrier_extra = 0;
+  BondDims bd;
+  const int64_t *edge_index = nullptr, *edge_attr = nullptr, *batch = nullptr;
+  int64_t n = 0, e = 0, g = 0;
+  int32_t *graph_ptr = nullptr, *cursor = nullptr, *slots = nullptr, *rowptr = nullptr, *tile_sums = nullptr;
+  int32_t *src = nullptr, *dst = nullptr, *combo = nullptr;
+  float *log_amp = nullptr, *log_att = nullptr;
+  int32_t *block_hist = nullptr, *hist = nullptr, *start = nullptr, *tiles = nullptr, *num_tiles = nullptr;
+  int32_t *sync = nullptr;            // kK0SyncInts ints, zero at entry, zero again at exit
+  int32_t *err = nullptr;
+};
+
 // internal fused launchers used by gnnsaft_forward (the C entry points keep the one-job-per-call form)
 int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_atom_cols,
                             const float *const *atom_tables_host, const int32_t *atom_dims_host,
@@ -315,7 +336,7 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
                             const float *const *w_pre0_host, const float *const *w_pre1_host, double *g_all,
                             int32_t *err_flag, hipStream_t st, int32_t *zero2_ptr = nullptr, int zero2_count = 0,
                             const struct EdgeTableLayers *tables = nullptr /* fold.hpp */, int32_t table_layers = 0,
-                            float *cenc = nullptr, float *rtab = nullptr);
+                            float *cenc = nullptr, float *rtab = nullptr, const K0ChainArgs *k0 = nullptr);
 int launch_add_pool_bn(const float *y, const float *xprev, const float *scale, const float *shift, float *xout,
                        const int32_t *graph_ptr, int64_t num_graphs, int64_t num_nodes, int hidden, float *out,
                        hipStream_t st);
@@ -335,9 +356,17 @@ struct DegreeFoldRequest {
   float *w_eff;
   int64_t layer_stride;
 };
+// the arrays the cooperative K0 chain wrote (for the empty structure installed after a lost barrier: degree.hip)
+struct K0Installed {
+  int32_t *rowptr, *src, *dst, *combo;
+  int64_t ep;
+  float *log_amp, *log_att;
+};
 int launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm, int32_t *tiles,
                         int32_t *num_tiles, int32_t *scratch, int32_t *err_flag, bool have_block_hist, hipStream_t st,
-                        const DegreeFoldRequest *fold = nullptr);
+                        const DegreeFoldRequest *fold = nullptr, const K0Installed *installed = nullptr);
+// where launch_csr_build keeps the fill cursors, the scan's tile sums and the slot rows inside its workspace
+void csr_workspace_parts(void *workspace, int64_t num_nodes, int32_t **cursor, int32_t **tile_sums, int32_t **slots);
 int launch_fold_post_weights(int32_t num_layers, const float *const *w_post0_host, const float *const *w_post1_host,
                              const float *const *avg_deg_log_host, const float *const *w_pre0_host,
                              const float *const *w_pre1_host, double *g_scratch, const int32_t *hist, int32_t hidden,

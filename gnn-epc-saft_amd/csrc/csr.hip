@@ -11,12 +11,9 @@
 // 1..5) so that the row order, hence every floating-point sum downstream, is
 // independent of atomic arrival order.
 #include "common.hpp"
+#include "k0_chain.hpp"
 
 namespace gs {
-
-constexpr int kScanBlock = 256;
-constexpr int kScanItems = 8;
-constexpr int kScanTile = kScanBlock * kScanItems;  // 2048 counts per workgroup
 
 __global__ void k_zero_i32(int32_t *p, int64_t n, int32_t *also = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -24,8 +21,6 @@ __global__ void k_zero_i32(int32_t *p, int64_t n, int32_t *also = nullptr) {
   if (i == 0 && also != nullptr) also[0] = 0;
 }
 
-__device__ __forceinline__ void batch_to_ptr_slot(const int64_t *__restrict__ batch, int64_t n, int64_t g,
-                                                  int32_t *__restrict__ ptr, int32_t *err, int64_t i);
 
 // in-degree histogram; the same launch optionally converts the PyG `batch` vector to graph offsets (an
 // independent job with the same parallel shape: one thread per node)
@@ -52,54 +47,12 @@ __global__ void k_count_in_degree(const int64_t *__restrict__ edge_index, int64_
   atomicAdd(&counts[d], 1);
 }
 
-// block-level exclusive scan of (counts[i] + extra), tile sums to `tile_sums`
-__device__ __forceinline__ int block_exclusive_scan(int v, int *lds, int &total) {
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(inc, o);
-    if (lane >= o) inc += t;
-  }
-  if (lane == 63) lds[wave] = inc;
-  __syncthreads();
-  int wave_off = 0;
-  int tot = 0;
-#pragma unroll
-  for (int w = 0; w < kScanBlock / 64; ++w) {
-    const int t = lds[w];
-    if (w < wave) wave_off += t;
-    tot += t;
-  }
-  __syncthreads();
-  total = tot;
-  return wave_off + inc - v;
-}
-
 __global__ __launch_bounds__(kScanBlock) void k_scan_tiles(const int32_t *__restrict__ counts, int64_t n, int extra,
                                                            int32_t *__restrict__ rowptr,
                                                            int32_t *__restrict__ tile_sums,
                                                            int clamp = 0x7fffffff) {
   __shared__ int lds[kScanBlock / 64];
-  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-  int v[kScanItems];
-  int local = 0;
-#pragma unroll
-  for (int j = 0; j < kScanItems; ++j) {
-    const int64_t i = base + j;
-    v[j] = i < n ? (counts[i] < clamp ? counts[i] : clamp) + extra : 0;
-    local += v[j];
-  }
-  int total;
-  int off = block_exclusive_scan(local, lds, total);
-#pragma unroll
-  for (int j = 0; j < kScanItems; ++j) {
-    const int64_t i = base + j;
-    if (i < n) rowptr[i] = off;  // tile-local; tile offset added by k_scan_add
-    off += v[j];
-  }
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+  scan_tile_body(counts, n, extra, rowptr, tile_sums, clamp, blockIdx.x, lds);
 }
 
 // single workgroup: exclusive scan of the tile sums, in place; writes the grand total to rowptr[n]
@@ -184,11 +137,6 @@ __global__ void k_fill_edge_ids(const int64_t *__restrict__ edge_index, int64_t 
   eid[pos] = (int32_t)i;
 }
 
-struct BondDims {
-  int32_t n;
-  int32_t dims[GNNSAFT_MAX_TABLES];
-};
-
 // one thread per node: order the segment, emit src / dst / combo rows and the degree scaler logs
 __device__ __forceinline__ int finish_row(const int64_t *__restrict__ edge_index,
                                           const int64_t *__restrict__ edge_attr, int64_t i, const BondDims &bd,
@@ -256,9 +204,8 @@ __global__ void k_finish_rows(const int64_t *__restrict__ edge_index, const int6
 // the degree bucketing flags): the edge ids go to a fixed row of kCsrSlots slots per destination node in ONE pass
 // over the edge list -- no histogram pass before the fill -- and the row offsets are completed by the kernel that
 // orders and emits the rows.  prologue (zero) -> k_fill_slots -> k_scan_tiles -> k_finish_rows_slots: two launches
-// fewer than the general chain, and the per-node sort runs in registers instead of through memory.
-constexpr int kCsrSlots = kDegreeBuckets;
-
+// fewer than the general chain, and the per-node sort runs in registers instead of through memory.  (Bodies in
+// k0_chain.hpp: the forward runs the same chain as workgroups of its prologue launch where it can.)
 __global__ void k_fill_slots(const int64_t *__restrict__ edge_index, int64_t n, int64_t e,
                              int32_t *__restrict__ cursor, int32_t *__restrict__ slots, int32_t *err,
                              const int64_t *__restrict__ batch, int64_t g, int32_t *__restrict__ graph_ptr) {
@@ -271,30 +218,11 @@ __global__ void k_fill_slots(const int64_t *__restrict__ edge_index, int64_t n, 
       graph_ptr[1] = (int32_t)n;
     }
   }
-  if (i >= e) return;
-  const int64_t s = edge_index[i];
-  const int64_t d = edge_index[e + i];
-  if (s < 0 || s >= n || d < 0 || d >= n) {
-    if (err) atomicOr(err, GNNSAFT_FLAG_BAD_EDGE);
-    return;  // dropped
-  }
-  const int pos = atomicAdd(&cursor[d], 1);
-  if (pos < kCsrSlots) {
-    slots[d * kCsrSlots + pos] = (int32_t)i;
-  } else if (err) {
-    atomicOr(err, GNNSAFT_FLAG_BAD_DEGREE);  // (the edge is dropped; the row keeps kCsrSlots edges)
-  }
+  fill_slot_body(edge_index, n, e, cursor, slots, err, i);
 }
 
-__device__ __forceinline__ void sort_exchange(int &a, int &b) {
-  const int lo = a < b ? a : b, hi = a < b ? b : a;
-  a = lo;
-  b = hi;
-}
-
-// one thread per node: final row offset (tile-local scan value + the totals of the tiles in front), the node's edge
-// ids in ascending order (8 or fewer: a sorting network in registers), src / dst / combo rows, degree scaler logs,
-// first pass of the degree bucketing.  blockDim.x divides kScanTile.
+// blockDim.x divides kScanTile; block_hist != nullptr: launched with kDegBlock threads (first pass of the degree
+// bucketing for free)
 __global__ void k_finish_rows_slots(const int64_t *__restrict__ edge_index, const int64_t *__restrict__ edge_attr,
                                     int64_t n, int64_t e, BondDims bd, int self_loops,
                                     int32_t *__restrict__ rowptr, const int32_t *__restrict__ tile_sums,
@@ -304,135 +232,11 @@ __global__ void k_finish_rows_slots(const int64_t *__restrict__ edge_index, cons
                                     float *__restrict__ log_amp, float *__restrict__ log_att, int32_t *err,
                                     int32_t *__restrict__ block_hist) {
   __shared__ int s_before[16], s_all[16];
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
-  // loads that do not depend on the row offset first
-  int cnt = live ? cursor[i] : 0;
-  cnt = cnt < kCsrSlots ? cnt : kCsrSlots;
-  int32_t *row = slots + (live ? i : 0) * kCsrSlots;
-  int key[8];
-  if (cnt <= 8) {
-    const int4 lo = cnt > 0 ? *reinterpret_cast<const int4 *>(row) : int4{0, 0, 0, 0};
-    const int4 hi = cnt > 4 ? *reinterpret_cast<const int4 *>(row + 4) : int4{0, 0, 0, 0};
-    const int raw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-    for (int a = 0; a < 8; ++a) key[a] = a < cnt ? raw[a] : 0x7fffffff;
-  }
-  // tile totals in front of this workgroup's tile (the last workgroup also sums all of them: rowptr[n])
-  const int64_t tile = ((int64_t)blockIdx.x * blockDim.x) / kScanTile;
-  const bool last = blockIdx.x == gridDim.x - 1;
-  const int64_t upto = last ? num_tiles : tile;
-  int before = 0, all = 0;
-  for (int64_t t = threadIdx.x; t < upto; t += blockDim.x) {
-    const int v = tile_sums[t];
-    all += v;
-    if (t < tile) before += v;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    before += __shfl_xor(before, o);
-    all += __shfl_xor(all, o);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    s_before[threadIdx.x >> 6] = before;
-    s_all[threadIdx.x >> 6] = all;
-  }
-  __syncthreads();
-  before = 0;
-  all = 0;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
-    before += s_before[w];
-    all += s_all[w];
-  }
-  if (last && threadIdx.x == 0) rowptr[n] = all;
-  int deg = 0;
-  if (live) {
-    const int beg = rowptr[i] + before;
-    rowptr[i] = beg;
-    if (cnt <= 8) {
-      // Batcher odd-even merge sort, 8 keys, 19 exchanges
-      sort_exchange(key[0], key[1]); sort_exchange(key[2], key[3]); sort_exchange(key[4], key[5]); sort_exchange(key[6], key[7]);
-      sort_exchange(key[0], key[2]); sort_exchange(key[1], key[3]); sort_exchange(key[4], key[6]); sort_exchange(key[5], key[7]);
-      sort_exchange(key[1], key[2]); sort_exchange(key[5], key[6]);
-      sort_exchange(key[0], key[4]); sort_exchange(key[1], key[5]); sort_exchange(key[2], key[6]); sort_exchange(key[3], key[7]);
-      sort_exchange(key[2], key[4]); sort_exchange(key[3], key[5]);
-      sort_exchange(key[1], key[2]); sort_exchange(key[3], key[4]); sort_exchange(key[5], key[6]);
-      int64_t sv[8];
-      int cid[8];
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {   // every row's loads are independent: all in flight together
-        const int64_t id = a < cnt ? key[a] : 0;
-        sv[a] = a < cnt ? edge_index[id] : 0;
-        int c = 0;
-        for (int k = 0; k < bd.n; ++k) {
-          int64_t v = a < cnt ? edge_attr[id * bd.n + k] : 0;
-          if (v < 0 || v >= bd.dims[k]) {
-            if (err) atomicOr(err, GNNSAFT_FLAG_BAD_ATTR);
-            v = 0;
-          }
-          c = c * bd.dims[k] + (int)v;
-        }
-        cid[a] = c;
-      }
-#pragma unroll
-      for (int a = 0; a < 8; ++a)
-        if (a < cnt) {
-          src[beg + a] = (int32_t)sv[a];
-          dst[beg + a] = (int32_t)i;
-          combo[beg + a] = cid[a];
-        }
-    } else {
-      for (int a = 1; a < cnt; ++a) {   // insertion sort in the slot row, ascending edge id
-        const int k2 = row[a];
-        int b = a - 1;
-        while (b >= 0 && row[b] > k2) {
-          row[b + 1] = row[b];
-          --b;
-        }
-        row[b + 1] = k2;
-      }
-      for (int a = 0; a < cnt; ++a) {
-        const int64_t id = row[a];
-        int c = 0;
-        for (int k = 0; k < bd.n; ++k) {
-          int64_t v = edge_attr[id * bd.n + k];
-          if (v < 0 || v >= bd.dims[k]) {
-            if (err) atomicOr(err, GNNSAFT_FLAG_BAD_ATTR);
-            v = 0;
-          }
-          c = c * bd.dims[k] + (int)v;
-        }
-        src[beg + a] = (int32_t)edge_index[id];
-        dst[beg + a] = (int32_t)i;
-        combo[beg + a] = c;
-      }
-    }
-    deg = cnt;
-    if (self_loops) {
-      src[beg + cnt] = (int32_t)i;
-      dst[beg + cnt] = (int32_t)i;
-      combo[beg + cnt] = 0;
-      deg += 1;
-    }
-    log_amp[i] = degree_log_amp(deg);
-    log_att[i] = degree_log_att(deg);
-  }
+  const int deg = finish_rows_slots_body(edge_index, edge_attr, n, bd, self_loops, rowptr, tile_sums, num_tiles, cursor,
+                                         slots, src, dst, combo, log_amp, log_att, err, blockIdx.x, (int)blockDim.x,
+                                         blockIdx.x == gridDim.x - 1, s_before, s_all);
+  const bool live = (int64_t)blockIdx.x * blockDim.x + threadIdx.x < n;
   if (block_hist != nullptr) block_degree_hist(live ? clamp_degree(deg, err) : 0, live, block_hist);
-}
-
-__device__ __forceinline__ void batch_to_ptr_slot(const int64_t *__restrict__ batch, int64_t n, int64_t g,
-                                                  int32_t *__restrict__ ptr, int32_t *err, int64_t i) {
-  if (i > n) return;
-  // thread i in [0,n) closes the gap between batch[i-1] and batch[i]; thread n closes the tail
-  int64_t prev = i == 0 ? -1 : batch[i - 1];
-  int64_t cur = i == n ? g : batch[i];
-  if (i < n && (cur < 0 || cur >= g || cur < prev)) {
-    if (err) atomicOr(err, GNNSAFT_FLAG_BAD_BATCH);
-    return;
-  }
-  if (prev < -1) prev = -1;
-  if (prev >= g) return;
-  for (int64_t q = prev + 1; q <= cur && q <= g; ++q) ptr[q] = (int32_t)i;
 }
 
 __global__ void k_batch_to_ptr(const int64_t *__restrict__ batch, int64_t n, int64_t g, int32_t *__restrict__ ptr,
@@ -544,6 +348,17 @@ extern "C" size_t gnnsaft_csr_workspace_bytes(int64_t num_nodes, int64_t num_edg
 void gs::csr_zero_region(void *workspace, int64_t num_nodes, int32_t **ptr, int64_t *count) {
   *ptr = static_cast<int32_t *>(workspace);
   *count = 2 * (int64_t)gs_align_up((size_t)num_nodes * 4, 256) / 4;
+}
+
+void gs::csr_workspace_parts(void *workspace, int64_t num_nodes, int32_t **cursor, int32_t **tile_sums,
+                             int32_t **slots) {
+  const int64_t tiles = gs_ceil_div(num_nodes > 0 ? num_nodes : 1, gs::kScanTile);
+  char *ws = static_cast<char *>(workspace) + gs_align_up((size_t)num_nodes * 4, 256);   // (counts first)
+  *cursor = reinterpret_cast<int32_t *>(ws);
+  ws += gs_align_up((size_t)num_nodes * 4, 256);
+  *tile_sums = reinterpret_cast<int32_t *>(ws);
+  ws += gs_align_up((size_t)tiles * 4, 256);
+  *slots = reinterpret_cast<int32_t *>(ws);
 }
 
 int gs::launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_t num_nodes, int64_t num_edges,

@@ -12,6 +12,7 @@
 // (GNNSAFT_FLAG_BAD_DEGREE) and clamped; callers with such graphs disable folding.
 #include "common.hpp"
 #include "fold.hpp"
+#include "k0_chain.hpp"
 
 namespace gs {
 
@@ -24,74 +25,13 @@ __global__ __launch_bounds__(kDegBlock) void k_degree_block_hist(const int32_t *
   block_degree_hist(d, live, block_hist);
 }
 
-// pass 2 (one workgroup): per-bucket exclusive scan over blocks (in place), bucket starts, tile table.
-// 8 lanes x 32 buckets: every lane scans a contiguous run of blocks, the lane totals are chained through LDS.
+// pass 2 (one workgroup): per-bucket exclusive scan over blocks (in place), bucket starts, tile table (k0_chain.hpp)
 __global__ __launch_bounds__(256) void k_degree_plan(int32_t *__restrict__ block_hist, int64_t num_blocks,
                                                      int tile_rows, int32_t *__restrict__ hist,
                                                      int32_t *__restrict__ start, int32_t *__restrict__ tiles,
                                                      int32_t *__restrict__ num_tiles) {
-  constexpr int kLanes = 256 / kDegreeBuckets;
-  __shared__ int32_t s_lane[kLanes][kDegreeBuckets];
-  __shared__ int32_t s_cnt[kDegreeBuckets], s_start[kDegreeBuckets], s_tile0[kDegreeBuckets + 1];
-  const int bucket = threadIdx.x % kDegreeBuckets, lane = threadIdx.x / kDegreeBuckets;
-  const int64_t per_lane = (num_blocks + kLanes - 1) / kLanes;
-  const int64_t b_beg = lane * per_lane;
-  int64_t b_end = b_beg + per_lane;
-  if (b_end > num_blocks) b_end = num_blocks;
-  int sum = 0;
-  for (int64_t b0 = b_beg; b0 < b_end; b0 += 8) {
-    int c[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) c[u] = b0 + u < b_end ? block_hist[(b0 + u) * kDegreeBuckets + bucket] : 0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) sum += c[u];
-  }
-  s_lane[lane][bucket] = sum;
-  __syncthreads();
-  int run = 0, total = 0;
-  for (int l = 0; l < kLanes; ++l) {
-    const int v = s_lane[l][bucket];
-    if (l < lane) run += v;
-    total += v;
-  }
-  for (int64_t b0 = b_beg; b0 < b_end; b0 += 8) {
-    int c[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) c[u] = b0 + u < b_end ? block_hist[(b0 + u) * kDegreeBuckets + bucket] : 0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (b0 + u < b_end) block_hist[(b0 + u) * kDegreeBuckets + bucket] = run;
-      run += c[u];
-    }
-  }
-  if (lane == 0) {
-    s_cnt[bucket] = total;
-    hist[bucket] = total;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int slot = 0, nt = 0;
-    for (int d = 0; d < kDegreeBuckets; ++d) {
-      s_start[d] = slot;
-      s_tile0[d] = nt;
-      slot += s_cnt[d];
-      nt += (s_cnt[d] + tile_rows - 1) / tile_rows;
-    }
-    s_tile0[kDegreeBuckets] = nt;
-    num_tiles[0] = nt;
-  }
-  __syncthreads();
-  if (threadIdx.x < kDegreeBuckets) start[threadIdx.x] = s_start[threadIdx.x];
-  const int nt = s_tile0[kDegreeBuckets];
-  for (int t = threadIdx.x; t < nt; t += blockDim.x) {
-    int d = 0;
-    while (t >= s_tile0[d + 1]) ++d;
-    const int o = (t - s_tile0[d]) * tile_rows;
-    tiles[4 * t + 0] = d;
-    tiles[4 * t + 1] = s_start[d] + o;
-    tiles[4 * t + 2] = s_cnt[d] - o < tile_rows ? s_cnt[d] - o : tile_rows;
-    tiles[4 * t + 3] = 0;
-  }
+  __shared__ DegreePlanLds s;
+  degree_plan_body(block_hist, num_blocks, tile_rows, hist, start, tiles, num_tiles, s);
 }
 
 // pass 3: perm[start[d] + (nodes of degree d in earlier blocks / waves / lanes)] = node
@@ -128,10 +68,11 @@ __global__ __launch_bounds__(256) void k_dst_fold(FoldLayers fl, int f, double *
 // slot: float4 index inside one [F/2, 5F] block; t: tower; dz: degree + kDegreeBuckets * layer
 __device__ __forceinline__ void fold_post_weights_body(const FoldLayers &fl, const int32_t *__restrict__ hist, int f,
                                                        float *__restrict__ w_eff_all, int64_t layer_stride,
-                                                       const double *__restrict__ g_all, int64_t slot, int t, int dz) {
+                                                       const double *__restrict__ g_all, int64_t slot, int t, int dz,
+                                                       bool only_degree0 = false) {
   const int d = dz % kDegreeBuckets;
   const int layer = dz / kDegreeBuckets;
-  if (hist[d] == 0) return;  // degree absent from this batch
+  if (only_degree0 ? d != 0 : hist[d] == 0) return;  // degree absent from this batch
   const float *w0 = fl.w0[layer], *w1 = fl.w1[layer], *avg = fl.avg[layer];
   float *w_eff = w_eff_all + layer * layer_stride;
   const int per_row4 = 5 * f / 4;
@@ -181,19 +122,65 @@ struct FoldJob {
   int num_layers;
 };
 
+// What the fill launch installs when the cooperative K0 chain of the prologue launch lost a grid barrier (the flag
+// word says so): an EMPTY structure -- no rows, every node of in-degree 0, identity permutation -- so that nothing
+// downstream indexes with half-built tables.  The outputs are garbage by then and say so (flag; the readout poisons).
+struct K0Sanitize {
+  const int32_t *err = nullptr;   // null: never
+  int32_t *rowptr = nullptr, *src = nullptr, *dst = nullptr, *combo = nullptr;
+  int64_t ep = 0;
+  float *log_amp = nullptr, *log_att = nullptr;
+  int32_t *hist = nullptr, *start = nullptr, *tiles = nullptr, *num_tiles = nullptr;
+  int tile_rows = 64;
+};
+
+__device__ __forceinline__ void k0_install_empty(const K0Sanitize &z, int64_t n, int32_t *__restrict__ perm,
+                                                 unsigned fill_blocks) {
+  const int64_t i = (int64_t)blockIdx.x * kDegBlock + threadIdx.x;
+  if (i < n) {
+    z.rowptr[i] = 0;
+    perm[i] = (int32_t)i;
+    z.log_amp[i] = degree_log_amp(0);
+    z.log_att[i] = degree_log_att(0);
+  }
+  for (int64_t r = i; r < z.ep; r += (int64_t)fill_blocks * kDegBlock) z.src[r] = z.dst[r] = z.combo[r] = 0;
+  if (blockIdx.x != 0) return;
+  if (threadIdx.x == 0) {
+    z.rowptr[n] = 0;
+    z.num_tiles[0] = (int32_t)((n + z.tile_rows - 1) / z.tile_rows);
+  }
+  if (threadIdx.x < kDegreeBuckets) {
+    z.hist[threadIdx.x] = threadIdx.x == 0 ? (int32_t)n : 0;
+    z.start[threadIdx.x] = threadIdx.x == 0 ? 0 : (int32_t)n;
+  }
+  const int64_t nt = (n + z.tile_rows - 1) / z.tile_rows;
+  for (int64_t t = threadIdx.x; t < nt; t += kDegBlock) {
+    const int64_t o = t * z.tile_rows;
+    z.tiles[4 * t + 0] = 0;
+    z.tiles[4 * t + 1] = (int32_t)o;
+    z.tiles[4 * t + 2] = (int32_t)(n - o < z.tile_rows ? n - o : z.tile_rows);
+    z.tiles[4 * t + 3] = 0;
+  }
+}
+
 __global__ __launch_bounds__(kDegBlock) void k_degree_fill_and_fold(const int32_t *__restrict__ rowptr, int64_t n,
                                                                     const int32_t *__restrict__ block_base,
                                                                     const int32_t *__restrict__ start,
                                                                     int32_t *__restrict__ perm, unsigned fill_blocks,
-                                                                    FoldJob job) {
+                                                                    FoldJob job, K0Sanitize z) {
+  const bool lost = z.err != nullptr && (__hip_atomic_load(z.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
+                                         GNNSAFT_FLAG_BARRIER_TIMEOUT) != 0;   // grid-uniform
   if (blockIdx.x < fill_blocks) {  // block-uniform
-    degree_fill_body(rowptr, n, block_base, start, perm);
+    if (lost)
+      k0_install_empty(z, n, perm, fill_blocks);
+    else
+      degree_fill_body(rowptr, n, block_base, start, perm);
     return;
   }
   const unsigned b = blockIdx.x - fill_blocks;
   const int xb = b % job.x_blocks, rest = b / job.x_blocks;
   fold_post_weights_body(job.fl, job.hist, job.f, job.w_eff_all, job.layer_stride, job.g_all,
-                         (int64_t)xb * kDegBlock + threadIdx.x, rest & 1, rest >> 1);
+                         (int64_t)xb * kDegBlock + threadIdx.x, rest & 1, rest >> 1, lost);
 }
 
 }  // namespace gs
@@ -212,16 +199,20 @@ extern "C" size_t gnnsaft_degree_scratch_ints(int64_t num_nodes) {
 
 int gs::launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm, int32_t *tiles,
                             int32_t *num_tiles, int32_t *scratch, int32_t *err_flag, bool have_block_hist,
-                            hipStream_t st, const DegreeFoldRequest *fold) {
+                            hipStream_t st, const DegreeFoldRequest *fold, const K0Installed *installed) {
   GS_REQUIRE(rowptr && perm && tiles && num_tiles && scratch, GNNSAFT_ERR_NULL);
   GS_REQUIRE(num_nodes >= 1 && hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
   int32_t *hist = scratch, *start = scratch + gs::kDegreeBuckets, *block_hist = scratch + 2 * gs::kDegreeBuckets;
   const int64_t nb = gs_ceil_div(num_nodes, gs::kDegBlock);
-  if (!have_block_hist)  // otherwise launch_csr_build's last kernel already left it there
-    hipLaunchKernelGGL(gs::k_degree_block_hist, dim3((unsigned)nb), dim3(gs::kDegBlock), 0, st, rowptr, num_nodes,
-                       block_hist, err_flag);
-  hipLaunchKernelGGL(gs::k_degree_plan, dim3(1), dim3(256), 0, st, block_hist, nb, gs::pna_fold_tile_rows(hidden),
-                     hist, start, tiles, num_tiles);
+  // `installed`: the cooperative chain of the prologue launch already left the histogram, the plan and the tile table
+  GS_REQUIRE(installed == nullptr || fold != nullptr, GNNSAFT_ERR_SHAPE);
+  if (installed == nullptr) {
+    if (!have_block_hist)  // otherwise launch_csr_build's last kernel already left it there
+      hipLaunchKernelGGL(gs::k_degree_block_hist, dim3((unsigned)nb), dim3(gs::kDegBlock), 0, st, rowptr, num_nodes,
+                         block_hist, err_flag);
+    hipLaunchKernelGGL(gs::k_degree_plan, dim3(1), dim3(256), 0, st, block_hist, nb, gs::pna_fold_tile_rows(hidden),
+                       hist, start, tiles, num_tiles);
+  }
   if (fold == nullptr) {
     hipLaunchKernelGGL(gs::k_degree_fill, dim3((unsigned)nb), dim3(gs::kDegBlock), 0, st, rowptr, num_nodes,
                        block_hist, start, perm);
@@ -248,8 +239,24 @@ int gs::launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hi
     job.x_blocks = (int)gs_ceil_div(threads, (int64_t)gs::kDegBlock);
     job.num_layers = fold->num_layers;
     const int64_t fold_blocks = (int64_t)job.x_blocks * 2 * gs::kDegreeBuckets * fold->num_layers;
+    gs::K0Sanitize z;
+    if (installed != nullptr) {
+      z.err = err_flag;
+      z.rowptr = installed->rowptr;
+      z.src = installed->src;
+      z.dst = installed->dst;
+      z.combo = installed->combo;
+      z.ep = installed->ep;
+      z.log_amp = installed->log_amp;
+      z.log_att = installed->log_att;
+      z.hist = hist;
+      z.start = start;
+      z.tiles = tiles;
+      z.num_tiles = num_tiles;
+      z.tile_rows = gs::pna_fold_tile_rows(hidden);
+    }
     hipLaunchKernelGGL(gs::k_degree_fill_and_fold, dim3((unsigned)(nb + fold_blocks)), dim3(gs::kDegBlock), 0, st, rowptr,
-                       num_nodes, block_hist, start, perm, (unsigned)nb, job);
+                       num_nodes, block_hist, start, perm, (unsigned)nb, job, z);
   }
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;

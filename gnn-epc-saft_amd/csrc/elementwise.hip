@@ -4,6 +4,7 @@
 // (models.py:133) and the MAPE loss (models.py:194).  All float4 per lane.
 #include "common.hpp"
 #include "fold.hpp"
+#include "k0_chain.hpp"
 
 namespace gs {
 
@@ -106,6 +107,8 @@ struct PrologueArgs {
   float *cenc, *rtab;              // [L][C][H], [L][C][2H]
   unsigned tab_blocks;             // tab_layers * combos workgroups at the very front of the grid
   int tab_layers;
+  // the batch structure (K0 chain) by the FIRST k0.wgs workgroups of the grid, grid barriers among them (0 = off)
+  K0ChainArgs k0;
 };
 
 // Edge-class tables of one (layer, class): cenc[c] = W_e emb_c + b_e, rtab[c, tF + f] = W_pre,t[f, 2F:3F] cenc[c] + b_pre,t[f]
@@ -166,23 +169,118 @@ __device__ __forceinline__ void edge_table_body(const PrologueArgs &a, unsigned 
   }
 }
 
+// ---- the K0 chain as `wgs` cooperating workgroups at the FRONT of the prologue grid (dispatched first, hence
+// resident together from the start; the embedding / table / fold workgroups behind them do not depend on them, so the
+// chain's four grid barriers cost the launch nothing while that work lasts):
+//   zero cursors + block histogram, graph offsets | slotted fill | tile scans | finish rows + block histogram | plan
+// The barrier counters live in caller memory that is zero between calls (gnnsaft_model_desc.persistent_sync_words):
+// the last workgroup out zeroes them again.  A barrier that times out raises GNNSAFT_FLAG_BARRIER_TIMEOUT; the
+// degree-fill launch that follows then installs an empty structure (degree.hip), and the readout poisons the outputs.
+__device__ __forceinline__ bool k0_barrier(int32_t *counter, int expected, int32_t *err) {
+  __shared__ int s_k0_ok;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    long spins = 0;
+    int ok = 1;
+    // poll relaxed (an acquire load invalidates the caches on EVERY poll, under the embedding workgroups running
+    // beside the chain), one acquire fence when the last arrival has been seen
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1L << 22)) {
+        if (err) atomicOr(err, GNNSAFT_FLAG_BARRIER_TIMEOUT);
+        ok = 0;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_k0_ok = ok;
+  }
+  __syncthreads();
+  return s_k0_ok != 0;
+}
+
+__device__ __forceinline__ void k0_chain_body(const K0ChainArgs &k, int w) {
+  __shared__ int s_scan[kScanBlock / 64], s_before[16], s_all[16];
+  __shared__ DegreePlanLds s_plan;
+  const int W = k.wgs, tid = threadIdx.x;
+  const int64_t n = k.n, e = k.e;
+  const int64_t stride = (int64_t)W * 256, gtid = (int64_t)w * 256 + tid;
+  const int64_t nb = (n + kDegBlock - 1) / kDegBlock;
+  const int expected = W + k.barrier_extra;
+  // phase 0: nothing here reads what another workgroup writes
+  for (int64_t i = gtid; i < n; i += stride) k.cursor[i] = 0;
+  for (int64_t i = gtid; i < nb * kDegreeBuckets; i += stride) k.block_hist[i] = 0;
+  if (k.graph_ptr != nullptr) {
+    if (k.batch != nullptr) {
+      for (int64_t i = gtid; i <= n; i += stride) batch_to_ptr_slot(k.batch, n, k.g, k.graph_ptr, k.err, i);
+    } else if (gtid == 0) {  // un-batched Data: one graph spanning all nodes
+      k.graph_ptr[0] = 0;
+      k.graph_ptr[1] = (int32_t)n;
+    }
+  }
+  k0_barrier(k.sync + 0, expected, k.err);
+  // phase 1: edge ids into the slot rows of their destinations
+  for (int64_t i = gtid; i < e; i += stride) fill_slot_body(k.edge_index, n, e, k.cursor, k.slots, k.err, i);
+  k0_barrier(k.sync + 1, expected, k.err);
+  // phase 2: tile-local scans of the (clamped) in-degrees
+  const int64_t scan_tiles = ((n > 0 ? n : 1) + kScanTile - 1) / kScanTile;
+  for (int64_t t = w; t < scan_tiles; t += W)
+    scan_tile_body(k.cursor, n, k.self_loops, k.rowptr, k.tile_sums, kCsrSlots, t, s_scan);
+  k0_barrier(k.sync + 2, expected, k.err);
+  // phase 3: rows of 256 nodes at a time; their degrees into the histogram of their 1024-node block
+  const int64_t groups = (n + 255) / 256;
+  for (int64_t gi = w; gi < groups; gi += W) {
+    const int deg = finish_rows_slots_body(k.edge_index, k.edge_attr, n, k.bd, k.self_loops, k.rowptr, k.tile_sums,
+                                           scan_tiles, k.cursor, k.slots, k.src, k.dst, k.combo, k.log_amp, k.log_att,
+                                           k.err, gi, 256, gi == groups - 1, s_before, s_all);
+    const bool live = gi * 256 + tid < n;
+    const int d = live ? clamp_degree(deg, k.err) : 0;
+    int32_t *bh = k.block_hist + (gi * 256 / kDegBlock) * kDegreeBuckets;
+    unsigned long long todo = __ballot(live);
+    while (todo != 0ull) {   // one integer atomic per (wave, degree): the sums do not depend on arrival order
+      const int leader = __ffsll((long long)todo) - 1;
+      const int dl = __shfl(d, leader);
+      const unsigned long long same = __ballot(live && d == dl);
+      if ((tid & 63) == leader) atomicAdd(&bh[dl], __popcll(same));
+      todo &= ~same;
+    }
+  }
+  if (groups == 0 && w == 0 && tid == 0) k.rowptr[0] = 0;
+  k0_barrier(k.sync + 3, expected, k.err);
+  // phase 4 (one workgroup): bucket starts, tile table; the permutation fill is the next launch
+  if (w == 0) degree_plan_body(k.block_hist, nb, k.tile_rows, k.hist, k.start, k.tiles, k.num_tiles, s_plan);
+  // the last workgroup out leaves the counters zero for the next call
+  __syncthreads();
+  if (tid == 0) {
+    const int before = __hip_atomic_fetch_add(k.sync + 4, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == W - 1)
+      for (int j = 0; j < 5; ++j) __hip_atomic_store(k.sync + j, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int MAXT>
 __global__ __launch_bounds__(256) void k_forward_prologue(PrologueArgs a) {
   // the destination fold goes FIRST in the grid: its workgroups are the long-latency ones (a k-loop with
   // barriers), so they should be resident from the start while the streaming jobs fill the remaining CUs
   // ... and in front of them the edge-table workgroups (two dependent rounds of L2 latency each)
-  if (blockIdx.x < a.tab_blocks) {
-    edge_table_body(a, blockIdx.x);
+  if (blockIdx.x < (unsigned)a.k0.wgs) {
+    k0_chain_body(a.k0, (int)blockIdx.x);
     return;
   }
-  if (blockIdx.x < a.tab_blocks + a.dst_blocks) {
-    const unsigned d = blockIdx.x - a.tab_blocks;
+  const unsigned bx = blockIdx.x - (unsigned)a.k0.wgs;
+  if (bx < a.tab_blocks) {
+    edge_table_body(a, bx);
+    return;
+  }
+  if (bx < a.tab_blocks + a.dst_blocks) {
+    const unsigned d = bx - a.tab_blocks;
     const int per_z = a.dst_gx * a.dst_gy;
     const int bz = d / per_z, r = d - bz * per_z;
     dst_fold_body(a.fl, a.h, a.g_all, r % a.dst_gx, r / a.dst_gx, bz);
     return;
   }
-  const unsigned b = blockIdx.x - a.tab_blocks - a.dst_blocks;
+  const unsigned b = bx - a.tab_blocks - a.dst_blocks;
   if (b < a.end_embed) {
     embed_sum_body<MAXT>((int64_t)b * 256 + threadIdx.x, a.x_idx, a.rows, a.atoms, a.h, a.x_out, a.err, a.rs);
   } else if (b < a.end_combo) {
@@ -388,7 +486,8 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
                             const float *const *w_post0_host, const float *const *w_post1_host,
                             const float *const *w_pre0_host, const float *const *w_pre1_host, double *g_all,
                             int32_t *err_flag, hipStream_t st, int32_t *zero2_ptr, int zero2_count,
-                            const EdgeTableLayers *tables, int32_t table_layers, float *cenc, float *rtab) {
+                            const EdgeTableLayers *tables, int32_t table_layers, float *cenc, float *rtab,
+                            const K0ChainArgs *k0) {
   GS_REQUIRE(x_idx && x_out && cemb && num_rows >= 1, GNNSAFT_ERR_NULL);
   GS_REQUIRE(zero2_count >= 0 && zero2_count <= 65536, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(hidden >= 4 && (hidden % 4) == 0, GNNSAFT_ERR_SHAPE);
@@ -449,8 +548,15 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
     for (int i = 0; i < GNNSAFT_MAX_FOLD_LAYERS; ++i)
       a.et.we[i] = a.et.be[i] = a.et.wpre0[i] = a.et.wpre1[i] = a.et.bpre0[i] = a.et.bpre1[i] = nullptr;
   }
-  GS_REQUIRE(be + bc + bz + bd + bt < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);
-  const dim3 grid((unsigned)(be + bc + bz + bd + bt));
+  int64_t bk = 0;
+  a.k0.wgs = 0;
+  if (k0 != nullptr && k0->wgs > 0) {
+    GS_REQUIRE(k0->wgs <= kK0MaxWgs && k0->sync != nullptr && k0->cursor != nullptr, GNNSAFT_ERR_SHAPE);
+    a.k0 = *k0;
+    bk = k0->wgs;
+  }
+  GS_REQUIRE(bk + be + bc + bz + bd + bt < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);
+  const dim3 grid((unsigned)(bk + be + bc + bz + bd + bt));
   if (num_atom_cols <= 9)
     hipLaunchKernelGGL(k_forward_prologue<9>, grid, dim3(256), 0, st, a);
   else

@@ -500,6 +500,11 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
   // The four independent first jobs (atom embedding sum, bond-class embedding table, zeroing of the CSR
   // histogram, destination-term weight fold) share ONE launch on the caller's stream; then the chains fork.
   const bool dst_in_prologue = fold_dst && d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS;
+  // K0 as cooperating workgroups of the prologue launch: needs the caller's persistent barrier words behind err_flag
+  // (gnnsaft_model_desc.persistent_sync_words), the bounded in-degree of the folded update and one stream
+  const bool k0_fused = structure_in == nullptr && aux == nullptr && d->fold_degree_scalers != 0 &&
+                        d->num_layers >= 1 && d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS && err_flag != nullptr &&
+                        d->persistent_sync_words >= GNNSAFT_K0_SYNC_WORDS;
   // the edge-class tables (cenc, rtab: weights only) as workgroups of the same launch instead of two small GEMMs
   const bool tables_in_prologue = d->num_layers >= 1 && d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS && h <= 256 &&
                                   (h % 16) == 0 && p.combos <= 4096;
@@ -514,7 +519,41 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     }
     int32_t *zero_ptr = nullptr;
     int64_t zero_count = 0;
-    if (structure_in == nullptr) csr_zero_region(ws + p.csr_ws, n, &zero_ptr, &zero_count);
+    if (structure_in == nullptr && !k0_fused) csr_zero_region(ws + p.csr_ws, n, &zero_ptr, &zero_count);
+    K0ChainArgs k0;
+    if (k0_fused) {
+      // the batch structure by cooperating workgroups at the front of this launch (elementwise.hip: k0_chain_body)
+      GS_REQUIRE(batch != nullptr || g == 1, GNNSAFT_ERR_SHAPE);
+      GS_REQUIRE(n + num_edges < ((int64_t)1 << 31) - 1, GNNSAFT_ERR_SHAPE);
+      const int64_t want = gs_ceil_div(n, (int64_t)256);
+      k0.wgs = (int)(want < kK0MaxWgs ? want : kK0MaxWgs);
+      k0.self_loops = d->self_loops ? 1 : 0;
+      k0.tile_rows = pna_fold_tile_rows(h);
+      k0.barrier_extra = d->debug_barrier_extra;
+      k0.bd.n = d->num_bond_cols;
+      for (int k = 0; k < GNNSAFT_MAX_TABLES; ++k) k0.bd.dims[k] = k < d->num_bond_cols ? d->bond_dims[k] : 1;
+      k0.edge_index = edge_index;
+      k0.edge_attr = edge_attr;
+      k0.batch = batch;
+      k0.n = n;
+      k0.e = num_edges;
+      k0.g = g;
+      k0.graph_ptr = I(p.graph_ptr);
+      csr_workspace_parts(ws + p.csr_ws, n, &k0.cursor, &k0.tile_sums, &k0.slots);
+      k0.rowptr = I(p.rowptr);
+      k0.src = I(p.src);
+      k0.dst = I(p.dst);
+      k0.combo = I(p.combo);
+      k0.log_amp = F(p.log_amp);
+      k0.log_att = F(p.log_att);
+      k0.hist = I(p.hist3);
+      k0.start = I(p.hist3) + kDegreeBuckets;
+      k0.block_hist = I(p.hist3) + 2 * kDegreeBuckets;
+      k0.tiles = I(p.tiles);
+      k0.num_tiles = I(p.num_tiles);
+      k0.sync = err_flag + 1;
+      k0.err = err_flag;
+    }
     EdgeTableLayers et;
     for (int i = 0; i < GNNSAFT_MAX_FOLD_LAYERS; ++i) {
       et.we[i] = et.be[i] = et.wpre0[i] = et.wpre1[i] = et.bpre0[i] = et.bpre1[i] = nullptr;
@@ -531,7 +570,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
                                    d->bond_dims, h, F(p.x0), F(p.cemb), zero_ptr, zero_count,
                                    dst_in_prologue ? d->num_layers : 0, w0, w1, p0, p1, D(p.gfold), err_flag, st,
                                    I(p.rd_sync), kRdSyncInts + kBnTailCounterInts, &et, tables_in_prologue ? d->num_layers : 0, F(p.cenc),
-                                   F(p.rtab)));
+                                   F(p.rtab), k0_fused ? &k0 : nullptr));
   }
   hipStream_t sa = st;
   if (aux != nullptr) {
@@ -567,11 +606,12 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
   // CSR + graph offsets (batch == NULL: un-batched Data, models.py:116, one graph spanning all nodes) + the first
   // pass of the degree bucketing, in 5 launches (the histogram was zeroed by the prologue)
   GS_REQUIRE(batch != nullptr || g == 1, GNNSAFT_ERR_SHAPE);
-  GS_TRY(launch_csr_build(edge_index, edge_attr, n, num_edges, d->num_bond_cols, d->bond_dims, d->self_loops,
-                          I(p.rowptr), I(p.src), I(p.dst), I(p.combo), F(p.log_amp), F(p.log_att), err_flag,
-                          ws + p.csr_ws, gnnsaft_csr_workspace_bytes(n, num_edges), batch, g, I(p.graph_ptr),
-                          d->fold_degree_scalers ? I(p.hist3) + 2 * kDegreeBuckets : nullptr, true, sa,
-                          d->fold_degree_scalers != 0));
+  if (!k0_fused)
+    GS_TRY(launch_csr_build(edge_index, edge_attr, n, num_edges, d->num_bond_cols, d->bond_dims, d->self_loops,
+                            I(p.rowptr), I(p.src), I(p.dst), I(p.combo), F(p.log_amp), F(p.log_att), err_flag,
+                            ws + p.csr_ws, gnnsaft_csr_workspace_bytes(n, num_edges), batch, g, I(p.graph_ptr),
+                            d->fold_degree_scalers ? I(p.hist3) + 2 * kDegreeBuckets : nullptr, true, sa,
+                            d->fold_degree_scalers != 0));
   if (d->fold_degree_scalers) {
     if (d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS) {  // weight fold rides along with the permutation fill
       const float *w0[GNNSAFT_MAX_FOLD_LAYERS], *w1[GNNSAFT_MAX_FOLD_LAYERS], *av[GNNSAFT_MAX_FOLD_LAYERS];
@@ -581,8 +621,9 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
         av[i] = lw[i].avg;
       }
       const DegreeFoldRequest req{d->num_layers, w0, w1, av, fold_dst ? D(p.gfold) : nullptr, F(p.weff), wstride};
+      const K0Installed inst{I(p.rowptr), I(p.src), I(p.dst), I(p.combo), p.ep, F(p.log_amp), F(p.log_att)};
       GS_TRY(launch_degree_tiles(I(p.rowptr), n, h, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3), err_flag,
-                                 true, sa, &req));
+                                 true, sa, &req, k0_fused ? &inst : nullptr));
     } else {
       GS_TRY(launch_degree_tiles(I(p.rowptr), n, h, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3), err_flag,
                                  true, sa));

@@ -28,6 +28,10 @@ from torch import nn
 from .. import _native
 from .._native import ModelDesc, aux_for, check, lib
 
+# int32 words of the per-module flag buffer: word 0 = the sticky GNNSAFT_FLAG_* word, the rest = persistent barrier
+# state of the cooperative structure chain (gnnsaft_model_desc.persistent_sync_words; zero between calls)
+_ERR_WORDS = 16
+
 ATOM_FEATURE_DIMS = (119, 5, 12, 12, 10, 6, 6, 2, 2)  # ogb >= 1.3
 BOND_FEATURE_DIMS = (5, 6, 2)
 TOWERS = 2  # models.py:76
@@ -167,6 +171,12 @@ class PNAPCSAFT(nn.Module):
         # hipGraph replay of the step is 0.490 ms with it and 0.491 ms without (C2), and the graph executor does
         # not reliably run the two branches concurrently (profiles/r01_c2_graph_replay_timeline.txt).
         self.use_side_stream = os.environ.get("GNNSAFT_SIDE_STREAM", "0") == "1"
+        # Batch structure (CSR by destination, degree plan) built by cooperating workgroups of the forward's FIRST
+        # launch beside the embedding work (csrc/elementwise.hip: k0_chain_body) instead of four dependent launches.
+        # Off by default: measured on MI355X (C2) the step has 21 launches instead of 25 and takes the same time
+        # (head of the step 57.4 us against 56.6 us): each of the chain's four grid barriers costs ~7 us while the
+        # embedding workgroups keep the L2s full of dirty lines (an agent-scope release writes them back).
+        self.fused_structure_chain = os.environ.get("GNNSAFT_K0_FUSED", "0") == "1"
         # gnnsaft_backward can run weight / bias gradients, edge-class sums and the edge-table chain on a side stream
         # (forked from and joined into the current stream inside the call).  True / False / None = decide per batch:
         # the ~10 event records + waits per layer cost the host more than the overlap gives the GPU on small batches
@@ -272,6 +282,7 @@ class PNAPCSAFT(nn.Module):
         d.unfused_readout = int(not self.fused_readout)
         d.debug_barrier_extra = int(self._debug_barrier_extra)
         d.unfused_bn_apply = {"pool": 0, True: 2, False: 1}[self.fused_batchnorm]
+        d.persistent_sync_words = _ERR_WORDS - 1 if self.fused_structure_chain else 0
         # Dropout of the readout MLP (models.py:88,95,99; config.dropout_rate through train/utils.py:66-70): a fresh
         # Philox key per training forward, drawn from torch's CPU generator (torch.manual_seed makes runs repeatable);
         # the backward regenerates the masks from the key kept in the tape's descriptor
@@ -380,7 +391,7 @@ class PNAPCSAFT(nn.Module):
                 self._workspace = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=dev)
             ws = self._workspace
         if self._err_flag is None or self._err_flag.device != dev:
-            self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)   # sticky: cleared when read
+            self._err_flag = torch.zeros(_ERR_WORDS, dtype=torch.int32, device=dev)   # word 0 sticky: cleared when read
         out = torch.empty((g, desc.num_para), dtype=torch.float32, device=dev)
         tgt_ptr, loss_ptr, loss = None, None, None
         if target is not None:
@@ -453,7 +464,7 @@ class PNAPCSAFT(nn.Module):
             ws = self._graph_ws
             ws_ptr = (ws.data_ptr() + 255) // 256 * 256
             if self._err_flag is None or self._err_flag.device != dev:
-                self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+                self._err_flag = torch.zeros(_ERR_WORDS, dtype=torch.int32, device=dev)
             out = torch.empty((g, desc.num_para), dtype=fdtype, device=dev)
             check(lib.gnnsaft_graph_forward(ctypes.byref(desc), code, pp, x.data_ptr(),
                                             edge_index.data_ptr() if e else None, edge_attr.data_ptr() if e else None,
@@ -565,7 +576,7 @@ class PNAPCSAFT(nn.Module):
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
         blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         if self._err_flag is None or self._err_flag.device != dev:
-            self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._err_flag = torch.zeros(_ERR_WORDS, dtype=torch.int32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             check(lib.gnnsaft_structure_build(ctypes.byref(desc), edge_index.data_ptr() if e else None,
@@ -601,9 +612,9 @@ class PNAPCSAFT(nn.Module):
         that would cost a launch at the head of every step for a word that is all but always zero."""
         if self._err_flag is None:
             return 0
-        flags = int(self._err_flag.item())
+        flags = int(self._err_flag[0].item())
         if flags:
-            self._err_flag.zero_()
+            self._err_flag.zero_()   # (a lost barrier may also have left the persistent barrier words non-zero)
         return flags
 
     def _apply(self, fn, *args, **kwargs):

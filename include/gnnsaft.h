@@ -51,6 +51,7 @@ extern "C" {
 #define GNNSAFT_FLAG_BAD_BATCH 4    /* batch not sorted / outside [0,G)          */
 #define GNNSAFT_FLAG_BAD_DEGREE 8   /* in-degree >= gnnsaft_degree_buckets() with */
                                     /* degree folding on: disable folding         */
+#define GNNSAFT_K0_SYNC_WORDS 8      /* see gnnsaft_model_desc.persistent_sync_words */
 #define GNNSAFT_FLAG_BARRIER_TIMEOUT 16 /* a grid barrier of the fused readout gave  */
                                     /* up waiting (workgroups not co-resident):    */
                                     /* the outputs of that call are invalid         */
@@ -323,7 +324,12 @@ typedef struct gnnsaft_model_desc {
   int32_t unfused_bn_apply;    /* train-mode node BatchNorm: 0 = combine + apply launches, except the LAST layer, whose */
                                /* normalisation the pooling kernel applies on load; 1 = combine + apply everywhere; */
                                /* 2 = statistics closed in one launch and applied on load by the next message GEMM  */
-  int32_t reserved0;
+  int32_t persistent_sync_words; /* int32 words the caller keeps BEHIND the err_flag word (err_flag[1 .. words]) for kernel   */
+                               /* synchronisation state that must survive between calls: zero before the first call,   */
+                               /* left zero by every call that completes (re-zero after GNNSAFT_FLAG_BARRIER_TIMEOUT). */
+                               /* >= GNNSAFT_K0_SYNC_WORDS: gnnsaft_forward builds the batch structure by workgroups  */
+                               /* of its FIRST launch (grid barriers among them) beside the embedding work instead of */
+                               /* four dependent launches.  0 (err_flag is one word): the launches.                   */
 } gnnsaft_model_desc;
 
 GNNSAFT_API int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);

@@ -503,11 +503,13 @@ def test_hip_path_properties_node_relabelling_explicit_loops_isolated_nodes():
         assert rel_err(got, want) < max(TOL, 3 * rel_err(copy.deepcopy(o2)(sparse), want))
 
 
+@pytest.mark.parametrize("chain", ["prologue workgroups", "launches"])
 @pytest.mark.parametrize("loops", [True, False])
-def test_the_forward_builds_the_csr_of_the_general_chain(loops):
+def test_the_forward_builds_the_csr_of_the_general_chain(loops, chain):
     """gnnsaft_forward builds its CSR with the slotted chain (csr.hip: in-degree < 32 promised by the folded update,
-    one pass over the edge list, per-node sort in registers); gnnsaft_csr_build keeps the general
-    histogram / scan / fill chain.  Same rows bit for bit, on an edge list in RANDOM order (the per-node sort has
+    one pass over the edge list, per-node sort in registers) -- by cooperating workgroups of its first launch with
+    grid barriers among them (elementwise.hip: k0_chain_body; needs the module's persistent barrier words), or as
+    launches; gnnsaft_csr_build keeps the general histogram / scan / fill chain.  Same rows bit for bit, on an edge list in RANDOM order (the per-node sort has
     work to do) with a hub of 13 in-edges (more than the 8 the register sort takes: the in-memory path) and the edge
     list's order kept inside every row (stable: the float sums downstream depend on it)."""
     import ctypes
@@ -526,8 +528,11 @@ def test_the_forward_builds_the_csr_of_the_general_chain(loops):
     oracle = oracle_model(64, 2, 1, 1, 1, 3, True, loops, degree_histogram(data), seed=2).train()
     m = hip_twin(copy.deepcopy(oracle))
     assert m.fold_degree_scalers
+    m.fused_structure_chain = chain == "prologue workgroups"
     pred = m(data.to(DEV))
-    assert m.input_error_flags() == 0
+    again = m(data.to(DEV))     # the barrier words are left zero: the next call meets the same barriers
+    assert torch.equal(pred, again)
+    assert m.input_error_flags() == 0 and int(m._err_flag.abs().sum()) == 0
     tape = pred.grad_fn.tape
     desc, e, gg = tape["desc"], tape["e"], tape["g"]
     wmap = WorkspaceMap()
