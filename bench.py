@@ -284,6 +284,11 @@ def main() -> None:
     # GNNSAFT_BENCH_REHEARSAL=1: multi-rank rehearsal on a ONE-GPU box (gloo backend, every rank on cuda:0);
     # exercises the N > 1 control flow only, its numbers mean nothing.
     rehearsal = os.environ.get("GNNSAFT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        # the ranks SHARE one GPU: kernels whose workgroups wait for each other (the cooperative structure chain of
+        # the forward's first launch) lose whole scheduling quanta there (measured 4x on the c4 forward); one process
+        # per GPU -- the deployment, and every real N > 1 run -- is unaffected
+        os.environ.setdefault("GNNSAFT_K0_FUSED", "0")
     rank, local_rank, world = parallel.init_from_env("gloo" if rehearsal else "nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")

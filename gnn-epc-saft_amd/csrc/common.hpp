@@ -307,7 +307,8 @@ __device__ __forceinline__ void block_degree_hist(int d, bool live, int32_t *__r
 
 // The K0 chain run by cooperating workgroups of the prologue launch (elementwise.hip: k0_chain_body)
 constexpr int kK0MaxWgs = 128;        // co-resident by construction: the first workgroups of the launch
-constexpr int kK0SyncInts = 5;        // four barriers + the exit count (<= GNNSAFT_K0_SYNC_WORDS)
+constexpr int kK0SyncInts = 2;        // one grid barrier + one ticket (<= GNNSAFT_K0_SYNC_WORDS)
+constexpr int kK0Group = 256;         // nodes per group of the chain (rows, look-back scan, degree histogram)
 struct BondDims {                     // vocabulary sizes of the bond attribute columns (edge class = mixed radix)
   int32_t n;
   int32_t dims[GNNSAFT_MAX_TABLES];
@@ -318,11 +319,14 @@ struct K0ChainArgs {
   BondDims bd;
   const int64_t *edge_index = nullptr, *edge_attr = nullptr, *batch = nullptr;
   int64_t n = 0, e = 0, g = 0;
-  int32_t *graph_ptr = nullptr, *cursor = nullptr, *slots = nullptr, *rowptr = nullptr, *tile_sums = nullptr;
+  int32_t *graph_ptr = nullptr, *slots = nullptr, *rowptr = nullptr;
   int32_t *src = nullptr, *dst = nullptr, *combo = nullptr;
   float *log_amp = nullptr, *log_att = nullptr;
-  int32_t *block_hist = nullptr, *hist = nullptr, *start = nullptr, *tiles = nullptr, *num_tiles = nullptr;
-  int32_t *sync = nullptr;            // kK0SyncInts ints, zero at entry, zero again at exit
+  unsigned long long *lookback = nullptr;   // [groups] (status << 32 | rows): decoupled look-back of the row offsets
+  int32_t *group_hist = nullptr;      // [groups][kDegreeBuckets]; the plan turns it into prefixes in place
+  int32_t *hist = nullptr, *start = nullptr, *tiles = nullptr, *num_tiles = nullptr;
+  int32_t *sync = nullptr;            // PERSISTENT: kK0SyncInts ints, zero at entry, zero again at exit
+  int32_t *cursor = nullptr;          // PERSISTENT: n fill cursors, zero at entry, zero again at exit
   int32_t *err = nullptr;
 };
 

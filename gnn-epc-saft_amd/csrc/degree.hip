@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void k_degree_plan(int32_t *__restrict__ block
 // pass 3: perm[start[d] + (nodes of degree d in earlier blocks / waves / lanes)] = node
 __device__ __forceinline__ void degree_fill_body(const int32_t *__restrict__ rowptr, int64_t n,
                                                  const int32_t *__restrict__ block_base,
-                                                 const int32_t *__restrict__ start, int32_t *__restrict__ perm) {
+                                                 const int32_t *__restrict__ start, int32_t *__restrict__ perm,
+                                                 int base_stride = 1 /* histogram entries per 1024-node block */) {
   __shared__ int32_t wcount[kDegBlock / 64][kDegreeBuckets];
   for (int t = threadIdx.x; t < (kDegBlock / 64) * kDegreeBuckets; t += kDegBlock) (&wcount[0][0])[t] = 0;
   __syncthreads();
@@ -51,7 +52,7 @@ __device__ __forceinline__ void degree_fill_body(const int32_t *__restrict__ row
   const int wave = threadIdx.x >> 6;
   int before = 0;
   for (int w = 0; w < wave; ++w) before += wcount[w][d];
-  perm[start[d] + block_base[(int64_t)blockIdx.x * kDegreeBuckets + d] + before + rank] = (int32_t)i;
+  perm[start[d] + block_base[(int64_t)blockIdx.x * base_stride * kDegreeBuckets + d] + before + rank] = (int32_t)i;
 }
 
 __global__ __launch_bounds__(kDegBlock) void k_degree_fill(const int32_t *__restrict__ rowptr, int64_t n,
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kDegBlock) void k_degree_fill_and_fold(const int32_
     if (lost)
       k0_install_empty(z, n, perm, fill_blocks);
     else
-      degree_fill_body(rowptr, n, block_base, start, perm);
+      degree_fill_body(rowptr, n, block_base, start, perm, z.err != nullptr ? kDegBlock / kK0Group : 1);
     return;
   }
   const unsigned b = blockIdx.x - fill_blocks;
@@ -193,8 +194,8 @@ extern "C" int64_t gnnsaft_degree_tiles_capacity(int64_t num_nodes, int32_t hidd
 extern "C" int32_t gnnsaft_degree_buckets(void) { return gs::kDegreeBuckets; }
 
 extern "C" size_t gnnsaft_degree_scratch_ints(int64_t num_nodes) {
-  // hist[B] | start[B] | block_hist[ceil(N/1024)][B]
-  return (size_t)(2 + gs_ceil_div(num_nodes > 0 ? num_nodes : 1, gs::kDegBlock)) * gs::kDegreeBuckets;
+  // hist[B] | start[B] | block_hist[ceil(N/1024)][B] (the cooperative chain of the forward: per group of 256 nodes)
+  return (size_t)(2 + gs_ceil_div(num_nodes > 0 ? num_nodes : 1, (int64_t)gs::kK0Group)) * gs::kDegreeBuckets;
 }
 
 int gs::launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm, int32_t *tiles,

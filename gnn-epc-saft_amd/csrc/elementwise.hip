@@ -170,11 +170,14 @@ __device__ __forceinline__ void edge_table_body(const PrologueArgs &a, unsigned 
 }
 
 // ---- the K0 chain as `wgs` cooperating workgroups at the FRONT of the prologue grid (dispatched first, hence
-// resident together from the start; the embedding / table / fold workgroups behind them do not depend on them, so the
-// chain's four grid barriers cost the launch nothing while that work lasts):
-//   zero cursors + block histogram, graph offsets | slotted fill | tile scans | finish rows + block histogram | plan
-// The barrier counters live in caller memory that is zero between calls (gnnsaft_model_desc.persistent_sync_words):
-// the last workgroup out zeroes them again.  A barrier that times out raises GNNSAFT_FLAG_BARRIER_TIMEOUT; the
+// resident together from the start; the embedding / table / fold workgroups behind them do not depend on them):
+//   slotted fill (+ graph offsets) | ONE grid barrier | per group of 256 nodes: row offsets by a decoupled look-back
+//   scan, rows, degree histogram of the group | ticket: the last workgroup out makes the degree plan
+// A release at agent scope writes back an L2 that the embedding workgroups keep full of dirty lines (~7 us per grid
+// barrier here against 1-1.5 us in the readout), hence ONE barrier: the fill cursors live in caller memory that is zero
+// between calls (gnnsaft_model_desc.persistent_sync_words; every cursor is reset by the thread that reads it), the
+// look-back words are relaxed agent-scope atomics (no fence needed: they carry their own data), the histogram is
+// per group and not atomic.  A lost barrier / a look-back that never resolves raises GNNSAFT_FLAG_BARRIER_TIMEOUT; the
 // degree-fill launch that follows then installs an empty structure (degree.hip), and the readout poisons the outputs.
 __device__ __forceinline__ bool k0_barrier(int32_t *counter, int expected, int32_t *err) {
   __shared__ int s_k0_ok;
@@ -183,8 +186,7 @@ __device__ __forceinline__ bool k0_barrier(int32_t *counter, int expected, int32
     __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     long spins = 0;
     int ok = 1;
-    // poll relaxed (an acquire load invalidates the caches on EVERY poll, under the embedding workgroups running
-    // beside the chain), one acquire fence when the last arrival has been seen
+    // poll relaxed (an acquire load invalidates the caches on EVERY poll), one acquire fence at the end
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > (1L << 22)) {
@@ -200,17 +202,52 @@ __device__ __forceinline__ bool k0_barrier(int32_t *counter, int expected, int32
   return s_k0_ok != 0;
 }
 
+constexpr unsigned long long kLbAggregate = 1ull << 32, kLbInclusive = 2ull << 32;
+
+// exclusive prefix of group gi (> 0) from the look-back words of its predecessors; called by wave 0, all 64 lanes
+__device__ __forceinline__ long long k0_look_back(unsigned long long *lb, int64_t gi, int32_t *err) {
+  const int lane = threadIdx.x & 63;
+  long long prefix = 0;
+  int64_t j = gi - 1;
+  for (;;) {
+    const int64_t jj = j - lane;   // lane 0: the nearest predecessor
+    unsigned long long v = kLbInclusive;   // in front of group 0: an inclusive prefix of 0
+    if (jj >= 0) {
+      long spins = 0;
+      for (;;) {
+        v = __hip_atomic_load(lb + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 32) != 0ull) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1L << 22)) {
+          if (err) atomicOr(err, GNNSAFT_FLAG_BARRIER_TIMEOUT);
+          v = kLbInclusive;
+          break;
+        }
+      }
+    }
+    const unsigned long long incl = __ballot((v >> 32) == 2ull);
+    const int first = incl != 0ull ? __ffsll((long long)incl) - 1 : 64;
+    long long c = lane <= first ? (long long)(v & 0xffffffffull) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    prefix += c;
+    if (first < 64) return prefix;
+    j -= 64;
+  }
+}
+
 __device__ __forceinline__ void k0_chain_body(const K0ChainArgs &k, int w) {
-  __shared__ int s_scan[kScanBlock / 64], s_before[16], s_all[16];
+  __shared__ int s_scan[kScanBlock / 64], s_hist[kDegreeBuckets], s_last;
+  __shared__ long long s_prefix;
   __shared__ DegreePlanLds s_plan;
   const int W = k.wgs, tid = threadIdx.x;
   const int64_t n = k.n, e = k.e;
-  const int64_t stride = (int64_t)W * 256, gtid = (int64_t)w * 256 + tid;
-  const int64_t nb = (n + kDegBlock - 1) / kDegBlock;
-  const int expected = W + k.barrier_extra;
-  // phase 0: nothing here reads what another workgroup writes
-  for (int64_t i = gtid; i < n; i += stride) k.cursor[i] = 0;
-  for (int64_t i = gtid; i < nb * kDegreeBuckets; i += stride) k.block_hist[i] = 0;
+  const int64_t stride = (int64_t)W * kK0Group, gtid = (int64_t)w * kK0Group + tid;
+  const int64_t groups = (n + kK0Group - 1) / kK0Group;
+  // phase 1: edge ids into the slot rows of their destinations (cursors: zero at entry); look-back words to "empty"
+  for (int64_t i = gtid; i < e; i += stride) fill_slot_body(k.edge_index, n, e, k.cursor, k.slots, k.err, i);
+  for (int64_t i = gtid; i < groups; i += stride)
+    __hip_atomic_store(k.lookback + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (k.graph_ptr != nullptr) {
     if (k.batch != nullptr) {
       for (int64_t i = gtid; i <= n; i += stride) batch_to_ptr_slot(k.batch, n, k.g, k.graph_ptr, k.err, i);
@@ -219,43 +256,72 @@ __device__ __forceinline__ void k0_chain_body(const K0ChainArgs &k, int w) {
       k.graph_ptr[1] = (int32_t)n;
     }
   }
-  k0_barrier(k.sync + 0, expected, k.err);
-  // phase 1: edge ids into the slot rows of their destinations
-  for (int64_t i = gtid; i < e; i += stride) fill_slot_body(k.edge_index, n, e, k.cursor, k.slots, k.err, i);
-  k0_barrier(k.sync + 1, expected, k.err);
-  // phase 2: tile-local scans of the (clamped) in-degrees
-  const int64_t scan_tiles = ((n > 0 ? n : 1) + kScanTile - 1) / kScanTile;
-  for (int64_t t = w; t < scan_tiles; t += W)
-    scan_tile_body(k.cursor, n, k.self_loops, k.rowptr, k.tile_sums, kCsrSlots, t, s_scan);
-  k0_barrier(k.sync + 2, expected, k.err);
-  // phase 3: rows of 256 nodes at a time; their degrees into the histogram of their 1024-node block
-  const int64_t groups = (n + 255) / 256;
+  k0_barrier(k.sync + 0, W + k.barrier_extra, k.err);
+  // phase 2: groups of 256 nodes, ascending per workgroup (a group only ever waits for groups in front of it)
   for (int64_t gi = w; gi < groups; gi += W) {
-    const int deg = finish_rows_slots_body(k.edge_index, k.edge_attr, n, k.bd, k.self_loops, k.rowptr, k.tile_sums,
-                                           scan_tiles, k.cursor, k.slots, k.src, k.dst, k.combo, k.log_amp, k.log_att,
-                                           k.err, gi, 256, gi == groups - 1, s_before, s_all);
-    const bool live = gi * 256 + tid < n;
-    const int d = live ? clamp_degree(deg, k.err) : 0;
-    int32_t *bh = k.block_hist + (gi * 256 / kDegBlock) * kDegreeBuckets;
+    const int64_t i = gi * kK0Group + tid;
+    const bool live = i < n;
+    int cnt = 0;
+    if (live) {
+      cnt = k.cursor[i];
+      k.cursor[i] = 0;     // left zero for the next call
+      cnt = cnt < 0 ? 0 : (cnt < kCsrSlots ? cnt : kCsrSlots);
+    }
+    int32_t *row = k.slots + (live ? i : 0) * kCsrSlots;
+    int key[8];
+    load_slot_keys(row, cnt, key);
+    if (tid < kDegreeBuckets) s_hist[tid] = 0;
+    int total;
+    const int off = block_exclusive_scan(live ? cnt + k.self_loops : 0, s_scan, total);   // (syncs inside)
+    if (tid < 64) {   // wave 0: publish the group's rows, resolve its exclusive prefix, publish the inclusive one
+      long long prefix = 0;
+      if (gi > 0) {
+        if (tid == 0)
+          __hip_atomic_store(k.lookback + gi, kLbAggregate | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        prefix = k0_look_back(k.lookback, gi, k.err);
+      }
+      if (tid == 0) {
+        __hip_atomic_store(k.lookback + gi, kLbInclusive | (unsigned long long)(unsigned)(prefix + total),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_prefix = prefix;
+        if (gi == groups - 1) k.rowptr[n] = (int32_t)(prefix + total);
+      }
+    }
+    __syncthreads();
+    int d = 0;
+    if (live) {
+      const int beg = (int)s_prefix + off;
+      k.rowptr[i] = beg;
+      const int deg = emit_node_rows(k.edge_index, k.edge_attr, k.bd, k.self_loops, i, cnt, beg, key, row, k.src, k.dst,
+                                     k.combo, k.log_amp, k.log_att, k.err);
+      d = clamp_degree(deg, k.err);
+    }
     unsigned long long todo = __ballot(live);
-    while (todo != 0ull) {   // one integer atomic per (wave, degree): the sums do not depend on arrival order
+    while (todo != 0ull) {   // the group's degree histogram: one LDS add per (wave, degree)
       const int leader = __ffsll((long long)todo) - 1;
       const int dl = __shfl(d, leader);
       const unsigned long long same = __ballot(live && d == dl);
-      if ((tid & 63) == leader) atomicAdd(&bh[dl], __popcll(same));
+      if ((tid & 63) == leader) atomicAdd(&s_hist[dl], __popcll(same));
       todo &= ~same;
     }
+    __syncthreads();
+    if (tid < kDegreeBuckets) k.group_hist[gi * kDegreeBuckets + tid] = s_hist[tid];
+    __syncthreads();   // (s_hist, s_prefix are reused by the next group)
   }
-  if (groups == 0 && w == 0 && tid == 0) k.rowptr[0] = 0;
-  k0_barrier(k.sync + 3, expected, k.err);
-  // phase 4 (one workgroup): bucket starts, tile table; the permutation fill is the next launch
-  if (w == 0) degree_plan_body(k.block_hist, nb, k.tile_rows, k.hist, k.start, k.tiles, k.num_tiles, s_plan);
-  // the last workgroup out leaves the counters zero for the next call
+  // ticket: the last workgroup out plans (bucket starts, tile table; the permutation fill is the next launch) and
+  // leaves the persistent words zero
   __syncthreads();
   if (tid == 0) {
-    const int before = __hip_atomic_fetch_add(k.sync + 4, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (before == W - 1)
-      for (int j = 0; j < 5; ++j) __hip_atomic_store(k.sync + j, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int before = __hip_atomic_fetch_add(k.sync + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = before == W - 1;
+  }
+  __syncthreads();
+  if (s_last != 0) {   // (workgroup-uniform)
+    degree_plan_body(k.group_hist, groups, k.tile_rows, k.hist, k.start, k.tiles, k.num_tiles, s_plan);
+    if (tid == 0) {
+      __hip_atomic_store(k.sync + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(k.sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -551,7 +617,8 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
   int64_t bk = 0;
   a.k0.wgs = 0;
   if (k0 != nullptr && k0->wgs > 0) {
-    GS_REQUIRE(k0->wgs <= kK0MaxWgs && k0->sync != nullptr && k0->cursor != nullptr, GNNSAFT_ERR_SHAPE);
+    GS_REQUIRE(k0->wgs <= kK0MaxWgs && k0->sync != nullptr && k0->cursor != nullptr && k0->lookback != nullptr,
+               GNNSAFT_ERR_SHAPE);
     a.k0 = *k0;
     bk = k0->wgs;
   }

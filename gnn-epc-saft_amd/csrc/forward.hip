@@ -504,7 +504,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
   // (gnnsaft_model_desc.persistent_sync_words), the bounded in-degree of the folded update and one stream
   const bool k0_fused = structure_in == nullptr && aux == nullptr && d->fold_degree_scalers != 0 &&
                         d->num_layers >= 1 && d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS && err_flag != nullptr &&
-                        d->persistent_sync_words >= GNNSAFT_K0_SYNC_WORDS;
+                        d->persistent_sync_words >= GNNSAFT_K0_SYNC_WORDS + n;
   // the edge-class tables (cenc, rtab: weights only) as workgroups of the same launch instead of two small GEMMs
   const bool tables_in_prologue = d->num_layers >= 1 && d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS && h <= 256 &&
                                   (h % 16) == 0 && p.combos <= 4096;
@@ -525,7 +525,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
       // the batch structure by cooperating workgroups at the front of this launch (elementwise.hip: k0_chain_body)
       GS_REQUIRE(batch != nullptr || g == 1, GNNSAFT_ERR_SHAPE);
       GS_REQUIRE(n + num_edges < ((int64_t)1 << 31) - 1, GNNSAFT_ERR_SHAPE);
-      const int64_t want = gs_ceil_div(n, (int64_t)256);
+      const int64_t want = gs_ceil_div(n, (int64_t)kK0Group);
       k0.wgs = (int)(want < kK0MaxWgs ? want : kK0MaxWgs);
       k0.self_loops = d->self_loops ? 1 : 0;
       k0.tile_rows = pna_fold_tile_rows(h);
@@ -539,7 +539,9 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
       k0.e = num_edges;
       k0.g = g;
       k0.graph_ptr = I(p.graph_ptr);
-      csr_workspace_parts(ws + p.csr_ws, n, &k0.cursor, &k0.tile_sums, &k0.slots);
+      int32_t *unused_cursor, *unused_sums;
+      csr_workspace_parts(ws + p.csr_ws, n, &unused_cursor, &unused_sums, &k0.slots);
+      k0.lookback = reinterpret_cast<unsigned long long *>(ws + p.csr_ws);   // the general chain's in-degree counts
       k0.rowptr = I(p.rowptr);
       k0.src = I(p.src);
       k0.dst = I(p.dst);
@@ -548,10 +550,11 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
       k0.log_att = F(p.log_att);
       k0.hist = I(p.hist3);
       k0.start = I(p.hist3) + kDegreeBuckets;
-      k0.block_hist = I(p.hist3) + 2 * kDegreeBuckets;
+      k0.group_hist = I(p.hist3) + 2 * kDegreeBuckets;
       k0.tiles = I(p.tiles);
       k0.num_tiles = I(p.num_tiles);
       k0.sync = err_flag + 1;
+      k0.cursor = err_flag + 1 + GNNSAFT_K0_SYNC_WORDS;
       k0.err = err_flag;
     }
     EdgeTableLayers et;

@@ -103,9 +103,98 @@ __device__ __forceinline__ void sort_exchange(int &a, int &b) {
   b = hi;
 }
 
+// the (<= 8) edge ids of a slot row into registers, unused entries = INT_MAX (cnt > 8: sorted in memory by emit_node_rows)
+__device__ __forceinline__ void load_slot_keys(const int32_t *__restrict__ row, int cnt, int (&key)[8]) {
+  if (cnt <= 8) {
+    const int4 lo = cnt > 0 ? *reinterpret_cast<const int4 *>(row) : int4{0, 0, 0, 0};
+    const int4 hi = cnt > 4 ? *reinterpret_cast<const int4 *>(row + 4) : int4{0, 0, 0, 0};
+    const int raw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int a = 0; a < 8; ++a) key[a] = a < cnt ? raw[a] : 0x7fffffff;
+  }
+}
+
+// node i with `cnt` in-edges (ids in key[] / in its slot row) whose rows start at `beg`: ids ascending (8 or fewer: a
+// sorting network in registers), src / dst / combo rows, the loop row, degree scaler logs.  Returns the in-degree
+// with the loop.
+__device__ __forceinline__ int emit_node_rows(const int64_t *__restrict__ edge_index,
+                                              const int64_t *__restrict__ edge_attr, const BondDims &bd, int self_loops,
+                                              int64_t i, int cnt, int beg, int (&key)[8], int32_t *__restrict__ row,
+                                              int32_t *__restrict__ src, int32_t *__restrict__ dst,
+                                              int32_t *__restrict__ combo, float *__restrict__ log_amp,
+                                              float *__restrict__ log_att, int32_t *err) {
+  if (cnt <= 8) {
+    // Batcher odd-even merge sort, 8 keys, 19 exchanges
+    sort_exchange(key[0], key[1]); sort_exchange(key[2], key[3]); sort_exchange(key[4], key[5]); sort_exchange(key[6], key[7]);
+    sort_exchange(key[0], key[2]); sort_exchange(key[1], key[3]); sort_exchange(key[4], key[6]); sort_exchange(key[5], key[7]);
+    sort_exchange(key[1], key[2]); sort_exchange(key[5], key[6]);
+    sort_exchange(key[0], key[4]); sort_exchange(key[1], key[5]); sort_exchange(key[2], key[6]); sort_exchange(key[3], key[7]);
+    sort_exchange(key[2], key[4]); sort_exchange(key[3], key[5]);
+    sort_exchange(key[1], key[2]); sort_exchange(key[3], key[4]); sort_exchange(key[5], key[6]);
+    int64_t sv[8];
+    int cid[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {   // every row's loads are independent: all in flight together
+      const int64_t id = a < cnt ? key[a] : 0;
+      sv[a] = a < cnt ? edge_index[id] : 0;
+      int c = 0;
+      for (int k = 0; k < bd.n; ++k) {
+        int64_t v = a < cnt ? edge_attr[id * bd.n + k] : 0;
+        if (v < 0 || v >= bd.dims[k]) {
+          if (err) atomicOr(err, GNNSAFT_FLAG_BAD_ATTR);
+          v = 0;
+        }
+        c = c * bd.dims[k] + (int)v;
+      }
+      cid[a] = c;
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+      if (a < cnt) {
+        src[beg + a] = (int32_t)sv[a];
+        dst[beg + a] = (int32_t)i;
+        combo[beg + a] = cid[a];
+      }
+  } else {
+    for (int a = 1; a < cnt; ++a) {   // insertion sort in the slot row, ascending edge id
+      const int k2 = row[a];
+      int b = a - 1;
+      while (b >= 0 && row[b] > k2) {
+        row[b + 1] = row[b];
+        --b;
+      }
+      row[b + 1] = k2;
+    }
+    for (int a = 0; a < cnt; ++a) {
+      const int64_t id = row[a];
+      int c = 0;
+      for (int k = 0; k < bd.n; ++k) {
+        int64_t v = edge_attr[id * bd.n + k];
+        if (v < 0 || v >= bd.dims[k]) {
+          if (err) atomicOr(err, GNNSAFT_FLAG_BAD_ATTR);
+          v = 0;
+        }
+        c = c * bd.dims[k] + (int)v;
+      }
+      src[beg + a] = (int32_t)edge_index[id];
+      dst[beg + a] = (int32_t)i;
+      combo[beg + a] = c;
+    }
+  }
+  int deg = cnt;
+  if (self_loops) {
+    src[beg + cnt] = (int32_t)i;
+    dst[beg + cnt] = (int32_t)i;
+    combo[beg + cnt] = 0;
+    deg += 1;
+  }
+  log_amp[i] = degree_log_amp(deg);
+  log_att[i] = degree_log_att(deg);
+  return deg;
+}
+
 // One thread per node of the group of `bsize` nodes number `group` (bsize divides kScanTile; every thread of the
-// workgroup calls): final row offset (tile-local scan value + the totals of the tiles in front), the node's edge ids
-// in ascending order (8 or fewer: a sorting network in registers), src / dst / combo rows, degree scaler logs.
+// workgroup calls): final row offset (tile-local scan value + the totals of the tiles in front), then the node's rows.
 // Returns the node's in-degree (with the loop), 0 where there is no node.  `last`: this group also writes rowptr[n].
 __device__ __forceinline__ int finish_rows_slots_body(
     const int64_t *__restrict__ edge_index, const int64_t *__restrict__ edge_attr, int64_t n, const BondDims &bd,
@@ -120,13 +209,7 @@ __device__ __forceinline__ int finish_rows_slots_body(
   cnt = cnt < 0 ? 0 : (cnt < kCsrSlots ? cnt : kCsrSlots);
   int32_t *row = slots + (live ? i : 0) * kCsrSlots;
   int key[8];
-  if (cnt <= 8) {
-    const int4 lo = cnt > 0 ? *reinterpret_cast<const int4 *>(row) : int4{0, 0, 0, 0};
-    const int4 hi = cnt > 4 ? *reinterpret_cast<const int4 *>(row + 4) : int4{0, 0, 0, 0};
-    const int raw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-    for (int a = 0; a < 8; ++a) key[a] = a < cnt ? raw[a] : 0x7fffffff;
-  }
+  load_slot_keys(row, cnt, key);
   // tile totals in front of this group's tile (the last group also sums all of them: rowptr[n])
   const int64_t tile = (group * bsize) / kScanTile;
   const int64_t upto = last ? num_tiles : tile;
@@ -158,73 +241,8 @@ __device__ __forceinline__ int finish_rows_slots_body(
   if (live) {
     const int beg = rowptr[i] + before;
     rowptr[i] = beg;
-    if (cnt <= 8) {
-      // Batcher odd-even merge sort, 8 keys, 19 exchanges
-      sort_exchange(key[0], key[1]); sort_exchange(key[2], key[3]); sort_exchange(key[4], key[5]); sort_exchange(key[6], key[7]);
-      sort_exchange(key[0], key[2]); sort_exchange(key[1], key[3]); sort_exchange(key[4], key[6]); sort_exchange(key[5], key[7]);
-      sort_exchange(key[1], key[2]); sort_exchange(key[5], key[6]);
-      sort_exchange(key[0], key[4]); sort_exchange(key[1], key[5]); sort_exchange(key[2], key[6]); sort_exchange(key[3], key[7]);
-      sort_exchange(key[2], key[4]); sort_exchange(key[3], key[5]);
-      sort_exchange(key[1], key[2]); sort_exchange(key[3], key[4]); sort_exchange(key[5], key[6]);
-      int64_t sv[8];
-      int cid[8];
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {   // every row's loads are independent: all in flight together
-        const int64_t id = a < cnt ? key[a] : 0;
-        sv[a] = a < cnt ? edge_index[id] : 0;
-        int c = 0;
-        for (int k = 0; k < bd.n; ++k) {
-          int64_t v = a < cnt ? edge_attr[id * bd.n + k] : 0;
-          if (v < 0 || v >= bd.dims[k]) {
-            if (err) atomicOr(err, GNNSAFT_FLAG_BAD_ATTR);
-            v = 0;
-          }
-          c = c * bd.dims[k] + (int)v;
-        }
-        cid[a] = c;
-      }
-#pragma unroll
-      for (int a = 0; a < 8; ++a)
-        if (a < cnt) {
-          src[beg + a] = (int32_t)sv[a];
-          dst[beg + a] = (int32_t)i;
-          combo[beg + a] = cid[a];
-        }
-    } else {
-      for (int a = 1; a < cnt; ++a) {   // insertion sort in the slot row, ascending edge id
-        const int k2 = row[a];
-        int b = a - 1;
-        while (b >= 0 && row[b] > k2) {
-          row[b + 1] = row[b];
-          --b;
-        }
-        row[b + 1] = k2;
-      }
-      for (int a = 0; a < cnt; ++a) {
-        const int64_t id = row[a];
-        int c = 0;
-        for (int k = 0; k < bd.n; ++k) {
-          int64_t v = edge_attr[id * bd.n + k];
-          if (v < 0 || v >= bd.dims[k]) {
-            if (err) atomicOr(err, GNNSAFT_FLAG_BAD_ATTR);
-            v = 0;
-          }
-          c = c * bd.dims[k] + (int)v;
-        }
-        src[beg + a] = (int32_t)edge_index[id];
-        dst[beg + a] = (int32_t)i;
-        combo[beg + a] = c;
-      }
-    }
-    deg = cnt;
-    if (self_loops) {
-      src[beg + cnt] = (int32_t)i;
-      dst[beg + cnt] = (int32_t)i;
-      combo[beg + cnt] = 0;
-      deg += 1;
-    }
-    log_amp[i] = degree_log_amp(deg);
-    log_att[i] = degree_log_att(deg);
+    deg = emit_node_rows(edge_index, edge_attr, bd, self_loops, i, cnt, beg, key, row, src, dst, combo, log_amp, log_att,
+                         err);
   }
   return deg;
 }

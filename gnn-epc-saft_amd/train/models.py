@@ -155,6 +155,7 @@ class PNAPCSAFT(nn.Module):
         self.mlp.append(nn.Sequential(*tail))
         self._workspace: Optional[torch.Tensor] = None
         self._err_flag: Optional[torch.Tensor] = None
+        self._retired_flags: list = []
         self._loss_buf: Optional[torch.Tensor] = None
         # Degree-folded update GEMM (K = 5F instead of 13F): exact for in-degrees (self-loop included) below
         # gnnsaft_degree_buckets() = 32, which covers molecular graphs.  Decided here, on the host, from the
@@ -172,11 +173,10 @@ class PNAPCSAFT(nn.Module):
         # not reliably run the two branches concurrently (profiles/r01_c2_graph_replay_timeline.txt).
         self.use_side_stream = os.environ.get("GNNSAFT_SIDE_STREAM", "0") == "1"
         # Batch structure (CSR by destination, degree plan) built by cooperating workgroups of the forward's FIRST
-        # launch beside the embedding work (csrc/elementwise.hip: k0_chain_body) instead of four dependent launches.
-        # Off by default: measured on MI355X (C2) the step has 21 launches instead of 25 and takes the same time
-        # (head of the step 57.4 us against 56.6 us): each of the chain's four grid barriers costs ~7 us while the
-        # embedding workgroups keep the L2s full of dirty lines (an agent-scope release writes them back).
-        self.fused_structure_chain = os.environ.get("GNNSAFT_K0_FUSED", "0") == "1"
+        # launch beside the embedding work (csrc/elementwise.hip: k0_chain_body: one grid barrier, a look-back scan,
+        # a ticket) instead of four dependent launches behind it.  Measured on MI355X (C2): 21 launches instead of 25,
+        # head of the step 43 us instead of 57 us.  Needs this module's persistent flag buffer (_flag_buffer).
+        self.fused_structure_chain = os.environ.get("GNNSAFT_K0_FUSED", "1") == "1"
         # gnnsaft_backward can run weight / bias gradients, edge-class sums and the edge-table chain on a side stream
         # (forked from and joined into the current stream inside the call).  True / False / None = decide per batch:
         # the ~10 event records + waits per layer cost the host more than the overlap gives the GPU on small batches
@@ -282,7 +282,6 @@ class PNAPCSAFT(nn.Module):
         d.unfused_readout = int(not self.fused_readout)
         d.debug_barrier_extra = int(self._debug_barrier_extra)
         d.unfused_bn_apply = {"pool": 0, True: 2, False: 1}[self.fused_batchnorm]
-        d.persistent_sync_words = _ERR_WORDS - 1 if self.fused_structure_chain else 0
         # Dropout of the readout MLP (models.py:88,95,99; config.dropout_rate through train/utils.py:66-70): a fresh
         # Philox key per training forward, drawn from torch's CPU generator (torch.manual_seed makes runs repeatable);
         # the backward regenerates the masks from the key kept in the tape's descriptor
@@ -390,8 +389,9 @@ class PNAPCSAFT(nn.Module):
             if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need + 256:
                 self._workspace = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=dev)
             ws = self._workspace
-        if self._err_flag is None or self._err_flag.device != dev:
-            self._err_flag = torch.zeros(_ERR_WORDS, dtype=torch.int32, device=dev)   # word 0 sticky: cleared when read
+        self._flag_buffer(dev, n)
+        # (the words behind the flag word: persistent barrier state + fill cursors of the cooperative structure chain)
+        desc.persistent_sync_words = self._err_flag.numel() - 1 if self.fused_structure_chain else 0
         out = torch.empty((g, desc.num_para), dtype=torch.float32, device=dev)
         tgt_ptr, loss_ptr, loss = None, None, None
         if target is not None:
@@ -463,8 +463,7 @@ class PNAPCSAFT(nn.Module):
                 self._graph_ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=dev)
             ws = self._graph_ws
             ws_ptr = (ws.data_ptr() + 255) // 256 * 256
-            if self._err_flag is None or self._err_flag.device != dev:
-                self._err_flag = torch.zeros(_ERR_WORDS, dtype=torch.int32, device=dev)
+            self._flag_buffer(dev)
             out = torch.empty((g, desc.num_para), dtype=fdtype, device=dev)
             check(lib.gnnsaft_graph_forward(ctypes.byref(desc), code, pp, x.data_ptr(),
                                             edge_index.data_ptr() if e else None, edge_attr.data_ptr() if e else None,
@@ -575,8 +574,7 @@ class PNAPCSAFT(nn.Module):
         ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
         blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        if self._err_flag is None or self._err_flag.device != dev:
-            self._err_flag = torch.zeros(_ERR_WORDS, dtype=torch.int32, device=dev)
+        self._flag_buffer(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             check(lib.gnnsaft_structure_build(ctypes.byref(desc), edge_index.data_ptr() if e else None,
@@ -612,10 +610,26 @@ class PNAPCSAFT(nn.Module):
         that would cost a launch at the head of every step for a word that is all but always zero."""
         if self._err_flag is None:
             return 0
-        flags = int(self._err_flag[0].item())
-        if flags:
-            self._err_flag.zero_()   # (a lost barrier may also have left the persistent barrier words non-zero)
+        flags = 0
+        for buf in [self._err_flag] + self._retired_flags:
+            f = int(buf[0].item())
+            if f:
+                buf.zero_()   # (a lost barrier may also have left the persistent barrier words non-zero)
+            flags |= f
         return flags
+
+    def _flag_buffer(self, dev, num_nodes: int = 0) -> torch.Tensor:
+        """The module's int32 flag buffer on ``dev``: word 0 = the sticky GNNSAFT_FLAG_* word (cleared when read), the
+        words behind it = state the cooperative structure chain keeps between calls (barrier words, one fill cursor
+        per node; zero between calls).  Grown by replacement; a replaced buffer stays alive -- a captured hipGraph
+        may still write its flag word -- and is read by ``input_error_flags`` too."""
+        need = _ERR_WORDS + (num_nodes if self.fused_structure_chain else 0)
+        buf = self._err_flag
+        if buf is None or buf.device != dev or buf.numel() < need:
+            if buf is not None and buf.device == dev:
+                self._retired_flags.append(buf)
+            self._err_flag = torch.zeros(need + need // 4, dtype=torch.int32, device=dev)
+        return self._err_flag
 
     def _apply(self, fn, *args, **kwargs):
         self._workspace = None

@@ -324,12 +324,13 @@ typedef struct gnnsaft_model_desc {
   int32_t unfused_bn_apply;    /* train-mode node BatchNorm: 0 = combine + apply launches, except the LAST layer, whose */
                                /* normalisation the pooling kernel applies on load; 1 = combine + apply everywhere; */
                                /* 2 = statistics closed in one launch and applied on load by the next message GEMM  */
-  int32_t persistent_sync_words; /* int32 words the caller keeps BEHIND the err_flag word (err_flag[1 .. words]) for kernel   */
-                               /* synchronisation state that must survive between calls: zero before the first call,   */
-                               /* left zero by every call that completes (re-zero after GNNSAFT_FLAG_BARRIER_TIMEOUT). */
-                               /* >= GNNSAFT_K0_SYNC_WORDS: gnnsaft_forward builds the batch structure by workgroups  */
-                               /* of its FIRST launch (grid barriers among them) beside the embedding work instead of */
-                               /* four dependent launches.  0 (err_flag is one word): the launches.                   */
+  int32_t persistent_sync_words; /* int32 words the caller keeps BEHIND the err_flag word (err_flag[1 .. words]) for state  */
+                               /* that must survive between calls: zero before the first call, left zero by every call  */
+                               /* that completes (re-zero all of it after GNNSAFT_FLAG_BARRIER_TIMEOUT).                */
+                               /* >= GNNSAFT_K0_SYNC_WORDS + num_nodes: gnnsaft_forward builds the batch structure by   */
+                               /* cooperating workgroups of its FIRST launch (one grid barrier, fill cursors in these    */
+                               /* words) beside the embedding work instead of four dependent launches.  0 (err_flag is  */
+                               /* one word): the launches.                                                              */
 } gnnsaft_model_desc;
 
 GNNSAFT_API int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);
