@@ -503,9 +503,10 @@ def test_hip_path_properties_node_relabelling_explicit_loops_isolated_nodes():
         assert rel_err(got, want) < max(TOL, 3 * rel_err(copy.deepcopy(o2)(sparse), want))
 
 
-@pytest.mark.parametrize("chain", ["prologue workgroups", "launches"])
+@pytest.mark.parametrize("graphs", [150, 1800])   # 1800: 36 k nodes = 141 groups of 256 on 128 workgroups (two rounds
+@pytest.mark.parametrize("chain", ["prologue workgroups", "launches"])   # of the look-back scan)
 @pytest.mark.parametrize("loops", [True, False])
-def test_the_forward_builds_the_csr_of_the_general_chain(loops, chain):
+def test_the_forward_builds_the_csr_of_the_general_chain(loops, chain, graphs):
     """gnnsaft_forward builds its CSR with the slotted chain (csr.hip: in-degree < 32 promised by the folded update,
     one pass over the edge list, per-node sort in registers) -- by cooperating workgroups of its first launch with
     grid barriers among them (elementwise.hip: k0_chain_body; needs the module's persistent barrier words), or as
@@ -517,7 +518,7 @@ def test_the_forward_builds_the_csr_of_the_general_chain(loops, chain):
     import gnn_epc_saft_amd.kernels as K
     from gnn_epc_saft_amd._native import WorkspaceMap, lib
     from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
-    data = make_synthetic_batch(150, 31)
+    data = make_synthetic_batch(graphs, 31)
     n = data.x.shape[0]
     g = torch.Generator().manual_seed(5)
     hub = torch.stack([torch.arange(1, 14), torch.zeros(13, dtype=torch.int64)])
