@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict
                                                        const float *__restrict__ msgs, float *__restrict__ agg,
                                                        int64_t num_nodes, int f, RowSplit rs) {
   // rs.per_row = f / 2 lanes per node (2F floats / 4 per thread)
-  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // (XCD-contiguous block numbering: the q rows of a molecule are gathered by ~3 nodes each -- through one L2)
+  const int64_t slot = (int64_t)gs_xcd_block_grouped(blockIdx.x, gridDim.x, gs_xcd_span(f)) * blockDim.x + threadIdx.x;
   int64_t node;
   int lane_in_node;
   gs_split(rs, slot, node, lane_in_node);

@@ -60,6 +60,29 @@ __device__ __forceinline__ void gs_split(const RowSplit rs, int64_t slot, int64_
 __device__ __forceinline__ f32x4 gs_ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void gs_st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2: MI355X_MICROARCH.md, "Workgroup
+// dispatch").  Bijective renumbering that gives every XCD ONE contiguous range of the logical block ids, so that
+// neighbouring rows (a molecule's nodes and their neighbours) are gathered through one L2 instead of eight.  A
+// speed choice only.
+__device__ __forceinline__ unsigned gs_xcd_block(unsigned orig, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7u, xcd = orig & 7u;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+// The same inside groups of 8 * span consecutive blocks: every XCD gets `span` consecutive logical blocks of each
+// group, and all XCDs stay inside one stretch of memory (DRAM page locality of the output stream).  The tail that does
+// not fill a group keeps its numbering.
+__device__ __forceinline__ unsigned gs_xcd_block_grouped(unsigned orig, unsigned nwg, unsigned span) {
+  const unsigned group = 8u * span;
+  if (orig >= (nwg / group) * group) return orig;
+  const unsigned o = orig % group;
+  return orig - o + (o & 7u) * span + (o >> 3);
+}
+
+// span for the row kernels with 2F / 4 lanes per node (256-thread workgroups hold 512 / F nodes): ~32 nodes, i.e. one or
+// two molecules, per XCD and group -- measured best at C2 and C3 (spans of 16 / 64 / 256 nodes and one range per XCD:
+// DESIGN.md section 9)
+__device__ __forceinline__ unsigned gs_xcd_span(int f) { return f >= 16 ? (unsigned)(f >> 4) : 1u; }
+
 // The dynamic-LDS limit above 64 KB is a property of (kernel, DEVICE): raise it once per device this process drives
 // (`devices`: one static bitmask per kernel instantiation; bit d = done on device d; devices >= 64: every launch).
 // Safe from several host threads.
