@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA
 MFMA_BF16_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA (the pipe the split-bf16 GEMMs run on)
 GEMM_X6 = os.environ.get("GNNSAFT_GEMM_X6", "1") != "0"   # csrc/gemm.hip: six bf16 MFMAs per f32-equivalent product
-K4_KERNEL = "k_pna_aggregate<2>"   # the kernel gnnsaft_forward launches for pre_layers == 1 (kFusedQ source)
+K4_KERNEL = "k_pna_aggregate<2"    # (rocprofv3 prints k_pna_aggregate<2, false> / <2, true>) the kernel gnnsaft_forward launches for pre_layers == 1 (kFusedQ source)
 PROFILE_TAG = "r03"        # profiles/<tag>_* files are the rocprofv3 evidence of THIS round's kernels
 
 

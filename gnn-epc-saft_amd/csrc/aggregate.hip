@@ -30,7 +30,7 @@ namespace gs {
 constexpr int kEdgeBatch = 4;  // gathers kept in flight per thread
 enum AggSource { kMsgs = 0, kFusedPQ = 1, kFusedQ = 2 };
 
-template <int MODE>
+template <int MODE, bool STREAM_OUT = false>
 __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict__ rowptr,
                                                        const int32_t *__restrict__ src,
                                                        const int32_t *__restrict__ combo,
@@ -131,10 +131,18 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict
     mx = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   float *o = agg + node * (int64_t)(8 * f) + tower * (4 * f) + col;
-  gs_st4(o, mean);
-  gs_st4(o + f, mn);
-  gs_st4(o + 2 * f, mx);
-  gs_st4(o + 3 * f, sd);
+  if constexpr (STREAM_OUT) {   // beyond the Infinity Cache: the aggregates must not evict the q rows being re-read
+    // (a template parameter: under a run-time condition the compiler merges the two arms into plain stores)
+    gs_st4_stream(o, mean);
+    gs_st4_stream(o + f, mn);
+    gs_st4_stream(o + 2 * f, mx);
+    gs_st4_stream(o + 3 * f, sd);
+  } else {
+    gs_st4(o, mean);
+    gs_st4(o + f, mn);
+    gs_st4(o + 2 * f, mx);
+    gs_st4(o + 3 * f, sd);
+  }
 }
 
 // h1pre[r, c] = pq[dst_r, c] + pq[src_r, 2F + c] + rtab[combo_r, c]: pre-activation of the first pre layer per
@@ -163,18 +171,31 @@ static int launch_aggregate(int mode, const int32_t *rowptr, const int32_t *src,
   if (num_nodes == 0) return GNNSAFT_OK;
   const int64_t threads = num_nodes * (hidden / 2);
   const dim3 grid((unsigned)gs_ceil_div(threads, 256)), block(256);
+  // streaming stores once the aggregates (N x 8F floats) exceed the 256 MiB Infinity Cache: measured C3 (1.34 GB) K4
+  // 432 -> 400 us; at C2 (84 MB) they make the update GEMM, which finds the aggregates in cache, 3 us slower
+  const int stream_out = num_nodes * (int64_t)(8 * hidden) * 4 > ((int64_t)256 << 20) ? 1 : 0;
+  const RowSplit rs = gs_row_split(hidden / 2);
   if (mode == kMsgs) {
     GS_REQUIRE(msgs != nullptr, GNNSAFT_ERR_NULL);
     hipLaunchKernelGGL((k_pna_aggregate<kMsgs>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
-                       num_nodes, hidden, gs_row_split(hidden / 2));
+                       num_nodes, hidden, rs);
   } else {
     GS_REQUIRE(src && combo && pq && rtab, GNNSAFT_ERR_NULL);
-    if (mode == kFusedPQ)
-      hipLaunchKernelGGL((k_pna_aggregate<kFusedPQ>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
-                         num_nodes, hidden, gs_row_split(hidden / 2));
-    else
-      hipLaunchKernelGGL((k_pna_aggregate<kFusedQ>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
-                         num_nodes, hidden, gs_row_split(hidden / 2));
+    if (mode == kFusedPQ) {
+      if (stream_out)
+        hipLaunchKernelGGL((k_pna_aggregate<kFusedPQ, true>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs,
+                           agg, num_nodes, hidden, rs);
+      else
+        hipLaunchKernelGGL((k_pna_aggregate<kFusedPQ>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
+                           num_nodes, hidden, rs);
+    } else {
+      if (stream_out)
+        hipLaunchKernelGGL((k_pna_aggregate<kFusedQ, true>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs,
+                           agg, num_nodes, hidden, rs);
+      else
+        hipLaunchKernelGGL((k_pna_aggregate<kFusedQ>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
+                           num_nodes, hidden, rs);
+    }
   }
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;

@@ -59,6 +59,10 @@ __device__ __forceinline__ void gs_split(const RowSplit rs, int64_t slot, int64_
 
 __device__ __forceinline__ f32x4 gs_ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void gs_st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+// streaming store (written once, read by a later kernel: should not evict what this kernel re-reads)
+__device__ __forceinline__ void gs_st4_stream(float *p, f32x4 v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
+}
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2: MI355X_MICROARCH.md, "Workgroup
 // dispatch").  Bijective renumbering that gives every XCD ONE contiguous range of the logical block ids, so that

@@ -25,7 +25,7 @@ def mean_kb(path, counter, needle):
 
 def main():
     fetch_csv, write_csv, cfg, n, ep, h = sys.argv[1:7]
-    needle = sys.argv[7] if len(sys.argv) > 7 else "k_pna_aggregate<2>"
+    needle = sys.argv[7] if len(sys.argv) > 7 else "k_pna_aggregate<2"
     n, ep, h = int(n), int(ep), int(h)
     f_kb, f_n, f_names = mean_kb(fetch_csv, "FETCH_SIZE", needle)
     w_kb, w_n, w_names = mean_kb(write_csv, "WRITE_SIZE", needle)
