@@ -206,7 +206,8 @@ def roofline_blocks(wl: Workload, times, event_overhead_ms=None):
     traffic, traffic_note, rocprof_ms = committed_k4_evidence(cfg["name"])
     ws_mb = (8 * h * n + 32 * h * n) / 1e6   # q [N,2H] gathered + agg [N,2,4H] written, f32
     roof = {
-        "kernel": f"{K4_KERNEL} (K4 segmented mean|min|max|std, messages gathered from q[src] + rtab[class])",
+        "kernel": f"{K4_KERNEL}, STREAM_OUT> (K4 segmented mean|min|max|std, messages gathered from q[src] + rtab[class]; "
+                  "streaming stores when the aggregates exceed the Infinity Cache)",
         "bound": "hbm", "achieved": k4_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k4_gbs / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_note,
         "algorithmic_bytes_per_launch": k4_bytes, "avg_launch_ms": k4_ms, "launches_timed": k4_n,
