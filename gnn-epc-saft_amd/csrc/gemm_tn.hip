@@ -1015,7 +1015,11 @@ static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, i
   // workgroups one CU holds (LDS 160 KB; the 64 x 64 kernel: four)
   const int64_t per_cu = wide ? (160 * 1024) / (2 * kTnBK * (tn_ + tk_ + 8) * 4) : 4;
   int64_t rows_per_z, chunks;
-  tn_chunking(m, tiles, 256 * (per_cu > 4 ? 4 : per_cu), rows_per_z, chunks);
+  // (few output tiles: half a resident set of longer workgroups -- tools/tn_tune.py, C2 [128,128] 27 -> 23 us,
+  //  C5 [256,64] 21 -> 15-18 us; with 16 tiles and more, or with the 60 k rows of the class sums, the full set is as
+  //  good or better)
+  const int64_t resident = 256 * (per_cu > 4 ? 4 : per_cu);
+  tn_chunking(m, tiles, !wide && tiles <= 4 && m <= 32768 ? resident / 2 : resident, rows_per_z, chunks);
   if (force_chunks > 0) {
     rows_per_z = gs_ceil_div(gs_ceil_div(m, force_chunks), kTnBK) * kTnBK;
     chunks = gs_ceil_div(m, rows_per_z);
