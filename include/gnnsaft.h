@@ -330,7 +330,9 @@ typedef struct gnnsaft_model_desc {
                                /* >= GNNSAFT_K0_SYNC_WORDS + num_nodes: gnnsaft_forward builds the batch structure by   */
                                /* cooperating workgroups of its FIRST launch (one grid barrier, fill cursors in these    */
                                /* words) beside the embedding work instead of four dependent launches.  0 (err_flag is  */
-                               /* one word): the launches.                                                              */
+                               /* one word): the launches.  Calls that share the words must be ordered (one stream, or  */
+                               /* events between streams); not for several PROCESSES sharing one GPU (their waits lose  */
+                               /* scheduling quanta: correct, but several times slower than the launches).             */
 } gnnsaft_model_desc;
 
 GNNSAFT_API int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);
