@@ -566,3 +566,29 @@ def test_an_in_degree_beyond_the_buckets_is_flagged_by_the_forward():
         out = m(data.to(DEV))
     torch.cuda.synchronize()
     assert m.input_error_flags() & 8 and out.shape[0] == 20
+
+
+@pytest.mark.parametrize("graphs,calls", [(260, 300), (1800, 60)])
+def test_the_cooperative_structure_chain_is_stable_over_many_calls(graphs, calls):
+    """The K0 chain inside the prologue launch synchronises through one grid barrier, relaxed look-back words and a
+    ticket (elementwise.hip: k0_chain_body); a race there would show as an occasional different row order or offset.
+    Back-to-back calls on one stream (the persistent words of call k are the entry state of call k + 1): every call
+    must return the bits of the first one, raise no flag and leave the persistent words zero."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    data = make_synthetic_batch(graphs, 77)
+    oracle = oracle_model(64, 2, 1, 1, 1, 3, True, True, degree_histogram(data), seed=5).train()
+    m = hip_twin(copy.deepcopy(oracle))
+    assert m.fused_structure_chain
+    dd, tgt = data.to(DEV), data.para.view(-1, 3).to(DEV)
+    with torch.no_grad():
+        first, loss0 = m.run(dd, target=tgt)
+        first, loss0 = first.clone(), loss0.clone()
+        outs = [m.run(dd, target=tgt) for _ in range(calls)]   # enqueued back to back, checked afterwards
+    torch.cuda.synchronize()
+    for k, (out, loss) in enumerate(outs):
+        assert torch.equal(out, first) and torch.equal(loss, loss0), f"call {k} differs"
+    assert m.input_error_flags() == 0 and int(m._err_flag.abs().sum()) == 0
+    m.fused_structure_chain = False
+    with torch.no_grad():
+        ref, _ = m.run(dd, target=tgt)
+    assert torch.equal(ref, first)     # and the launches build the same structure
