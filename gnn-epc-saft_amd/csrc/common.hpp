@@ -111,6 +111,7 @@ struct GemmBatchEntry {
   const float *bias;  // [n_out] or null
   float *out;         // out + column offset already applied
   int64_t a_off;      // provider-specific offset (e.g. tower offset into agg)
+  const char *w3 = nullptr;   // W3 image of the weights (w3.hpp) for the kernels of gemm_w3.hip, or null
 };
 
 constexpr int kMaxGemmBatch = 8;
@@ -178,6 +179,17 @@ int launch_pna_edge_mlp(const int32_t *src, const int32_t *dst, const int32_t *c
                         hipStream_t stream);
 
 int pna_fold_tile_rows(int hidden);
+
+// ---- split-bf16 GEMMs on pre-split weight images (gemm_w3.hip, w3.hpp); cfg from w3_pick_cfg / w3_cfg_for_update
+int launch_linear_w3(const float *a, int64_t lda, int nbatch, const GemmBatchEntry *entries /* .w3 set */, int n_pad,
+                     int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi, hipStream_t stream, int cfg);
+// wave-specialised form (gemm_w3s.hip): cfg 0 = 128 x 128, 1 = 64 x 128
+int launch_linear_w3s(const float *a, int64_t lda, int nbatch, const GemmBatchEntry *entries /* .w3 set */, int n_pad,
+                      int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi, hipStream_t stream, int cfg);
+int w3_cfg_for_update(int hidden);   // -1: the folded update stays on k_gemm_f32
+int launch_pna_update_folded_w3(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
+                                const int32_t *num_tiles, int64_t max_tiles, int64_t n, int hidden, const char *w_eff3,
+                                const float *b_post0, const float *b_post1, float *u, hipStream_t stream);
 
 int launch_pna_update_folded(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
                              const int32_t *num_tiles, int64_t max_tiles, int64_t n, int hidden, const float *w_eff,
@@ -334,7 +346,8 @@ __device__ __forceinline__ void block_degree_hist(int d, bool live, int32_t *__r
 
 // The K0 chain run by cooperating workgroups of the prologue launch (elementwise.hip: k0_chain_body)
 constexpr int kK0MaxWgs = 128;        // co-resident by construction: the first workgroups of the launch
-constexpr int kK0SyncInts = 2;        // one grid barrier + one ticket (<= GNNSAFT_K0_SYNC_WORDS)
+constexpr int kK0SyncInts = 3;        // grid barrier, ticket, "this call lost a barrier" (<= GNNSAFT_K0_SYNC_WORDS)
+constexpr int kK0LostWord = 2;        // index of the third among the sync words
 constexpr int kK0Group = 256;         // nodes per group of the chain (rows, look-back scan, degree histogram)
 struct BondDims {                     // vocabulary sizes of the bond attribute columns (edge class = mixed radix)
   int32_t n;
@@ -352,7 +365,8 @@ struct K0ChainArgs {
   unsigned long long *lookback = nullptr;   // [groups] (status << 32 | rows): decoupled look-back of the row offsets
   int32_t *group_hist = nullptr;      // [groups][kDegreeBuckets]; the plan turns it into prefixes in place
   int32_t *hist = nullptr, *start = nullptr, *tiles = nullptr, *num_tiles = nullptr;
-  int32_t *sync = nullptr;            // PERSISTENT: kK0SyncInts ints, zero at entry, zero again at exit
+  int32_t *sync = nullptr;            // PERSISTENT: kK0SyncInts ints, zero at entry; barrier and ticket zero again at exit of
+                                      // the launch, the lost word at the end of the forward (the pooling launch)
   int32_t *cursor = nullptr;          // PERSISTENT: n fill cursors, zero at entry, zero again at exit
   int32_t *err = nullptr;
 };
@@ -368,9 +382,15 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
                             int32_t *err_flag, hipStream_t st, int32_t *zero2_ptr = nullptr, int zero2_count = 0,
                             const struct EdgeTableLayers *tables = nullptr /* fold.hpp */, int32_t table_layers = 0,
                             float *cenc = nullptr, float *rtab = nullptr, const K0ChainArgs *k0 = nullptr);
+// `clear_word` (both pooling launchers; or null): a word this launch leaves zero -- the structure chain's "lost" word,
+// read by the launches in front of the pooling, zero again for the next call
 int launch_add_pool_bn(const float *y, const float *xprev, const float *scale, const float *shift, float *xout,
                        const int32_t *graph_ptr, int64_t num_graphs, int64_t num_nodes, int hidden, float *out,
-                       hipStream_t st);
+                       hipStream_t st, int32_t *clear_word = nullptr);
+int launch_add_pool(const float *x, const int32_t *graph_ptr, int64_t num_graphs, int64_t num_nodes, int hidden,
+                    float *out, hipStream_t st, int32_t *clear_word = nullptr);
+// out[0 .. count) and loss3[0 .. 3) become NaN when *lost != 0 (the per-op readout after a lost structure barrier)
+int launch_poison_if(const int32_t *lost, float *out, int64_t count, float *loss3, hipStream_t st);
 void csr_zero_region(void *workspace, int64_t num_nodes, int32_t **ptr, int64_t *count);
 int launch_csr_build(const int64_t *edge_index, const int64_t *edge_attr, int64_t num_nodes, int64_t num_edges,
                      int32_t num_bond_cols, const int32_t *bond_dims_host, int32_t self_loops, int32_t *rowptr,
@@ -386,12 +406,15 @@ struct DegreeFoldRequest {
   const double *g_all;  // destination-term products (k_dst_fold, float64) or null
   float *w_eff;
   int64_t layer_stride;
+  char *w_eff3 = nullptr;   // also as W3 images (w3.hpp; 6 bytes per weight, block order of w_eff), or null
 };
 // the arrays the cooperative K0 chain wrote (for the empty structure installed after a lost barrier: degree.hip)
 struct K0Installed {
   int32_t *rowptr, *src, *dst, *combo;
   int64_t ep;
   float *log_amp, *log_att;
+  int32_t *sync, *cursor;   // the chain's persistent words: restored to zero by the launch that installs the empty structure
+  int32_t *lost_out;        // workspace word written by EVERY call: 1 = this call's structure chain lost a barrier
 };
 int launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hidden, int32_t *perm, int32_t *tiles,
                         int32_t *num_tiles, int32_t *scratch, int32_t *err_flag, bool have_block_hist, hipStream_t st,
@@ -402,6 +425,6 @@ int launch_fold_post_weights(int32_t num_layers, const float *const *w_post0_hos
                              const float *const *avg_deg_log_host, const float *const *w_pre0_host,
                              const float *const *w_pre1_host, double *g_scratch, const int32_t *hist, int32_t hidden,
                              float *w_eff, int64_t layer_stride, int phases /* 1: dst fold, 2: degree fold */,
-                             hipStream_t st);
+                             hipStream_t st, char *w_eff3 = nullptr /* W3 images of w_eff (w3.hpp) */);
 
 }  // namespace gs

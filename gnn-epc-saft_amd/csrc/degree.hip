@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "fold.hpp"
 #include "k0_chain.hpp"
+#include "w3.hpp"
 
 namespace gs {
 
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(256) void k_dst_fold(FoldLayers fl, int f, double *
 __device__ __forceinline__ void fold_post_weights_body(const FoldLayers &fl, const int32_t *__restrict__ hist, int f,
                                                        float *__restrict__ w_eff_all, int64_t layer_stride,
                                                        const double *__restrict__ g_all, int64_t slot, int t, int dz,
-                                                       bool only_degree0 = false) {
+                                                       bool only_degree0 = false,
+                                                       char *__restrict__ w_eff3_all = nullptr) {
   const int d = dz % kDegreeBuckets;
   const int layer = dz / kDegreeBuckets;
   if (only_degree0 ? d != 0 : hist[d] == 0) return;  // degree absent from this batch
@@ -101,13 +103,18 @@ __device__ __forceinline__ void fold_post_weights_body(const FoldLayers &fl, con
     for (int j = 0; j < 4; ++j) v[j] = (float)((double)w_id[j] + (double)w_amp[j] * amp + (double)w_att[j] * att);
   }
   gs_st4(w_eff + (((int64_t)d * 2 + t) * (f / 2) + o) * (int64_t)(5 * f) + c, v);
+  // the same folded weight as bf16 planes for the GEMM that copies its B tiles straight into LDS (w3.hpp): one image of
+  // [F/2, 5F] per (layer, degree, tower), in the block order of w_eff
+  if (w_eff3_all != nullptr)
+    w3_store4(w_eff3_all + (layer * layer_stride + ((int64_t)d * 2 + t) * (f / 2) * (int64_t)(5 * f)) * 6, f / 2, o, c, v);
 }
 
 __global__ __launch_bounds__(256) void k_fold_post_weights(FoldLayers fl, const int32_t *__restrict__ hist, int f,
                                                            float *__restrict__ w_eff_all, int64_t layer_stride,
-                                                           const double *__restrict__ g_all) {
+                                                           const double *__restrict__ g_all,
+                                                           char *__restrict__ w_eff3_all) {
   fold_post_weights_body(fl, hist, f, w_eff_all, layer_stride, g_all, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
-                         blockIdx.y, blockIdx.z);
+                         blockIdx.y, blockIdx.z, false, w_eff3_all);
 }
 
 // pass 3 of the degree bucketing and the weight fold both need only the plan (bucket starts / histogram): one
@@ -121,13 +128,18 @@ struct FoldJob {
   const double *g_all;
   int x_blocks;      // kDegBlock-thread workgroups per [F/2, 5F] block
   int num_layers;
+  char *w_eff3_all;  // W3 images of the folded weights (6 bytes per weight, same block order), or null
 };
 
-// What the fill launch installs when the cooperative K0 chain of the prologue launch lost a grid barrier (the flag
-// word says so): an EMPTY structure -- no rows, every node of in-degree 0, identity permutation -- so that nothing
-// downstream indexes with half-built tables.  The outputs are garbage by then and say so (flag; the readout poisons).
+// What the fill launch installs when the cooperative K0 chain of the prologue launch lost a grid barrier (the chain's
+// "lost" word of THIS call says so; the sticky flag word tells the host): an EMPTY structure -- no rows, every node of
+// in-degree 0, identity permutation -- so that nothing downstream indexes with half-built tables; the chain's
+// persistent words (fill cursors, barrier, ticket) are restored to zero here, so the next call starts clean without
+// the host's help; `lost_out` tells the end of the forward to write NaN (the outputs are garbage).
 struct K0Sanitize {
   const int32_t *err = nullptr;   // null: never
+  int32_t *sync = nullptr, *cursor = nullptr;   // persistent words of the chain (sync[kK0LostWord]: this call lost)
+  int32_t *lost_out = nullptr;
   int32_t *rowptr = nullptr, *src = nullptr, *dst = nullptr, *combo = nullptr;
   int64_t ep = 0;
   float *log_amp = nullptr, *log_att = nullptr;
@@ -139,6 +151,7 @@ __device__ __forceinline__ void k0_install_empty(const K0Sanitize &z, int64_t n,
                                                  unsigned fill_blocks) {
   const int64_t i = (int64_t)blockIdx.x * kDegBlock + threadIdx.x;
   if (i < n) {
+    z.cursor[i] = 0;     // (the chain's phase that resets them did not run)
     z.rowptr[i] = 0;
     perm[i] = (int32_t)i;
     z.log_amp[i] = degree_log_amp(0);
@@ -149,6 +162,8 @@ __device__ __forceinline__ void k0_install_empty(const K0Sanitize &z, int64_t n,
   if (threadIdx.x == 0) {
     z.rowptr[n] = 0;
     z.num_tiles[0] = (int32_t)((n + z.tile_rows - 1) / z.tile_rows);
+    z.sync[0] = 0;       // barrier and ticket (workgroups that gave up at different times may have left them anywhere);
+    z.sync[1] = 0;       // the lost word itself is still being read by this launch: the pooling launch zeroes it
   }
   if (threadIdx.x < kDegreeBuckets) {
     z.hist[threadIdx.x] = threadIdx.x == 0 ? (int32_t)n : 0;
@@ -169,8 +184,9 @@ __global__ __launch_bounds__(kDegBlock) void k_degree_fill_and_fold(const int32_
                                                                     const int32_t *__restrict__ start,
                                                                     int32_t *__restrict__ perm, unsigned fill_blocks,
                                                                     FoldJob job, K0Sanitize z) {
-  const bool lost = z.err != nullptr && (__hip_atomic_load(z.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
-                                         GNNSAFT_FLAG_BARRIER_TIMEOUT) != 0;   // grid-uniform
+  const bool lost = z.err != nullptr && __hip_atomic_load(z.sync + kK0LostWord, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT) != 0;   // grid-uniform, THIS call
+  if (blockIdx.x == 0 && threadIdx.x == 0 && z.lost_out != nullptr) z.lost_out[0] = lost ? 1 : 0;
   if (blockIdx.x < fill_blocks) {  // block-uniform
     if (lost)
       k0_install_empty(z, n, perm, fill_blocks);
@@ -181,7 +197,7 @@ __global__ __launch_bounds__(kDegBlock) void k_degree_fill_and_fold(const int32_
   const unsigned b = blockIdx.x - fill_blocks;
   const int xb = b % job.x_blocks, rest = b / job.x_blocks;
   fold_post_weights_body(job.fl, job.hist, job.f, job.w_eff_all, job.layer_stride, job.g_all,
-                         (int64_t)xb * kDegBlock + threadIdx.x, rest & 1, rest >> 1, lost);
+                         (int64_t)xb * kDegBlock + threadIdx.x, rest & 1, rest >> 1, lost, job.w_eff3_all);
 }
 
 }  // namespace gs
@@ -239,6 +255,7 @@ int gs::launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hi
     const int64_t threads = (int64_t)(hidden / 2) * (5 * hidden / 4);
     job.x_blocks = (int)gs_ceil_div(threads, (int64_t)gs::kDegBlock);
     job.num_layers = fold->num_layers;
+    job.w_eff3_all = fold->w_eff3;
     const int64_t fold_blocks = (int64_t)job.x_blocks * 2 * gs::kDegreeBuckets * fold->num_layers;
     gs::K0Sanitize z;
     if (installed != nullptr) {
@@ -250,6 +267,10 @@ int gs::launch_degree_tiles(const int32_t *rowptr, int64_t num_nodes, int32_t hi
       z.ep = installed->ep;
       z.log_amp = installed->log_amp;
       z.log_att = installed->log_att;
+      z.sync = installed->sync;
+      z.cursor = installed->cursor;
+      z.lost_out = installed->lost_out;
+      GS_REQUIRE(z.sync != nullptr && z.cursor != nullptr, GNNSAFT_ERR_NULL);
       z.hist = hist;
       z.start = start;
       z.tiles = tiles;
@@ -279,14 +300,14 @@ extern "C" int gnnsaft_pna_fold_post_weights_multi(int32_t num_layers, const flo
   GS_REQUIRE((reinterpret_cast<uintptr_t>(g_scratch) & 7) == 0, GNNSAFT_ERR_SHAPE);
   return gs::launch_fold_post_weights(num_layers, w_post0_host, w_post1_host, avg_deg_log_host, w_pre0_host,
                                       w_pre1_host, static_cast<double *>(g_scratch), hist, hidden, w_eff, layer_stride, 3,
-                                      static_cast<hipStream_t>(stream));
+                                      static_cast<hipStream_t>(stream), nullptr);
 }
 
 int gs::launch_fold_post_weights(int32_t num_layers, const float *const *w_post0_host,
                                  const float *const *w_post1_host, const float *const *avg_deg_log_host,
                                  const float *const *w_pre0_host, const float *const *w_pre1_host, double *g_scratch,
                                  const int32_t *hist, int32_t hidden, float *w_eff, int64_t layer_stride, int phases,
-                                 hipStream_t st) {
+                                 hipStream_t st, char *w_eff3) {
   GS_REQUIRE(w_post0_host && w_post1_host && avg_deg_log_host && hist && w_eff, GNNSAFT_ERR_NULL);
   GS_REQUIRE(hidden >= 32 && (hidden % 32) == 0, GNNSAFT_ERR_SHAPE);
   GS_REQUIRE(num_layers >= 1 && num_layers <= GNNSAFT_MAX_FOLD_LAYERS, GNNSAFT_ERR_SHAPE);
@@ -311,8 +332,9 @@ int gs::launch_fold_post_weights(int32_t num_layers, const float *const *w_post0
   if (phases & 2) {
     const int64_t threads = (int64_t)(hidden / 2) * (5 * hidden / 4);
     const dim3 grid((unsigned)gs_ceil_div(threads, 256), 2, (unsigned)(gs::kDegreeBuckets * num_layers));
+    GS_REQUIRE(w_eff3 == nullptr || (hidden % 64) == 0, GNNSAFT_ERR_SHAPE);
     hipLaunchKernelGGL(gs::k_fold_post_weights, grid, dim3(256), 0, st, fl, hist, hidden, w_eff, layer_stride,
-                       fold_dst ? g_scratch : nullptr);
+                       fold_dst ? g_scratch : nullptr, w_eff3);
   }
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;

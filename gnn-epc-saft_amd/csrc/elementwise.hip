@@ -177,9 +177,19 @@ __device__ __forceinline__ void edge_table_body(const PrologueArgs &a, unsigned 
 // barrier here against 1-1.5 us in the readout), hence ONE barrier: the fill cursors live in caller memory that is zero
 // between calls (gnnsaft_model_desc.persistent_sync_words; every cursor is reset by the thread that reads it), the
 // look-back words are relaxed agent-scope atomics (no fence needed: they carry their own data), the histogram is
-// per group and not atomic.  A lost barrier / a look-back that never resolves raises GNNSAFT_FLAG_BARRIER_TIMEOUT; the
-// degree-fill launch that follows then installs an empty structure (degree.hip), and the readout poisons the outputs.
-__device__ __forceinline__ bool k0_barrier(int32_t *counter, int expected, int32_t *err) {
+// per group and not atomic.  A lost barrier / a look-back that never resolves raises GNNSAFT_FLAG_BARRIER_TIMEOUT (sticky,
+// for the host) AND sets the chain's "lost" word for THIS call: every workgroup that sees it skips the rest of the chain,
+// the degree-fill launch that follows installs an empty structure and restores the persistent words to zero itself
+// (degree.hip), and the end of the forward writes NaN to the outputs in every mode -- a caller that never reads the
+// flag word gets NaN for that call and a correct forward on the next one.
+__device__ __forceinline__ bool k0_lost(const int32_t *lost) {
+  return __hip_atomic_load(lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+__device__ __forceinline__ void k0_give_up(int32_t *lost, int32_t *err) {
+  if (err) atomicOr(err, GNNSAFT_FLAG_BARRIER_TIMEOUT);
+  __hip_atomic_store(lost, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool k0_barrier(int32_t *counter, int expected, int32_t *err, int32_t *lost) {
   __shared__ int s_k0_ok;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -190,13 +200,17 @@ __device__ __forceinline__ bool k0_barrier(int32_t *counter, int expected, int32
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > (1L << 22)) {
-        if (err) atomicOr(err, GNNSAFT_FLAG_BARRIER_TIMEOUT);
+        k0_give_up(lost, err);
+        ok = 0;
+        break;
+      }
+      if ((spins & 1023) == 0 && k0_lost(lost)) {   // somebody else gave up: do not wait out the whole bound too
         ok = 0;
         break;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    s_k0_ok = ok;
+    s_k0_ok = ok && !k0_lost(lost);
   }
   __syncthreads();
   return s_k0_ok != 0;
@@ -205,7 +219,7 @@ __device__ __forceinline__ bool k0_barrier(int32_t *counter, int expected, int32
 constexpr unsigned long long kLbAggregate = 1ull << 32, kLbInclusive = 2ull << 32;
 
 // exclusive prefix of group gi (> 0) from the look-back words of its predecessors; called by wave 0, all 64 lanes
-__device__ __forceinline__ long long k0_look_back(unsigned long long *lb, int64_t gi, int32_t *err) {
+__device__ __forceinline__ long long k0_look_back(unsigned long long *lb, int64_t gi, int32_t *err, int32_t *lost) {
   const int lane = threadIdx.x & 63;
   long long prefix = 0;
   int64_t j = gi - 1;
@@ -218,8 +232,8 @@ __device__ __forceinline__ long long k0_look_back(unsigned long long *lb, int64_
         v = __hip_atomic_load(lb + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((v >> 32) != 0ull) break;
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1L << 22)) {
-          if (err) atomicOr(err, GNNSAFT_FLAG_BARRIER_TIMEOUT);
+        if (++spins > (1L << 22)) k0_give_up(lost, err);
+        if ((spins & 1023) == 0 && k0_lost(lost)) {   // (a predecessor that skipped the chain never publishes)
           v = kLbInclusive;
           break;
         }
@@ -256,9 +270,11 @@ __device__ __forceinline__ void k0_chain_body(const K0ChainArgs &k, int w) {
       k.graph_ptr[1] = (int32_t)n;
     }
   }
-  k0_barrier(k.sync + 0, W + k.barrier_extra, k.err);
-  // phase 2: groups of 256 nodes, ascending per workgroup (a group only ever waits for groups in front of it)
-  for (int64_t gi = w; gi < groups; gi += W) {
+  int32_t *lost = k.sync + kK0LostWord;
+  const bool met = k0_barrier(k.sync + 0, W + k.barrier_extra, k.err, lost);
+  // phase 2: groups of 256 nodes, ascending per workgroup (a group only ever waits for groups in front of it).  Not
+  // after a lost barrier: the slot rows and cursors are incomplete, the next launch installs an empty structure
+  for (int64_t gi = w; met && gi < groups; gi += W) {
     const int64_t i = gi * kK0Group + tid;
     const bool live = i < n;
     int cnt = 0;
@@ -278,7 +294,7 @@ __device__ __forceinline__ void k0_chain_body(const K0ChainArgs &k, int w) {
       if (gi > 0) {
         if (tid == 0)
           __hip_atomic_store(k.lookback + gi, kLbAggregate | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        prefix = k0_look_back(k.lookback, gi, k.err);
+        prefix = k0_look_back(k.lookback, gi, k.err, lost);
       }
       if (tid == 0) {
         __hip_atomic_store(k.lookback + gi, kLbInclusive | (unsigned long long)(unsigned)(prefix + total),
@@ -317,8 +333,8 @@ __device__ __forceinline__ void k0_chain_body(const K0ChainArgs &k, int w) {
   }
   __syncthreads();
   if (s_last != 0) {   // (workgroup-uniform)
-    degree_plan_body(k.group_hist, groups, k.tile_rows, k.hist, k.start, k.tiles, k.num_tiles, s_plan);
-    if (tid == 0) {
+    if (!k0_lost(lost)) degree_plan_body(k.group_hist, groups, k.tile_rows, k.hist, k.start, k.tiles, k.num_tiles, s_plan);
+    if (tid == 0) {   // (the lost word stays for the launches behind this one; the pooling launch zeroes it)
       __hip_atomic_store(k.sync + 0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(k.sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -443,8 +459,9 @@ __global__ __launch_bounds__(256) void k_bn_relu_residual(const float *__restric
 // out[g, :] = sum over rows ptr[g] .. ptr[g+1]-1, sequential (graph-contiguous rows)
 __global__ __launch_bounds__(256) void k_add_pool(const float *__restrict__ x, const int32_t *__restrict__ ptr,
                                                   int64_t graphs, int64_t nodes, int h, float *__restrict__ out,
-                                                  RowSplit rs) {
+                                                  RowSplit rs, int32_t *clear_word) {
   const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot == 0 && clear_word != nullptr) __hip_atomic_store(clear_word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int64_t g;
   int lane_in_row;
   gs_split(rs, slot, g, lane_in_row);
@@ -475,8 +492,9 @@ __global__ __launch_bounds__(256) void k_add_pool_bn(const float *__restrict__ y
                                                      const float *__restrict__ scale, const float *__restrict__ shift,
                                                      float *__restrict__ xout, const int32_t *__restrict__ ptr,
                                                      int64_t graphs, int64_t nodes, int h, float *__restrict__ out,
-                                                     RowSplit rs) {
+                                                     RowSplit rs, int32_t *clear_word) {
   const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot == 0 && clear_word != nullptr) __hip_atomic_store(clear_word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int64_t g;
   int lane_in_row;
   gs_split(rs, slot, g, lane_in_row);
@@ -634,13 +652,41 @@ int launch_forward_prologue(const int64_t *x_idx, int64_t num_rows, int32_t num_
 
 int launch_add_pool_bn(const float *y, const float *xprev, const float *scale, const float *shift, float *xout,
                        const int32_t *graph_ptr, int64_t num_graphs, int64_t num_nodes, int hidden, float *out,
-                       hipStream_t st) {
+                       hipStream_t st, int32_t *clear_word) {
   GS_REQUIRE(y && scale && shift && graph_ptr && out, GNNSAFT_ERR_NULL);
   GS_REQUIRE(hidden >= 4 && (hidden % 4) == 0 && num_graphs >= 0, GNNSAFT_ERR_SHAPE);
   if (num_graphs == 0) return GNNSAFT_OK;
   const int64_t threads = num_graphs * (hidden / 4);
   hipLaunchKernelGGL(k_add_pool_bn, dim3((unsigned)gs_ceil_div(threads, 256)), dim3(256), 0, st, y, xprev, scale, shift,
-                     xout, graph_ptr, num_graphs, num_nodes, hidden, out, gs_row_split(hidden / 4));
+                     xout, graph_ptr, num_graphs, num_nodes, hidden, out, gs_row_split(hidden / 4), clear_word);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+int launch_add_pool(const float *x, const int32_t *graph_ptr, int64_t num_graphs, int64_t num_nodes, int hidden,
+                    float *out, hipStream_t st, int32_t *clear_word) {
+  GS_REQUIRE(graph_ptr && out && (x != nullptr || num_nodes == 0), GNNSAFT_ERR_NULL);
+  GS_REQUIRE(hidden >= 4 && (hidden % 4) == 0 && num_graphs >= 0, GNNSAFT_ERR_SHAPE);
+  if (num_graphs == 0) return GNNSAFT_OK;
+  const int64_t threads = num_graphs * (hidden / 4);
+  hipLaunchKernelGGL(k_add_pool, dim3((unsigned)gs_ceil_div(threads, 256)), dim3(256), 0, st, x, graph_ptr, num_graphs,
+                     num_nodes, hidden, out, gs_row_split(hidden / 4), clear_word);
+  GS_CHECK_LAUNCH();
+  return GNNSAFT_OK;
+}
+
+__global__ __launch_bounds__(256) void k_poison_if(const int32_t *__restrict__ lost, float *__restrict__ out,
+                                                   int64_t count, float *__restrict__ loss3) {
+  if (lost[0] == 0) return;
+  const float nanv = __builtin_nanf("");
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) out[i] = nanv;
+  if (loss3 != nullptr && blockIdx.x == 0 && threadIdx.x < 3) loss3[threadIdx.x] = nanv;
+}
+
+int launch_poison_if(const int32_t *lost, float *out, int64_t count, float *loss3, hipStream_t st) {
+  GS_REQUIRE(lost != nullptr && out != nullptr && count >= 0, GNNSAFT_ERR_NULL);
+  const int64_t blocks = gs_ceil_div(count > 0 ? count : 1, 256);
+  hipLaunchKernelGGL(k_poison_if, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, st, lost, out, count, loss3);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }
@@ -724,15 +770,7 @@ extern "C" int gnnsaft_bn_relu_residual(const float *y, const float *scale, cons
 
 extern "C" int gnnsaft_add_pool(const float *x, const int32_t *graph_ptr, int64_t num_graphs, int64_t num_nodes,
                                 int32_t hidden, float *out, gnnsaft_stream_t stream) {
-  GS_REQUIRE(graph_ptr && out && (x != nullptr || num_nodes == 0), GNNSAFT_ERR_NULL);
-  GS_REQUIRE(hidden >= 4 && (hidden % 4) == 0 && num_graphs >= 0, GNNSAFT_ERR_SHAPE);
-  if (num_graphs == 0) return GNNSAFT_OK;
-  const int64_t threads = num_graphs * (hidden / 4);
-  hipLaunchKernelGGL(gs::k_add_pool, dim3((unsigned)gs_ceil_div(threads, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, graph_ptr, num_graphs, num_nodes, hidden, out,
-                     gs_row_split(hidden / 4));
-  GS_CHECK_LAUNCH();
-  return GNNSAFT_OK;
+  return gs::launch_add_pool(x, graph_ptr, num_graphs, num_nodes, hidden, out, static_cast<hipStream_t>(stream), nullptr);
 }
 
 extern "C" int gnnsaft_mape(const float *pred, const float *target, int64_t numel, float *out3,

@@ -21,6 +21,7 @@
 #include "fold.hpp"
 #include "plan.hpp"
 #include "readout.hpp"
+#include "w3.hpp"
 
 // Event pairs recorded on the launch stream around selected launches (bench.py roofline).
 struct gnnsaft_profile {
@@ -84,9 +85,16 @@ struct ProfScope {
 static int linear_bn_relu(const float *a, int64_t lda, const float *w, const float *b, int64_t rows, int n_out, int k,
                           const BnPtrs &bn, const gnnsaft_model_desc *d, char *ws, const Plan &p, float *y_tmp,
                           const float *residual, float *out, hipStream_t st, gnnsaft_profile *prof = nullptr,
-                          float *save_stat = nullptr, bool defer_apply = false) {
+                          float *save_stat = nullptr, bool defer_apply = false,
+                          const char *w3 = nullptr /* W3 image of w (w3.hpp): the GEMM reads it instead of w */) {
   float *stats = reinterpret_cast<float *>(ws + p.stats);
-  GemmBatchEntry ent{w, b, nullptr, 0};
+  GemmBatchEntry ent{w, b, nullptr, 0, w3};
+  const int w3cfg = w3 != nullptr ? w3_pick_cfg(rows, n_out, k, d->training != 0) : -1;
+  auto launch_linear = [&](const float *a_, int64_t lda_, int relu_in, int nbatch, const GemmBatchEntry *e, int64_t ldw,
+                           int64_t ldo, int64_t m, int n_out_, int k_, const LinearEpilogue &epi, hipStream_t s_) -> int {
+    if (w3cfg >= 0 && relu_in == 0) return launch_linear_w3(a_, lda_, nbatch, e, n_out_, ldo, m, n_out_, k_, epi, s_, w3cfg);
+    return gs::launch_linear(a_, lda_, relu_in, nbatch, e, ldw, ldo, m, n_out_, k_, epi, s_);
+  };
   if (d->training && defer_apply) {
     GS_REQUIRE(rows >= 2, GNNSAFT_ERR_SHAPE);
     ent.out = y_tmp;
@@ -161,7 +169,13 @@ static int node_terms(const NodeState &ns, int64_t n, int h, const float *w0, co
 }
 
 static int src_terms(const NodeState &ns, int64_t n, int h, const float *w0, const float *w1, float *q,
-                     hipStream_t st) {
+                     hipStream_t st, const char *w3 = nullptr /* image of [W0_src ; W1_src] = [2H, H] */) {
+  const int w3cfg = w3 != nullptr && ns.y == nullptr ? w3_pick_cfg(n, 2 * h, h, false) : -1;
+  if (w3cfg >= 0) {   // both towers as ONE GEMM over the stacked image: A is split once per 256 output columns
+    GemmBatchEntry e1{nullptr, nullptr, q, 0, w3};
+    LinearEpilogue epi;
+    return launch_linear_w3(ns.x, h, 1, &e1, 2 * h, 2 * (int64_t)h, n, 2 * h, h, epi, st, w3cfg);
+  }
   GemmBatchEntry e[2] = {{w0 + h, nullptr, q, 0}, {w1 + h, nullptr, q + h, 0}};
   if (ns.y != nullptr)
     return launch_linear_bnres(ns.y, ns.xres, ns.scale, ns.shift, ns.xdst, 2, e, 3 * (int64_t)h, 2 * (int64_t)h, n, h, h,
@@ -575,6 +589,23 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
                                    I(p.rd_sync), kRdSyncInts + kBnTailCounterInts, &et, tables_in_prologue ? d->num_layers : 0, F(p.cenc),
                                    F(p.rtab), k0_fused ? &k0 : nullptr));
   }
+  // ---- W3 images (w3.hpp) of the weights the big GEMMs read: the source block of pre_nns[t][0] of both towers
+  //      stacked [2H, H] and lin [H, H], every layer, one launch; the folded update weights get theirs from the fold
+  const bool w3_src = p.w3src_stride != 0 && fold_dst && w3_pick_cfg(n, 2 * h, h, false) >= 0;
+  const bool w3_lin = p.w3lin_stride != 0 && w3_pick_cfg(n, h, h, d->training != 0) >= 0;
+  const bool w3_upd = p.w3eff_stride != 0 && d->fold_degree_scalers && w3_cfg_for_update(h) >= 0;
+  if (w3_src || w3_lin) {
+    std::vector<W3PackItem> items;
+    for (int l = 0; l < d->num_layers; ++l) {
+      char *is = ws + p.w3src + (size_t)l * p.w3src_stride, *il = ws + p.w3lin + (size_t)l * p.w3lin_stride;
+      if (w3_src) {
+        items.push_back(W3PackItem{lw[l].wpre[0][0] + h, is, 3 * (int64_t)h, h, h, 2 * h, 0});
+        items.push_back(W3PackItem{lw[l].wpre[1][0] + h, is, 3 * (int64_t)h, h, h, 2 * h, h});
+      }
+      if (w3_lin) items.push_back(W3PackItem{lw[l].wlin, il, h, h, h, h, 0});
+    }
+    GS_TRY(launch_w3_pack((int)items.size(), items.data(), st));
+  }
   hipStream_t sa = st;
   if (aux != nullptr) {
     sa = aux->stream;
@@ -595,7 +626,8 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
       }
       GS_TRY(launch_fold_post_weights(nl, w0, w1, av, fold_dst ? p0 : nullptr, fold_dst ? p1 : nullptr,
                                       fold_dst ? D(p.gfold) + (int64_t)l0 * 6 * (h / 2) * h : nullptr, I(p.hist3), h,
-                                      F(p.weff) + l0 * wstride, wstride, phases, sa));
+                                      F(p.weff) + l0 * wstride, wstride, phases, sa,
+                                      w3_upd ? ws + p.w3eff + (size_t)l0 * p.w3eff_stride : nullptr));
     }
     return GNNSAFT_OK;
   };
@@ -623,8 +655,11 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
         w1[i] = lw[i].wpost[1][0];
         av[i] = lw[i].avg;
       }
-      const DegreeFoldRequest req{d->num_layers, w0, w1, av, fold_dst ? D(p.gfold) : nullptr, F(p.weff), wstride};
-      const K0Installed inst{I(p.rowptr), I(p.src), I(p.dst), I(p.combo), p.ep, F(p.log_amp), F(p.log_att)};
+      const DegreeFoldRequest req{d->num_layers, w0, w1, av, fold_dst ? D(p.gfold) : nullptr, F(p.weff), wstride,
+                                  w3_upd ? ws + p.w3eff : nullptr};
+      const K0Installed inst{I(p.rowptr), I(p.src), I(p.dst), I(p.combo), p.ep, F(p.log_amp), F(p.log_att),
+                             k0_fused ? err_flag + 1 : nullptr, k0_fused ? err_flag + 1 + GNNSAFT_K0_SYNC_WORDS : nullptr,
+                             I(p.k0_lost)};
       GS_TRY(launch_degree_tiles(I(p.rowptr), n, h, I(p.perm), I(p.tiles), I(p.num_tiles), I(p.hist3), err_flag,
                                  true, sa, &req, k0_fused ? &inst : nullptr));
     } else {
@@ -691,7 +726,8 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     {
       ProfScope ps(prof, GNNSAFT_PROF_NODE_TERMS, st);
       if (fold_dst)
-        GS_TRY(src_terms(state, n, h, wpre[0][0], wpre[1][0], pq_l, st));
+        GS_TRY(src_terms(state, n, h, wpre[0][0], wpre[1][0], pq_l, st,
+                         w3_src ? ws + p.w3src + (size_t)l * p.w3src_stride : nullptr));
       else
         GS_TRY(node_terms(state, n, h, wpre[0][0], wpre[1][0], pq_l, st));
       state = NodeState{};   // x_l (= xc) is in memory now
@@ -735,7 +771,11 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     }
     // update: first post-layer with scalers on load, then extra post-layers
     float *ua = u_l, *ub = F(p.u1);
-    if (d->fold_degree_scalers) {
+    if (d->fold_degree_scalers && w3_upd) {
+      ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
+      GS_TRY(launch_pna_update_folded_w3(xc, agg_l, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap, n, h,
+                                         ws + p.w3eff + (size_t)l * p.w3eff_stride, bpost[0][0], bpost[1][0], ua, st));
+    } else if (d->fold_degree_scalers) {
       ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
       GS_TRY(launch_pna_update_folded(xc, agg_l, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap, n, h, weff,
                                       bpost[0][0], bpost[1][0], ua, st));
@@ -756,7 +796,8 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     // lin -> BatchNorm -> ReLU -> (+ x)
     const bool bn_deferred = bn_all || (bn_last && l == d->num_layers - 1);
     GS_TRY(linear_bn_relu(ua, h, wlin, blin, n, h, h, bn, d, ws, p, y_l, d->skip_connections ? xc : nullptr, xn, st,
-                          prof, F(p.bnstat) + (int64_t)l * 2 * h, bn_deferred));
+                          prof, F(p.bnstat) + (int64_t)l * 2 * h, bn_deferred,
+                          w3_lin ? ws + p.w3lin + (size_t)l * p.w3lin_stride : nullptr));
     if (bn_deferred) {   // x_{l+1} = relu(y_l scale + shift) (+ x_l): formed by whoever reads it next
       state = NodeState{};
       state.y = y_l;
@@ -777,11 +818,15 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
 
   // global_add_pool of the final node state; a pending BatchNorm of the last layer is applied on load (the tape
   // keeps x_L: the tests read the ReLU gates off it)
+  // (the pooling launch also leaves the structure chain's "lost" word zero for the next call: every launch that reads
+  // it -- the permutation fill -- is in front of this one, and I(p.k0_lost) carries its value to the end of the call)
+  int32_t *k0_clear = k0_fused ? err_flag + 1 + kK0LostWord : nullptr;
+  const int32_t *k0_lost = k0_fused ? I(p.k0_lost) : nullptr;
   auto pool = [&](hipStream_t s_) -> int {
     if (state.y != nullptr)
       return launch_add_pool_bn(state.y, state.xres, state.scale, state.shift, tape ? state.xdst : nullptr,
-                                I(p.graph_ptr), g, n, h, F(p.pooled), s_);
-    return gnnsaft_add_pool(xc, I(p.graph_ptr), g, n, h, F(p.pooled), s_);
+                                I(p.graph_ptr), g, n, h, F(p.pooled), s_, k0_clear);
+    return launch_add_pool(xc, I(p.graph_ptr), g, n, h, F(p.pooled), s_, k0_clear);
   };
   // ---- readout: one launch (readout.hip) while its workgroups are co-resident, the per-op path beyond
   // (an eval-mode tape keeps the readout's pre-activations through the per-op path)
@@ -814,6 +859,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     rp.scratch = ws + p.rd_scratch;
     rp.sync = I(p.rd_sync);
     rp.err = err_flag;
+    rp.k0_lost = k0_lost;
     rp.barrier_extra = d->debug_barrier_extra;
     rp.dropout_p = d->readout_dropout;
     rp.dropout_seed = d->dropout_seed;
@@ -848,5 +894,8 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     GS_TRY(launch_linear(cur, width, 0, 1, &ent, width, d->num_para, g, d->num_para, width, epi, st));
   }
   if (target != nullptr && loss3 != nullptr) GS_TRY(gnnsaft_mape(out, target, g * d->num_para, loss3, st));
+  // a structure chain that lost its barrier: NaN instead of the garbage computed on the empty structure
+  if (k0_lost != nullptr)
+    GS_TRY(launch_poison_if(k0_lost, out, g * d->num_para, target != nullptr ? loss3 : nullptr, st));
   return GNNSAFT_OK;
 }

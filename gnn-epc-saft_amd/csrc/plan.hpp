@@ -33,8 +33,11 @@ struct Plan {
   size_t csr_ws, rowptr, src, dst, combo, log_amp, log_att, graph_ptr;
   size_t x0, x1, pq, agg, u0, u1, y, msg0, msg1, cemb, cenc, rtab, stats, bnseg, bnseg_bytes, scale, shift, pooled, m0, m1, m2;
   size_t perm, tiles, num_tiles, hist3, weff, gfold;
+  size_t w3src, w3lin, w3eff;   // W3 weight images (w3.hpp), per layer: source block of pre_nns [2H,H], lin [H,H], w_eff
+  size_t w3src_stride, w3lin_stride, w3eff_stride;   // bytes per layer (0 where the images are not built)
   size_t rd_scratch, rd_sync;   // fused readout: per-workgroup partials, barrier counters (+ BatchNorm tail tickets)
   size_t bn_tail_seg;
+  size_t k0_lost;               // one int: 1 = the structure chain of THIS call lost a barrier (written by every call)
   size_t struct_begin, struct_bytes;  // [rowptr .. hist3]: everything that depends on edge_index / batch only
   int64_t tile_cap;
   // per-layer strides in floats (0 unless desc->save_tape: then every layer keeps its own tensors for backward)
@@ -139,9 +142,18 @@ static inline int make_plan(const gnnsaft_model_desc *d, int64_t n, int64_t e, i
     // then k_bn_stats_close's slab tickets (kBnTailCounterInts)
     p.rd_sync = take((16 + (size_t)kBnTailCounterInts) * 4);
     p.bn_tail_seg = take((size_t)64 * 2 * h * 8);   // [kBnMaxSegments][2][H] f64 segment sums of k_bn_stats_close
+    p.k0_lost = take(4);
   }
   p.weff = d->fold_degree_scalers ? take(nl * (size_t)kDegreeBuckets * 5 * h * h * 4) : 0;
   p.gfold = d->fold_degree_scalers ? take(nl * 2 * 3 * (h / 2) * h * 8) : 0;   // float64 (fold.hpp)
+  // weight images of the split-bf16 GEMMs (6 bytes per weight); K of every image (H, 5H) must be a multiple of 32
+  const bool w3 = (h % 64) == 0;
+  p.w3src_stride = w3 ? gs_align_up(2 * h * h * 6, 256) : 0;
+  p.w3lin_stride = w3 ? gs_align_up(h * h * 6, 256) : 0;
+  p.w3eff_stride = w3 && d->fold_degree_scalers ? (size_t)kDegreeBuckets * 5 * h * h * 6 : 0;
+  p.w3src = take(nl * p.w3src_stride);
+  p.w3lin = take(nl * p.w3lin_stride);
+  p.w3eff = take(nl * p.w3eff_stride);
   p.total = off;
   return GNNSAFT_OK;
 }

@@ -58,8 +58,9 @@ struct ReadoutArgs {
   float *pooled, *ry, *ro, *rstat;   // tape: [G,H], [nb][G,H], [nb][G,H], [nb][2][H]   (ry / ro row stride H)
   float *part;               // [nb][W][2][H] per-workgroup (mean, M2)
   float *mape_part;          // [W]
-  int32_t *sync;             // [nb + 1] counters, zero at launch
+  int32_t *sync;             // [nb + 1] counters, zero at launch; sync[kRdSyncInts - 1]: "this call lost a barrier"
   int32_t *err;
+  const int32_t *k0_lost;    // or null: the structure chain of this call lost a barrier (forward.hip)
   int barrier_extra;         // 0; > 0 (test hook): the barriers expect that many arrivals more than there are workgroups
   float dropout_p;           // 0: no dropout (or eval mode)
   uint64_t dropout_seed;
@@ -67,7 +68,7 @@ struct ReadoutArgs {
 
 // all workgroups of the grid meet here; returns true after every one of them has arrived, false when the spin bound
 // was hit (the flag word is raised; the caller poisons its outputs)
-__device__ __forceinline__ bool grid_barrier(int32_t *counter, int expected, int32_t *err) {
+__device__ __forceinline__ bool grid_barrier(int32_t *counter, int expected, int32_t *err, int32_t *lost_word) {
   __shared__ int s_barrier_ok;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -78,6 +79,7 @@ __device__ __forceinline__ bool grid_barrier(int32_t *counter, int expected, int
       __builtin_amdgcn_s_sleep(2);
       if (++spins > (1L << 21)) {  // ~0.5 s: a workgroup never became resident; give up loudly instead of hanging
         if (err) atomicOr(err, GNNSAFT_FLAG_BARRIER_TIMEOUT);
+        __hip_atomic_store(lost_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = 0;
         break;
       }
@@ -88,12 +90,14 @@ __device__ __forceinline__ bool grid_barrier(int32_t *counter, int expected, int
   return s_barrier_ok != 0;
 }
 
-// has THIS call lost a barrier anywhere?  (the flag word is sticky across calls until the host reads it: a later call
-// on a device that lost one keeps poisoning until somebody looks)
-__device__ __forceinline__ bool barrier_lost(bool all_ok, const int32_t *err) {
-  return !all_ok ||
-         (err != nullptr && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
-                             GNNSAFT_FLAG_BARRIER_TIMEOUT) != 0);
+// has THIS call lost a barrier anywhere?  `lost_word`: the last of the kernel's sync words (zero at launch), set by
+// every workgroup that gave up -- one that arrived late and found the counters complete still learns that the others
+// computed with incomplete statistics; `k0_lost` (forward, or null): the structure chain in front of this kernel.
+// Per call: the sticky flag word is for the host, a later call is not poisoned by it.
+constexpr int kRdLostWord = kRdSyncInts - 1;
+__device__ __forceinline__ bool barrier_lost(bool all_ok, const int32_t *lost_word, const int32_t *k0_lost = nullptr) {
+  return !all_ok || __hip_atomic_load(lost_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+         (k0_lost != nullptr && k0_lost[0] != 0);
 }
 
 // y[64][n_out] = a[64][n_in] (LDS) x W^T + bias : 32 x 32 output tiles round-robin over the 8 waves, k in the order
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_fused(ReadoutArgs a) {
         }
       }
       RD_STAMP(2 + 6 * b);
-      barriers_ok &= grid_barrier(a.sync + b, nwg + a.barrier_extra, a.err);
+      barriers_ok &= grid_barrier(a.sync + b, nwg + a.barrier_extra, a.err, a.sync + kRdLostWord);
       RD_STAMP(3 + 6 * b);
       {
         // every workgroup folds all partials: S1 = sum n_w (mean_w - K), S2 = sum (M2_w + n_w (mean_w - K)^2) in f64
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_fused(ReadoutArgs a) {
     rd_gemm(at, ld, a.w[b], a.b[b], a.n_in[b], a.num_para, yt, ld);
     __syncthreads();
     float ape = 0.f;
-    const bool lost = a.training && barrier_lost(barriers_ok, a.err);   // block-uniform
+    const bool lost = barrier_lost(barriers_ok, a.sync + kRdLostWord, a.k0_lost);   // block-uniform; every mode
     for (int idx = tid; idx < rows * a.num_para; idx += kRdThreads) {
       const int r = idx / a.num_para, c = idx - r * a.num_para;
       const float v = lost ? __builtin_nanf("") : yt[r * ld + c];
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_fused(ReadoutArgs a) {
           float tot = 0.f;
           for (int w = 0; w < nwg; ++w) tot += __builtin_nontemporal_load(a.mape_part + w);
           const float cnt = (float)(a.g * a.num_para);
-          if (a.training && barrier_lost(barriers_ok, a.err)) tot = __builtin_nanf("");
+          if (barrier_lost(barriers_ok, a.sync + kRdLostWord, a.k0_lost)) tot = __builtin_nanf("");
           a.loss3[0] = tot / cnt;
           a.loss3[1] = tot;
           a.loss3[2] = cnt;
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_bwd_fused(ReadoutBwdArgs
         pp[h + c] = (float)s2;
       }
     }
-    barriers_ok &= grid_barrier(a.sync + b, nwg + a.barrier_extra, a.err);
+    barriers_ok &= grid_barrier(a.sync + b, nwg + a.barrier_extra, a.err, a.sync + kRdLostWord);
     {
       const float *pp = a.part + (int64_t)b * nwg * 2 * h;
       const int cc = col_ok ? c : 0;
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_bwd_fused(ReadoutBwdArgs
   }
   // ---- gradient of the pooled rows (NaN after a lost barrier: it reaches every gradient below the readout, and
   //      through the flat gradient buffer the optimizer's parameters -- wrong statistics cannot train silently)
-  const bool lost = barrier_lost(barriers_ok, a.err);
+  const bool lost = barrier_lost(barriers_ok, a.sync + kRdLostWord);
   const float nanv = __builtin_nanf("");
   for (int idx = tid; idx < rows * (h / 4); idx += kRdThreads) {
     const int r = idx / (h / 4), c4 = (idx - r * (h / 4)) * 4;
@@ -720,6 +724,7 @@ int launch_readout_fused(const ReadoutFusedParams &p, hipStream_t st) {
                                           gs_align_up((size_t)p.nblocks * wgs * 2 * p.h * 4, 256));
   a.sync = p.sync;
   a.err = p.err;
+  a.k0_lost = p.k0_lost;
   a.barrier_extra = p.barrier_extra > 0 ? p.barrier_extra : 0;
   GS_REQUIRE(p.dropout_p >= 0.f && p.dropout_p < 1.f, GNNSAFT_ERR_SHAPE);
   a.dropout_p = p.training ? p.dropout_p : 0.f;

@@ -21,8 +21,9 @@ struct ReadoutFusedParams {
   float *out, *loss3;
   float *pooled, *ry, *ro, *rstat;       // kept for the backward (may be null)
   void *scratch;                          // readout_fused_scratch_bytes
-  int32_t *sync;                          // kRdSyncInts ints, zero at launch
+  int32_t *sync;                          // kRdSyncInts ints, zero at launch (the last one: "this call lost a barrier")
   int32_t *err;
+  const int32_t *k0_lost;                 // or null: 1 = the structure chain of this call lost a barrier (NaN outputs)
   int barrier_extra;                      // test hook (desc->debug_barrier_extra): arrivals the barriers wait for in vain
   float dropout_p;                        // Dropout behind every ReLU of the readout (models.py:88,95,99); training only
   uint64_t dropout_seed;                  // Philox key of this call's masks

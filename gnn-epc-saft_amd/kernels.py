@@ -111,6 +111,35 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu_
     return (out, stats) if want_stats else out
 
 
+def w3_pack(w: torch.Tensor) -> torch.Tensor:
+    """The "W3" image of a weight matrix [rows, k] (csrc/w3.hpp): bf16 planes of the exact f32 split in the GEMM's
+    LDS-stage order.  k % 32 == 0."""
+    rows, k = w.shape
+    nbytes = lib.gnnsaft_w3_image_bytes(rows, k)
+    if nbytes == 0:
+        raise ValueError(f"no W3 image for a [{rows}, {k}] matrix (k must be a positive multiple of 32)")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    w = w if w.stride(1) == 1 else w.contiguous()
+    check(lib.gnnsaft_w3_pack(_p(w), w.stride(0), rows, k, _p(img), _stream(w)), "gnnsaft_w3_pack")
+    return img
+
+
+def linear_w3(a: torch.Tensor, w_image: torch.Tensor, n_out: int, bias: Optional[torch.Tensor], tile_config: int,
+              want_stats: bool = False, specialised: bool = False):
+    """out = a W^T + bias on the split-bf16 kernels that read pre-split weights (csrc/gemm_w3.hip; ``specialised``:
+    the consumer / producer wave form of csrc/gemm_w3s.hip); test / tuning hook."""
+    m, k = a.shape
+    out = torch.empty((m, n_out), dtype=torch.float32, device=a.device)
+    stats = None
+    if want_stats:
+        groups = (m + bn_rows_per_group() - 1) // bn_rows_per_group()
+        stats = torch.full((groups, 2, n_out), float("nan"), dtype=torch.float32, device=a.device)
+    fn = lib.gnnsaft_debug_linear_w3s if specialised else lib.gnnsaft_debug_linear_w3
+    check(fn(_p(a), a.stride(0), _p(w_image), _p(bias), _p(out), n_out, m, n_out, k, _p(stats), int(tile_config),
+             _stream(a)), "gnnsaft_debug_linear_w3s" if specialised else "gnnsaft_debug_linear_w3")
+    return (out, stats) if want_stats else out
+
+
 def pna_node_terms(x: torch.Tensor, w_pre0: torch.Tensor, w_pre1: torch.Tensor) -> torch.Tensor:
     n, h = x.shape
     pq = torch.empty((n, 4 * h), dtype=torch.float32, device=x.device)

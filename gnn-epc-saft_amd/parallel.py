@@ -25,12 +25,24 @@ import torch.distributed as dist
 from .data.synthetic import GraphData, split_graphs
 
 
+def exchange_active() -> bool:
+    """True when the exchange steps must issue their collectives: more than one rank -- or ONE rank with
+    ``GNNSAFT_FORCE_COLLECTIVES=1`` (read at every call), which sends every collective of the data-parallel path
+    through the backend anyway.  That is how a one-GPU box runs communicator creation, the asynchronous loss
+    all-reduce, the flat gradient all-reduce and the segment-wise exchange on real RCCL
+    (tests/test_gpu_nccl_single_rank.py); an all-reduce over one rank leaves the buffer as it is."""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("GNNSAFT_FORCE_COLLECTIVES") == "1"
+
+
 def init_from_env(backend: Optional[str] = None) -> tuple:
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run contract)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    forced = os.environ.get("GNNSAFT_FORCE_COLLECTIVES") == "1"
+    if (world > 1 or forced) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -46,7 +58,7 @@ def shard(data: GraphData, rank: int, world: int) -> GraphData:
 
 def global_mape(loss3: torch.Tensor) -> torch.Tensor:
     """``loss3 = [local mape, local sum(ape), local count]`` -> global MAPE over all ranks."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not exchange_active():
         return loss3[0]  # one rank: the kernel's own mean is the answer, no extra launches
     parts = loss3[1:3].clone()
     dist.all_reduce(parts, op=dist.ReduceOp.SUM)
@@ -72,7 +84,7 @@ def global_mape_async(loss3: torch.Tensor) -> PendingMape:
     a logged metric (``sync_dist=True``), so the next step's kernels need not queue behind it."""
     parts = loss3[1:3].clone()
     work = None
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if exchange_active():
         work = dist.all_reduce(parts, op=dist.ReduceOp.SUM, async_op=True)
     return PendingMape(parts, work)
 
@@ -82,7 +94,7 @@ def allreduce_flat_sum(flat: torch.Tensor) -> float:
     mean (1 / world) so that the caller can fold it into its next kernel (the fused optimizers' ``grad_scale``)
     instead of spending a launch on the division."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world > 1:
+    if exchange_active():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return 1.0 / world
 
@@ -128,7 +140,7 @@ class OverlappedGradientExchange:
         """All-reduce every segment of ``flat`` behind its completion event; returns 1 / world (the factor the fused
         optimizer folds into its kernel)."""
         world = dist.get_world_size() if dist.is_initialized() else 1
-        if world > 1:
+        if exchange_active():
             with torch.cuda.stream(self.stream):
                 for (a, b), ev in zip(self.segments, self.events):
                     self.stream.wait_event(ev)
@@ -156,9 +168,10 @@ class FlatGradientAllReduce:
         world = dist.get_world_size() if dist.is_initialized() else 1
         shared = common_gradient_buffer(self.params)
         if shared is not None:     # gradients already live in one buffer: reduce it where it is
-            if world > 1:
+            if exchange_active():
                 dist.all_reduce(shared, op=dist.ReduceOp.SUM)
-                shared.div_(world)
+                if world > 1:
+                    shared.div_(world)
             return
         off = 0
         for p in self.params:
@@ -168,9 +181,10 @@ class FlatGradientAllReduce:
             else:
                 self.flat[off:off + n].zero_()
             off += n
-        if world > 1:
+        if exchange_active():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(world)
+            if world > 1:
+                self.flat.div_(world)
         off = 0
         for p in self.params:
             n = p.numel()

@@ -19,7 +19,7 @@ from typing import Callable, Iterable, List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-from ..parallel import OverlappedGradientExchange, allreduce_flat_sum, common_gradient_buffer
+from ..parallel import OverlappedGradientExchange, allreduce_flat_sum, common_gradient_buffer, exchange_active
 from .checkpoint import lightning_checkpoint, resume, save_checkpoint
 from .models import PNApcsaftL, _cfg
 
@@ -40,7 +40,7 @@ def broadcast_training_state(lit: PNApcsaftL, optimizer, scheduler, step: int, s
     parameters and buffers -- plus, here, its optimizer / scheduler state and step counter, so that a resume on
     one rank or a per-rank seed cannot leave silently diverging replicas.  One flat parameter buffer, one flat
     buffer per optimizer state, one packed buffer for the BatchNorm statistics."""
-    if _world() == 1:
+    if not exchange_active():   # (one rank: nothing to agree on -- unless the collectives are forced through the backend)
         return step
     dist.broadcast(optimizer.flat_parameters(), src)          # every trainable parameter, one collective
     owned = {id(p) for p in optimizer._params}
@@ -102,7 +102,7 @@ def training_loop(lit: PNApcsaftL, batches: Iterable, max_steps: Optional[int] =
     step = broadcast_training_state(lit, opt, sched, step)
     # world > 1, opt-in: all-reduce every finished gradient segment under the rest of the backward (needs the
     # gradients in backward's own flat buffer, i.e. no frozen parameters; otherwise the single flat all-reduce)
-    exchange = OverlappedGradientExchange(lit.model) if (overlap_gradient_exchange and world > 1) else None
+    exchange = OverlappedGradientExchange(lit.model) if (overlap_gradient_exchange and exchange_active()) else None
     history: List[Tuple[int, float]] = []
     epoch = 0
     while step < max_steps:
@@ -125,9 +125,10 @@ def training_loop(lit: PNApcsaftL, batches: Iterable, max_steps: Optional[int] =
             step += 1
             if log_every_steps and step % log_every_steps == 0:
                 logged = loss.detach().clone()
-                if world > 1:   # sync_dist=True: mean of the per-rank means
+                if exchange_active():   # sync_dist=True: mean of the per-rank means
                     dist.all_reduce(logged, op=dist.ReduceOp.SUM)
-                    logged /= world
+                    if world > 1:
+                        logged /= world
                 value = float(logged)   # the only host sync of the loop
                 flags = lit.model.input_error_flags()      # rides on that sync: clamped / dropped indices are not
                 if flags & 16:                              # fatal: BatchNorm statistics of the readout incomplete

@@ -251,6 +251,25 @@ GNNSAFT_API int gnnsaft_debug_linear_tile(const float *a, int64_t lda, const flo
                               float *stats /* or NULL */, int32_t tile_config, gnnsaft_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
+/* "W3" weight images (csrc/w3.hpp): a weight matrix [rows, k] (k % 32 == 0) split ONCE into the three bf16     */
+/* planes of its exact f32 split, laid out as the split-bf16 GEMM's LDS stage wants them, so the GEMM copies    */
+/* its B tile with direct-to-LDS loads.  gnnsaft_forward builds the images of pre_nns / lin / the folded update  */
+/* weights (models.py:69-80,128) in its workspace on every call; these entry points serve the stage tests and    */
+/* tools/gemm_tune.py.  tile_config: 0..5 = 128x128, 128x256, 64x128, 64x64, 128x64, 64x256 (one LDS stage, several */
+/* workgroups per CU), 6 / 7 = 128x128 / 128x256 double-buffered (one workgroup per CU).                        */
+GNNSAFT_API size_t gnnsaft_w3_image_bytes(int64_t rows, int64_t k);
+GNNSAFT_API int gnnsaft_w3_pack(const float *w, int64_t ldw, int32_t rows, int32_t k, void *image /* 16-B aligned */,
+                    gnnsaft_stream_t stream);
+GNNSAFT_API int gnnsaft_debug_linear_w3(const float *a, int64_t lda, const void *w_image, const float *bias, float *out,
+                            int64_t ldo, int64_t m, int32_t n_out, int32_t k, float *stats /* or NULL */,
+                            int32_t tile_config, gnnsaft_stream_t stream);
+/* the wave-specialised kernel (csrc/gemm_w3s.hip: consumer waves = fragment reads + MFMAs, producer waves =   */
+/* operand path); tile_config 0 = 128x128, 1 = 64x128                                                          */
+GNNSAFT_API int gnnsaft_debug_linear_w3s(const float *a, int64_t lda, const void *w_image, const float *bias, float *out,
+                             int64_t ldo, int64_t m, int32_t n_out, int32_t k, float *stats /* or NULL */,
+                             int32_t tile_config, gnnsaft_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
 /* BatchNorm (PyG BatchNorm -> torch BatchNorm1d, models.py:82,87,94,98,128).  */
 /* training != 0: combine the (mean, M2) partials written by gnnsaft_linear    */
 /* into batch statistics, update running_mean / running_var (unbiased) /       */

@@ -141,6 +141,47 @@ def test_every_gemm_tile_configuration(cfg, m, n_out, k, mode):
         assert err <= 1.5 * err_other + 1e-8
 
 
+W3_TILES = ["128x128", "128x256", "64x128", "64x64", "128x64", "64x256", "128x128 double-buffered", "128x256 double-buffered",
+            "wave-specialised 128x128", "wave-specialised 64x128"]
+
+
+@pytest.mark.parametrize("cfg", range(len(W3_TILES)))
+@pytest.mark.parametrize("m,n_out,k", [(1000, 128, 128), (257, 96, 64), (300, 64, 1280), (130, 256, 32), (4099, 512, 256)])
+def test_every_w3_gemm_tile_configuration(cfg, m, n_out, k):
+    """k_gemm_w3 (pre-split weight images, direct-to-LDS weight copies, 32-k stages) in every tile shape against the
+    f64 product under the bar of test_every_gemm_tile_configuration (4e-7 of sum |a||w|), next to the f32 fma chain of
+    the f32 matrix cores and to k_gemm_f32<X6>; with BatchNorm partials (STATS) against the f64 column statistics."""
+    torch.manual_seed(cfg * 7 + m)
+    a = torch.randn(m, k) * torch.logspace(-1.5, 1.5, m).view(-1, 1)
+    w, b = torch.randn(n_out, k) / math.sqrt(k), torch.randn(n_out)
+    ref = a.double() @ w.double().t() + b.double()
+    row_scale = (a.double().abs() @ w.double().abs().t() + b.double().abs())
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    img = K().w3_pack(wd)
+    spec = cfg >= 8      # gemm_w3s.hip: consumer / producer waves
+    out, stats = K().linear_w3(ad, img, n_out, bd, cfg - 8 if spec else cfg, want_stats=True, specialised=spec)
+    out = out.cpu().double()
+    f32 = K().linear(ad, wd, bd, tile_config=3 + 32).cpu().double()
+    x6 = K().linear(ad, wd, bd, tile_config=3 + 16).cpu().double()
+    err, err32, err6 = (float(((o - ref).abs() / row_scale).max()) for o in (out, f32, x6))
+    print(f"w3 {W3_TILES[cfg]} [{m},{k}]x[{k},{n_out}]: max |err| / sum|a||w| = {err:.2e} (f32 chain {err32:.2e}, "
+          f"in-kernel split {err6:.2e})")
+    assert not torch.isnan(out).any()
+    assert rel_err(out, ref) < 2e-6
+    assert err < 4e-7 and err <= 1.5 * err32 + 1e-8
+    # the same k order and the same six products as the in-kernel split: equal up to the order of the k16 steps
+    assert float((out - x6).abs().max()) <= 4e-7 * float(row_scale.max())
+    # BatchNorm partials: (mean, M2) per 64-row group and column
+    rpg = K().bn_rows_per_group()
+    groups = (m + rpg - 1) // rpg
+    st = stats.cpu().double()
+    for gi in (0, groups - 1):
+        rows = ref[gi * rpg:(gi + 1) * rpg]
+        mean, m2 = rows.mean(0), ((rows - rows.mean(0)) ** 2).sum(0)
+        assert float((st[gi, 0] - mean).abs().max()) < 2e-6 * float(row_scale.max())
+        assert float((st[gi, 1] - m2).abs().max()) < 2e-5 * float(m2.abs().max() + 1e-30)
+
+
 @pytest.mark.parametrize("rows,ch", [(1000, 128), (63, 64), (20480, 256), (2, 32), (777, 16)])
 def test_fused_batchnorm_train_apply(rows, ch):
     torch.manual_seed(rows + ch)

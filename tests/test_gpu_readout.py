@@ -142,18 +142,39 @@ def test_a_lost_grid_barrier_raises_the_flag_and_poisons_the_results():
         assert bool(torch.isnan(bad).all()) and bool(torch.isnan(bl[0]))
         assert m.input_error_flags() & 16
         assert m.input_error_flags() == 0                 # cleared by the read
-        # eval mode has no batch statistics, but the optional structure chain inside the forward's first launch meets
-        # at grid barriers too (elementwise.hip: k0_chain_body): lost ones raise the flag, the next launch installs an
-        # EMPTY structure instead of indexing with half-built tables -- no fault, and the flag says "garbage"
+        # eval mode has no batch statistics, but the structure chain inside the forward's first launch meets at a grid
+        # barrier too (elementwise.hip: k0_chain_body).  A lost one raises the flag, the next launch installs an EMPTY
+        # structure instead of indexing with half-built tables AND restores the chain's persistent words, and the end
+        # of the forward writes NaN in EVERY mode and on BOTH readout paths -- then, WITHOUT the host ever reading the
+        # flag word, the next call is a correct forward again (the same bits as before the loss).
         m.eval()
         m.fused_structure_chain = True
-        m(dd)
-        torch.cuda.synchronize()
-        assert m.input_error_flags() & 16
-        m.train()
         m._debug_barrier_extra = 0
-        ok, okl = m.run(dd, target=tgt)                   # (reading the flag re-zeroed the persistent barrier words)
-        assert torch.equal(ok, good) and torch.equal(okl, gl) and m.input_error_flags() == 0
+        good_eval = m(dd).clone()
+        m._debug_barrier_extra = 1
+        bad_eval = m(dd)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(bad_eval).all()), "eval mode: finite garbage after a lost structure barrier"
+        m.fused_readout = False
+        bad_perop = m(dd)
+        assert bool(torch.isnan(bad_perop).all()), "per-op readout: finite garbage after a lost structure barrier"
+        m._debug_barrier_extra = 0
+        again_perop = m(dd)                               # (no input_error_flags() in between)
+        m.fused_readout = True
+        again = m(dd)
+        assert torch.equal(again, good_eval) and bool(torch.isfinite(again_perop).all())
+        m.train()
+        ok, okl = m.run(dd, target=tgt)                   # training mode right behind it: not poisoned by the sticky flag
+        assert torch.equal(ok, good) and torch.equal(okl, gl)
+        assert m.input_error_flags() & 16                 # the sticky word still tells the host what happened
+        assert m.input_error_flags() == 0
+        m._debug_barrier_extra = 1                        # training mode: both the chain's and the readout's barriers are lost
+        bad, bl = m.run(dd, target=tgt)
+        assert bool(torch.isnan(bad).all()) and bool(torch.isnan(bl[0]))
+        m._debug_barrier_extra = 0
+        ok, okl = m.run(dd, target=tgt)
+        assert torch.equal(ok, good) and torch.equal(okl, gl)
+        assert m.input_error_flags() & 16 and m.input_error_flags() == 0
     # backward: the forward's barriers pass, the backward's are lost
     m._debug_barrier_extra = 0
     pred = m(dd)

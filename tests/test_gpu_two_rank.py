@@ -17,8 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("overlap", [False, True], ids=["flat-allreduce", "segment-overlap"])
-def test_two_processes_on_one_gpu_match_a_single_process_replay(tmp_path, overlap):
+@pytest.mark.parametrize("overlap,k0_fused", [(False, "0"), (True, "0"), (False, "1")],
+                         ids=["flat-allreduce", "segment-overlap", "flat-allreduce-cooperative-structure-chain"])
+def test_two_processes_on_one_gpu_match_a_single_process_replay(tmp_path, overlap, k0_fused):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import gloo_hip_worker as W
     from gnn_epc_saft_amd.data.loader import GraphLoader
@@ -26,9 +27,11 @@ def test_two_processes_on_one_gpu_match_a_single_process_replay(tmp_path, overla
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    # (two processes share this GPU: the cooperative structure chain would lose scheduling quanta at its waits; the
-    #  launches build the same structure -- tests/test_gpu_forward.py compares them bit for bit)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT, GNNSAFT_K0_FUSED="0")
+    # (two processes share this GPU: the cooperative structure chain loses scheduling quanta at its waits, so the
+    #  rehearsals run the launches, which build the same structure -- tests/test_gpu_forward.py compares them bit for
+    #  bit; the third case runs the chain anyway, as every real rank does: slow is fine, a lost barrier is not -- the
+    #  workers' training loop raises on GNNSAFT_FLAG_BARRIER_TIMEOUT -- and the bits must be the same)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT, GNNSAFT_K0_FUSED=k0_fused)
     worker = os.path.join(ROOT, "tests", "gloo_hip_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(tmp_path)] + (["overlap"] if overlap else []),
                               env=dict(env, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2"),
