@@ -165,11 +165,16 @@ class Workload:
                 f"P={c['num_para']} skip+self-loops")
 
 
-def instrumented_kernel_times(wl: Workload, steps: int, stream, barrier):
+def instrumented_kernel_times(wl: Workload, steps: int, stream, barrier, fused: bool = False):
     """K eager steps with HIP events recorded ON THE LAUNCH STREAM around every K4 / GEMM launch (gnnsaft_profile_*):
-    {kernel: (launches, avg ms)} and the wall time of the instrumented repeat."""
+    {kernel: (launches, avg ms)} and the wall time of the instrumented repeat.  Asking for the aggregation kernel's
+    events makes the forward launch it on its own (k_pna_aggregate + the update GEMM: the two launches the taped
+    training forward always issues); ``fused``: no aggregation events -- the no-grad forward's own schedule, in which
+    the update kernel aggregates inside its operand path (k_update_agg_w3s) and `update` times THAT launch."""
     from gnn_epc_saft_amd import _native
-    mask = _native.PROF_AGGREGATE | _native.PROF_UPDATE | _native.PROF_NODE_TERMS | _native.PROF_LIN
+    mask = _native.PROF_UPDATE | _native.PROF_NODE_TERMS | _native.PROF_LIN
+    if not fused:
+        mask |= _native.PROF_AGGREGATE
     handle = ctypes.c_void_p()
     _native.check(_native.lib.gnnsaft_profile_create(steps * wl.cfg["depth"] * 4, mask, ctypes.byref(handle)),
                   "gnnsaft_profile_create")
@@ -197,7 +202,7 @@ def instrumented_kernel_times(wl: Workload, steps: int, stream, barrier):
     return out, elapsed
 
 
-def roofline_blocks(wl: Workload, times, event_overhead_ms=None):
+def roofline_blocks(wl: Workload, times, event_overhead_ms=None, fused_times=None):
     """`roofline` (K4, HBM) and `roofline_gemm` (f32 MFMA) objects from the event-timed launches."""
     cfg, n, ep, h = wl.cfg, wl.n, wl.e_prime, wl.cfg["hidden"]
     k4_n, k4_ms = times["k4"]
@@ -211,11 +216,18 @@ def roofline_blocks(wl: Workload, times, event_overhead_ms=None):
         "bound": "hbm", "achieved": k4_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k4_gbs / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_note,
         "algorithmic_bytes_per_launch": k4_bytes, "avg_launch_ms": k4_ms, "launches_timed": k4_n,
+        "achieved_physical": (traffic / (k4_ms * 1e-3) / 1e9) if traffic else None,   # PMC bytes / event time
+        "frac_physical": (traffic / (k4_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
         "rocprofv3_avg_launch_ms": rocprof_ms,   # from profiles/ (kernel time without the event overhead)
         "event_pair_ms_around_empty_kernel": event_overhead_ms,
         "working_set_mb": ws_mb,
+        "launched_by": "the taped (training) forward and this instrumented repeat of the timed steps; the timed no-grad "
+                       "forward itself fuses the aggregation into the update GEMM's operand path (k_update_agg_w3s, "
+                       "`roofline_gemm.fused_update_agg`) where the shape allows (hidden % 128 == 0), so that the "
+                       "aggregates never reach HBM",
         "how": "HIP events on the launch stream around every K4 launch of an instrumented repeat of the timed steps; "
-               "`achieved` = SURVEY 8(d) algorithmic bytes / event time.  " +
+               "`achieved` = SURVEY 8(d) algorithmic bytes / event time, `achieved_physical` = the PMC-counted HBM "
+               "bytes of `traffic` / the same time.  " +
                (f"Working set {ws_mb:.0f} MB < 256 MiB Infinity Cache and the same batch is replayed: part of this "
                 "rate is L3, not HBM -- the `c3` block is the beyond-L3 figure."
                 if ws_mb < 256 else f"Working set {ws_mb:.0f} MB > 256 MiB Infinity Cache: HBM-bound in earnest."),
@@ -251,6 +263,19 @@ def roofline_blocks(wl: Workload, times, event_overhead_ms=None):
                                           "GEMMs; the restructured path issues 16 N H^2 f32-equivalent -- the ratio is an "
                                           "algorithmic saving, not a fraction of peak",
         }
+        if fused_times is not None and fused_times["update"][0] > 0 and fused_times["k4"][0] == 0:
+            ms = fused_times["update"][1]
+            two = times["k4"][1] + times["update"][1]
+            flop = 10.0 * n * h * h
+            gemm["fused_update_agg"] = {
+                "kernel": "k_update_agg_w3s: aggregation (k_pna_aggregate's reduction, by the producer waves) + "
+                          "degree-folded update GEMM in one launch -- what the timed no-grad forward runs per layer",
+                "avg_ms": ms, "launches_timed": fused_times["update"][0],
+                "replaces_ms": two, "replaces": "k_pna_aggregate + update GEMM launched separately (above)",
+                "bf16_mfma_tflops_issued": 6.0 * flop / (ms * 1e-3) / 1e12,
+                "frac_of_bf16_mfma_peak": 6.0 * flop / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
+                "hbm_bytes_not_moved": 2 * 32 * h * n,   # the aggregates [N,2,4H] f32: written once, read once
+            }
         return roof, gemm
     gemm = {
         "kernels": "k_gemm_f32: source terms (PlainA), degree-folded update (PostFoldA), lin (+BN partials); per layer",
@@ -392,6 +417,7 @@ def main() -> None:
     # ---- timed region 2: the same K steps launched eagerly with HIP events recorded on the
     # launch stream around the K4 / GEMM launches -> per-kernel durations for the roofline
     times, elapsed_instr = instrumented_kernel_times(wl, args.steps, stream, barrier)
+    fused_times, _ = instrumented_kernel_times(wl, args.steps, stream, barrier, fused=True)
 
     # ---- secondary measurement: a training step WITH backward (gnnsaft_backward), eager; for N > 1 followed by
     # the single flat RCCL all-reduce of the gradients (what DDP does for the reference, train.py:142-145)
@@ -503,7 +529,7 @@ def main() -> None:
 
     if rank == 0:
         total_graphs = cfg["graphs"] * world * args.steps
-        roof, gemm = roofline_blocks(wl, times, event_overhead_ms)
+        roof, gemm = roofline_blocks(wl, times, event_overhead_ms, fused_times)
         out = {
             "metric": "molecular graphs/sec (forward+loss)",
             "value": total_graphs / elapsed,
@@ -699,7 +725,8 @@ def measure_c3(dev, stream, event_overhead_ms, steps: int = 10, warmup: int = 3,
         barrier()
         elapsed = time.perf_counter() - t0
     times, _ = instrumented_kernel_times(wl, steps, stream, barrier)
-    roof, gemm = roofline_blocks(wl, times, event_overhead_ms)
+    fused_times, _ = instrumented_kernel_times(wl, steps, stream, barrier, fused=True)
+    roof, gemm = roofline_blocks(wl, times, event_overhead_ms, fused_times)
     out = {"workload": wl.describe() + ", train-mode BatchNorm forward + MAPE loss, eager", "steps": steps,
            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "graphs_per_s": wl.cfg["graphs"] * steps / elapsed,
            "nodes": wl.n, "edges_with_self_loops": wl.e_prime, "final_loss": float(parts[0]),

@@ -186,6 +186,12 @@ int launch_linear_w3(const float *a, int64_t lda, int nbatch, const GemmBatchEnt
 // wave-specialised form (gemm_w3s.hip): cfg 0 = 128 x 128, 1 = 64 x 128
 int launch_linear_w3s(const float *a, int64_t lda, int nbatch, const GemmBatchEntry *entries /* .w3 set */, int n_pad,
                       int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi, hipStream_t stream, int cfg);
+// fused aggregation + folded update of the no-tape forward (update_agg.hip): the aggregates never reach HBM
+bool update_agg_supported(int hidden, int classes);
+int launch_pna_update_agg(const float *x, const float *q, const float *rtab, int classes, const int32_t *rowptr,
+                          const int32_t *src, const int32_t *combo, const int32_t *perm, const int32_t *tiles,
+                          const int32_t *num_tiles, int64_t max_tiles, int64_t n, int hidden, const char *w_eff3,
+                          const float *b_post0, const float *b_post1, float *u, hipStream_t stream);
 int w3_cfg_for_update(int hidden);   // -1: the folded update stays on k_gemm_f32
 int launch_pna_update_folded_w3(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
                                 const int32_t *num_tiles, int64_t max_tiles, int64_t n, int hidden, const char *w_eff3,

@@ -14,6 +14,7 @@
 //     batch_norms[l].module: weight, bias, running_mean, running_var, num_batches_tracked
 //   readout: num_mlp_layers x (Linear weight, bias, BN x5)
 //            Linear(H,H/2) w,b, BN x5, Linear(H/2,H/4) w,b, BN x5, Linear(H/4,P) w,b
+#include <cstdlib>
 #include <vector>
 
 #include "bn_fold.hpp"
@@ -593,7 +594,20 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
   //      stacked [2H, H] and lin [H, H], every layer, one launch; the folded update weights get theirs from the fold
   const bool w3_src = p.w3src_stride != 0 && fold_dst && w3_pick_cfg(n, 2 * h, h, false) >= 0;
   const bool w3_lin = p.w3lin_stride != 0 && w3_pick_cfg(n, h, h, d->training != 0) >= 0;
-  const bool w3_upd = p.w3eff_stride != 0 && d->fold_degree_scalers && w3_cfg_for_update(h) >= 0;
+  const bool w3_upd_gemm = p.w3eff_stride != 0 && d->fold_degree_scalers && w3_cfg_for_update(h) >= 0;
+  // the no-tape forward's fused aggregation + update (update_agg.hip): the aggregates never reach HBM.  Not while the
+  // aggregation kernel itself is being timed (bench.py's roofline events around k_pna_aggregate), not with a tape (the
+  // backward reads the aggregates), not for the explicit destination term.  GNNSAFT_FUSED_AGG = 0 / 1 forces the two
+  // launches / the fused launch; unset: fused from 64 k nodes up (measured: C3 -6 % per step; at C2's 20 k nodes the
+  // two launches are 10 us per layer faster -- profiles/r04_*)
+  static const int fused_agg_env = [] {
+    const char *e = getenv("GNNSAFT_FUSED_AGG");
+    return e == nullptr ? -1 : (e[0] != '0' ? 1 : 0);
+  }();
+  const bool fused_agg_on = fused_agg_env < 0 ? n >= 65536 : fused_agg_env == 1;
+  const bool fuse_agg = fused_agg_on && p.w3eff_stride != 0 && d->fold_degree_scalers && fold_dst && !d->save_tape &&
+                        update_agg_supported(h, (int)p.combos) && !(prof != nullptr && (prof->mask & GNNSAFT_PROF_AGGREGATE) != 0);
+  const bool w3_upd = w3_upd_gemm || fuse_agg;   // the fold leaves W3 images of the folded weights
   if (w3_src || w3_lin) {
     std::vector<W3PackItem> items;
     for (int l = 0; l < d->num_layers; ++l) {
@@ -761,8 +775,8 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
       }
       msgs = ma;
     }
-    // K4 aggregation
-    {
+    // K4 aggregation (unless the update does it itself)
+    if (!fuse_agg) {
       ProfScope ps(prof, GNNSAFT_PROF_AGGREGATE, st);
       if (fold_dst)
         GS_TRY(gnnsaft_pna_aggregate_src(I(p.rowptr), I(p.src), I(p.combo), n, h, pq_l, rtab, agg_l, st));
@@ -771,7 +785,12 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     }
     // update: first post-layer with scalers on load, then extra post-layers
     float *ua = u_l, *ub = F(p.u1);
-    if (d->fold_degree_scalers && w3_upd) {
+    if (fuse_agg) {
+      ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
+      GS_TRY(launch_pna_update_agg(xc, pq_l, rtab, (int)p.combos, I(p.rowptr), I(p.src), I(p.combo), I(p.perm), I(p.tiles),
+                                   I(p.num_tiles), p.tile_cap, n, h, ws + p.w3eff + (size_t)l * p.w3eff_stride,
+                                   bpost[0][0], bpost[1][0], ua, st));
+    } else if (d->fold_degree_scalers && w3_upd_gemm) {
       ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
       GS_TRY(launch_pna_update_folded_w3(xc, agg_l, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap, n, h,
                                          ws + p.w3eff + (size_t)l * p.w3eff_stride, bpost[0][0], bpost[1][0], ua, st));

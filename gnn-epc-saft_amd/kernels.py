@@ -243,6 +243,24 @@ def pna_update_folded(x, agg, perm, tiles, num_tiles, hist3, avg_deg_log, w_post
     return u
 
 
+def pna_update_agg(x, q, rtab, rowptr, src, combo, perm, tiles, num_tiles, hist3, avg_deg_log, w_post0, b_post0, w_post1,
+                   b_post1):
+    """Aggregation + degree-folded update in ONE launch (csrc/update_agg.hip): what ``pna_aggregate_src`` followed by
+    ``pna_update_folded`` computes, without the aggregates ever reaching HBM.  (The folded weights are packed into W3
+    images block by block here; ``gnnsaft_forward`` gets them from the fold kernel directly.)"""
+    n, h = x.shape
+    buckets = int(lib.gnnsaft_degree_buckets())
+    w_eff = torch.zeros((buckets, 2, h // 2, 5 * h), dtype=torch.float32, device=x.device)
+    check(lib.gnnsaft_pna_fold_post_weights(_p(w_post0), _p(w_post1), _p(avg_deg_log), _p(hist3), h, _p(w_eff),
+                                            _stream(x)), "gnnsaft_pna_fold_post_weights")
+    images = torch.cat([w3_pack(w_eff[d, t]) for d in range(buckets) for t in range(2)])
+    u = torch.empty((n, h), dtype=torch.float32, device=x.device)
+    check(lib.gnnsaft_pna_update_agg(_p(x), _p(q), _p(rtab), rtab.shape[0], _p(rowptr), _p(src), _p(combo), _p(perm), _p(tiles),
+                                     _p(num_tiles), n, h, _p(images), _p(b_post0), _p(b_post1), _p(u), _stream(x)),
+          "gnnsaft_pna_update_agg")
+    return u
+
+
 def bn_train_apply(stats, y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum: float, eps: float,
                    residual=None) -> torch.Tensor:
     out = torch.empty_like(y)

@@ -614,7 +614,7 @@ class PNAPCSAFT(nn.Module):
         for buf in [self._err_flag] + self._retired_flags:
             f = int(buf[0].item())
             if f:
-                buf.zero_()   # (a lost barrier may also have left the persistent barrier words non-zero)
+                buf[0:1].zero_()   # only the sticky flag word: the library keeps the words behind it zero itself
             flags |= f
         return flags
 

@@ -263,6 +263,15 @@ GNNSAFT_API int gnnsaft_w3_pack(const float *w, int64_t ldw, int32_t rows, int32
 GNNSAFT_API int gnnsaft_debug_linear_w3(const float *a, int64_t lda, const void *w_image, const float *bias, float *out,
                             int64_t ldo, int64_t m, int32_t n_out, int32_t k, float *stats /* or NULL */,
                             int32_t tile_config, gnnsaft_stream_t stream);
+/* K4 + degree-folded update in ONE launch (csrc/update_agg.hip): the aggregation of m~ = q[src] + rtab[class] over   */
+/* the in-edges (what gnnsaft_pna_aggregate_src computes) happens inside the update GEMM's operand path, the aggregates */
+/* [N,2,4F] never reach HBM.  w_eff_images: the W3 images of the folded weights [D][2][F/2,5F] in the block order of  */
+/* gnnsaft_pna_fold_post_weights' w_eff (gnnsaft_w3_pack of every [F/2,5F] block).  hidden % 128 == 0.               */
+GNNSAFT_API int gnnsaft_pna_update_agg(const float *x, const float *q, const float *rtab, int32_t num_classes /* <= 64 */,
+                           const int32_t *rowptr, const int32_t *src, const int32_t *combo, const int32_t *perm,
+                           const int32_t *tiles, const int32_t *num_tiles, int64_t num_nodes, int32_t hidden,
+                           const void *w_eff_images, const float *b_post0, const float *b_post1, float *u,
+                           gnnsaft_stream_t stream);
 /* the wave-specialised kernel (csrc/gemm_w3s.hip: consumer waves = fragment reads + MFMAs, producer waves =   */
 /* operand path); tile_config 0 = 128x128, 1 = 64x128                                                          */
 GNNSAFT_API int gnnsaft_debug_linear_w3s(const float *a, int64_t lda, const void *w_image, const float *bias, float *out,
@@ -344,8 +353,11 @@ typedef struct gnnsaft_model_desc {
                                /* normalisation the pooling kernel applies on load; 1 = combine + apply everywhere; */
                                /* 2 = statistics closed in one launch and applied on load by the next message GEMM  */
   int32_t persistent_sync_words; /* int32 words the caller keeps BEHIND the err_flag word (err_flag[1 .. words]) for state  */
-                               /* that must survive between calls: zero before the first call, left zero by every call  */
-                               /* that completes (re-zero all of it after GNNSAFT_FLAG_BARRIER_TIMEOUT).                */
+                               /* that must survive between calls: zero before the FIRST call; the library keeps them   */
+                               /* zero between calls by itself -- also after a call that lost a grid barrier            */
+                               /* (GNNSAFT_FLAG_BARRIER_TIMEOUT): that call's outputs are NaN in every mode, the launch */
+                               /* that installs the empty structure restores the words, and the next call is a correct  */
+                               /* forward whether or not the host ever read the flag word.                              */
                                /* >= GNNSAFT_K0_SYNC_WORDS + num_nodes: gnnsaft_forward builds the batch structure by   */
                                /* cooperating workgroups of its FIRST launch (one grid barrier, fill cursors in these    */
                                /* words) beside the embedding work instead of four dependent launches.  0 (err_flag is  */

@@ -141,6 +141,69 @@ def test_every_gemm_tile_configuration(cfg, m, n_out, k, mode):
         assert err <= 1.5 * err_other + 1e-8
 
 
+@pytest.mark.parametrize("hidden,graphs,loops", [(128, 96, True), (256, 40, True), (128, 33, False), (256, 300, True)])
+def test_fused_aggregate_update_equals_the_two_launches(hidden, graphs, loops):
+    """gnnsaft_pna_update_agg (csrc/update_agg.hip: the PNA aggregation done by the producer waves of the update GEMM,
+    the aggregates never in HBM) against the two launches it replaces -- gnnsaft_pna_aggregate_src then the folded
+    update on its output -- on the same operands, and both against the f64 evaluation of the same algebra.  Same
+    per-element reduction arithmetic (sums of m - m_first, PyG's std clamp and mask); the f32 accumulation walks the k
+    stages slab-major instead of aggregator-major: equal to rounding (1e-6 of the scale; a std entry within rounding
+    of PyG's 1e-5 threshold may mask differently, as between any two evaluations).  Batches with in-degrees up to 13
+    (beyond the 4 gathers a lane keeps in flight), 1-node graphs, with and without self-loops."""
+    from gnn_epc_saft_amd.data.synthetic import GraphData, collate, make_synthetic_batch
+    torch.manual_seed(hidden + graphs)
+    base = make_synthetic_batch(graphs, 7 + graphs, num_para=3)
+    n0 = base.x.shape[0]
+    # a hub with 12 in-edges and two isolated single-node graphs appended
+    hub = GraphData(base.x[:14], torch.stack([torch.arange(1, 13), torch.zeros(12, dtype=torch.long)]),
+                    base.edge_attr[:12])
+    lone = GraphData(base.x[:1], base.edge_index[:, :0], base.edge_attr[:0])
+    parts = []
+    ptr = base.ptr.tolist()
+    for gi in range(graphs):
+        lo, hi = ptr[gi], ptr[gi + 1]
+        m = (base.edge_index[0] >= lo) & (base.edge_index[0] < hi)
+        parts.append(GraphData(base.x[lo:hi], base.edge_index[:, m] - lo, base.edge_attr[m]))
+    d = collate(parts + [hub, lone, lone])
+    n = d.x.shape[0]
+    assert n == n0 + 16
+    k = K()
+    x = torch.randn(n, hidden)
+    rowptr, src, dst, combo, la, lt, err = k.csr_build(d.edge_index.to(DEV), d.edge_attr.to(DEV), n, BOND_DIMS, loops)
+    perm, tiles, num_tiles, hist3, err2 = k.degree_tiles(rowptr, hidden)
+    q = torch.randn(n, 2 * hidden) * 0.7
+    rtab = torch.randn(60, 2 * hidden) * 0.5
+    w_post = [torch.randn(hidden // 2, 13 * hidden) / math.sqrt(13 * hidden) for _ in range(2)]
+    b_post = [torch.randn(hidden // 2) for _ in range(2)]
+    avg = torch.tensor([1.1])
+    g = lambda t: t.float().to(DEV)
+    agg = k.pna_aggregate_src(rowptr, src, combo, hidden, g(q), g(rtab))
+    two = k.pna_update_folded(g(x), agg, perm, tiles, num_tiles, hist3, g(avg), g(w_post[0]), g(b_post[0]), g(w_post[1]),
+                              g(b_post[1])).cpu().double()
+    one = k.pna_update_agg(g(x), g(q), g(rtab), rowptr, src, combo, perm, tiles, num_tiles, hist3, g(avg), g(w_post[0]),
+                           g(b_post[0]), g(w_post[1]), g(b_post[1])).cpu().double()
+    assert int(err.item()) == 0 and not torch.isnan(one).any()
+    # f64 evaluation of the same algebra from the kernel's own f32 aggregates (the aggregation itself is covered by
+    # test_gpu_stages.py::test_message_and_aggregate): cat[x, A, A amp, A att] W^T + b per tower
+    deg = (rowptr[1:] - rowptr[:-1]).cpu().double()
+    amp = torch.log(deg + 1) / float(avg)
+    att = float(avg) / torch.log(deg.clamp(min=1) + 1)
+    a64 = agg.cpu().double()
+    want = torch.empty(n, hidden, dtype=torch.float64)
+    for t in range(2):
+        z = torch.cat([x.double(), a64[:, t], a64[:, t] * amp[:, None], a64[:, t] * att[:, None]], 1)
+        want[:, t * hidden // 2:(t + 1) * hidden // 2] = z @ w_post[t].double().t() + b_post[t].double()
+    scale = float(want.abs().max())
+    e_one, e_two = float((one - want).abs().max()) / scale, float((two - want).abs().max()) / scale
+    diff = (one - two).abs() / scale
+    print(f"H={hidden} {n} nodes, max in-degree {int(deg.max())}: fused vs f64 {e_one:.2e}, two launches vs f64 {e_two:.2e}, "
+          f"fused vs two launches max {float(diff.max()):.2e}, rows differing by > 1e-6: {int((diff.max(1).values > 1e-6).sum())}")
+    assert e_one <= max(2 * e_two, 2e-6)
+    # rows whose std mask flipped between the two evaluations of the SAME f32 arithmetic should not exist at all:
+    # the reductions are the same instruction sequence on the same operands
+    assert float(diff.max()) <= 2e-6
+
+
 W3_TILES = ["128x128", "128x256", "64x128", "64x64", "128x64", "64x256", "128x128 double-buffered", "128x256 double-buffered",
             "wave-specialised 128x128", "wave-specialised 64x128"]
 

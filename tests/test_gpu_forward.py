@@ -224,9 +224,15 @@ def test_zero_crossing_case_behind_the_coarse_gate():
     abs_o_max = float((want32 - want64).abs().max()) / scale
     print(f"worst element: exact value {b / scale:.2e} of the output scale, HIP gate value {float(gate.view(-1)[worst]):.2e}, "
           f"HIP absolute error there {abs_h:.2e} of scale; f32 oracle's largest absolute error {abs_o_max:.2e} of scale")
-    if float(gate.max()) > FLIP_BAR:
-        assert abs(b) <= 1e-3 * scale          # the excess sits on an output passing through zero ...
-        assert abs_h <= 1.5 * abs_o_max        # ... and is an ordinary f32 absolute error
+    # the condition under which check_population takes its coarse gate -- this case must still NEED it: if the excess is
+    # gone (e.g. after a kernel change), this test fails on purpose and the gate is to be removed from helpers.py
+    worst_h = float(gate_err(out, want64, per_row=True).max())
+    worst_o = float(gate_err(want32, want64, per_row=True).max())
+    assert worst_h > max(FLIP_BAR, 3 * worst_o), \
+        (f"worst per-graph gate value hip {worst_h:.2e} vs f32 oracle {worst_o:.2e}: no case of the suite needs "
+         "check_population's coarse gate any more -- delete that branch of tests/helpers.py::check_population")
+    assert abs(b) <= 1e-3 * scale          # the excess sits on an output passing through zero ...
+    assert abs_h <= 1.5 * abs_o_max        # ... and is an ordinary f32 absolute error
 
 
 FLIP_BAR = 5e-3
@@ -383,6 +389,56 @@ def test_full_size_properties(config_id):
                 _, loss3 = hip_twin(copy.deepcopy(o)).run(dd, target=tgt.to(DEV))
             want = float(mape(want64, tgt.double()))
             assert abs(float(loss3[0]) - want) < 1e-4 * want
+
+
+@pytest.mark.parametrize("config_id", [2, 3])
+def test_full_size_against_the_oracle_with_the_literal_1e5_bar(config_id):
+    """BASELINE.json configs[1] and configs[2] AT FULL SIZE against the oracle run once per mode (f32 and f64; at C3 --
+    8192 graphs, 164 k nodes, H=256, L=5: the size at which k_pna_aggregate<2, true> (streaming stores) and the big GEMM
+    tiles are the kernels that run -- about a minute of host time per mode):
+      * the literal north_star number where it holds: EVAL mode, every element within 1e-5 of the output scale of the
+        f64 oracle (measured ~2e-6) -- an oracle-independent bar, no population statistics; the train-mode value is
+        printed beside it and must stay within 3x the f32 oracle's own;
+      * the frozen population bar (helpers.check_population) in both modes, and the MAPE loss to 1e-4;
+      * train mode, grad enabled: the discrete decisions (std masks, ReLU gates, min / max routing) read off the HIP
+        tape against the free f64 oracle's -- printed, and bounded at 2e-5 of all decisions as in the gradient test."""
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    from helpers import branch_differences, branch_of_oracle, branch_of_tape
+    g, hidden, depth = (1024, 128, 3) if config_id == 2 else (8192, 256, 5)
+    data = make_synthetic_batch(g, 1234 + config_id)
+    oracle = oracle_model(hidden, depth, 1, 1, 1, 3, True, True, degree_histogram(data), seed=config_id)
+    dd = data.to(DEV)
+    tgt = data.para.view(-1, 3)
+    for mode in (False, True):
+        o = copy.deepcopy(oracle)
+        o.train(mode)
+        hip = hip_twin(copy.deepcopy(o))
+        with torch.no_grad():
+            out, loss3 = hip.run(dd, target=tgt.to(DEV))
+            out = out.cpu()
+            want32 = copy.deepcopy(o)(data)
+            want64 = copy.deepcopy(o).double()(data)
+        assert hip.input_error_flags() == 0
+        e_hip, e_f32 = rel_err(out, want64), rel_err(want32, want64)
+        print(f"C{config_id} full size, {'train' if mode else 'eval'}: max |hip - f64 oracle| / max |f64 oracle| = {e_hip:.2e} "
+              f"(f32 oracle {e_f32:.2e})")
+        if not mode:
+            assert e_hip <= TOL, "eval mode: the literal 1e-5 (of the output scale) against the f64 oracle"
+        else:
+            assert e_hip <= max(3 * e_f32, TOL)
+        check_population(out, want32, want64)
+        want = float(mape(want64, tgt.double()))
+        assert abs(float(loss3[0]) - want) < 1e-4 * want
+        del want32, want64
+    # decisions of the taped train-mode forward at this size
+    o = copy.deepcopy(oracle).train()
+    hip = hip_twin(copy.deepcopy(o))
+    pred = hip(dd)
+    branch = branch_of_tape(pred, data, True, True)
+    free = branch_of_oracle(copy.deepcopy(o).double(), data, True, True)
+    diff = branch_differences(branch, free)
+    print(f"C{config_id} full size: decisions taken differently from the free f64 oracle: {diff}")
+    assert sum(v for k, v in diff.items() if k != "decisions") <= 2e-5 * diff["decisions"], diff
 
 
 def test_side_stream_and_graph_replay_give_the_same_bits():
