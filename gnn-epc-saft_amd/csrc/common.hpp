@@ -192,7 +192,7 @@ int launch_pna_update_agg(const float *x, const float *q, const float *rtab, int
                           const int32_t *src, const int32_t *combo, const int32_t *perm, const int32_t *tiles,
                           const int32_t *num_tiles, int64_t max_tiles, int64_t n, int hidden, const char *w_eff3,
                           const float *b_post0, const float *b_post1, float *u, hipStream_t stream);
-int w3_cfg_for_update(int hidden);   // -1: the folded update stays on k_gemm_f32
+int w3_cfg_for_update(int hidden, int64_t n);   // -1: the folded update stays on k_gemm_f32
 int launch_pna_update_folded_w3(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
                                 const int32_t *num_tiles, int64_t max_tiles, int64_t n, int hidden, const char *w_eff3,
                                 const float *b_post0, const float *b_post1, float *u, hipStream_t stream);

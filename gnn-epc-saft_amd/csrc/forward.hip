@@ -594,7 +594,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
   //      stacked [2H, H] and lin [H, H], every layer, one launch; the folded update weights get theirs from the fold
   const bool w3_src = p.w3src_stride != 0 && fold_dst && w3_pick_cfg(n, 2 * h, h, false) >= 0;
   const bool w3_lin = p.w3lin_stride != 0 && w3_pick_cfg(n, h, h, d->training != 0) >= 0;
-  const bool w3_upd_gemm = p.w3eff_stride != 0 && d->fold_degree_scalers && w3_cfg_for_update(h) >= 0;
+  const bool w3_upd_gemm = p.w3eff_stride != 0 && d->fold_degree_scalers && w3_cfg_for_update(h, n) >= 0;
   // the no-tape forward's fused aggregation + update (update_agg.hip): the aggregates never reach HBM.  Not while the
   // aggregation kernel itself is being timed (bench.py's roofline events around k_pna_aggregate), not with a tape (the
   // backward reads the aggregates), not for the explicit destination term.  GNNSAFT_FUSED_AGG = 0 / 1 forces the two

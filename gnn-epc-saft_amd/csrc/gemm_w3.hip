@@ -346,8 +346,8 @@ int w3_cfg_bm(int cfg) { return cfg >= 0 && cfg < kNumW3Cfg ? kW3BM[cfg] : 0; }
 
 bool gemm_w3_enabled() {
   static const bool on = [] {
-    const char *e = getenv("GNNSAFT_GEMM_W3");   // (off by default until the forward measures faster with it)
-    return e != nullptr && e[0] == '1' && gemm_x6_enabled();
+    const char *e = getenv("GNNSAFT_GEMM_W3");   // 0: the in-kernel weight split everywhere
+    return (e == nullptr || e[0] != '0') && gemm_x6_enabled();
   }();
   return on;
 }
@@ -360,9 +360,10 @@ int w3_pick_cfg(int64_t m, int n_out, int k, bool stats) {
   }();
   if (forced >= 0 && forced < kNumW3Cfg) return forced;
   (void)stats;   // every configuration has 64-row wave tiles
+  // measured (tools/w3_tune.py, profiles/r04_w3_tile_sweep.txt): from 64 k rows up the images win 3-5 % on every shape
+  // of the forward; below, the in-kernel split with its smaller tiles is as fast or faster (latency-bound launches)
   if (m >= 65536) return n_out >= 256 ? kW3_128x256 : (n_out >= 128 ? kW3_128x128 : kW3_128x64);
-  if (n_out >= 256) return kW3_64x256;
-  return n_out >= 128 ? kW3_64x128 : kW3_64x64;
+  return -1;
 }
 
 template <int BM, int BN, int WM, int WN, int NBUF, int MINWG, class AProv, bool STATS, bool AFFINE, bool RESID, int VAR = 0>
@@ -434,8 +435,8 @@ int launch_linear_w3(const float *a, int64_t lda, int nbatch, const GemmBatchEnt
 }
 
 // the W3 configuration whose BM equals the degree tile table's rows (pna_fold_tile_rows), or -1
-int w3_cfg_for_update(int hidden) {
-  if (!gemm_w3_enabled() || (hidden % 64) != 0 || hidden < 128) return -1;
+int w3_cfg_for_update(int hidden, int64_t n) {
+  if (!gemm_w3_enabled() || (hidden % 64) != 0 || hidden < 128 || n < 65536) return -1;
   const int rows = pna_fold_tile_rows(hidden), n_out = hidden / 2;
   if (rows == 128) return n_out >= 128 ? kW3_128x128 : kW3_128x64;
   if (rows == 64) return n_out >= 128 ? kW3_64x128 : kW3_64x64;
@@ -448,7 +449,7 @@ int launch_pna_update_folded_w3(const float *x, const float *agg, const int32_t 
                                 const int32_t *num_tiles, int64_t max_tiles, int64_t n, int hidden, const char *w_eff3,
                                 const float *b_post0, const float *b_post1, float *u, hipStream_t stream) {
   GS_REQUIRE(x && agg && perm && tiles && num_tiles && w_eff3 && u, GNNSAFT_ERR_NULL);
-  const int cfg = w3_cfg_for_update(hidden);
+  const int cfg = w3_cfg_for_update(hidden, (int64_t)1 << 20);   // (the caller decided; the size rule is the forward's)
   GS_REQUIRE(cfg >= 0, GNNSAFT_ERR_UNSUPPORTED);
   if (n == 0) return GNNSAFT_OK;
   GS_REQUIRE((n + 1) * (int64_t)hidden < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);   // 32-bit epilogue offsets
