@@ -81,6 +81,7 @@ SIGNATURES = {
     "gnnsaft_debug_linear_w3": (c_int32, [P, c_int64, P, P, P, c_int64, c_int64, c_int32, c_int32, P, c_int32, P]),
     "gnnsaft_debug_linear_w3s": (c_int32, [P, c_int64, P, P, P, c_int64, c_int64, c_int32, c_int32, P, c_int32, P]),
     "gnnsaft_pna_update_agg": (c_int32, [P, P, P, c_int32, P, P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
+    "gnnsaft_debug_update_agg_stamps": (c_int32, [P]),
     "gnnsaft_bn_finalize": (c_int32, [P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, c_int32, P, P, P]),
     "gnnsaft_bn_train_scratch_bytes": (c_size_t, [c_int64, c_int32]),
     "gnnsaft_bn_train_apply": (c_int32, [P, P, c_int64, c_int32, P, P, P, P, P, c_float, c_float, P, P, P, P, c_size_t,

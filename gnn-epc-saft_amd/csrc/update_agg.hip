@@ -53,15 +53,10 @@ __device__ __forceinline__ void ua_split_store(char *p, int plane, const f32x4 v
 // x / c for a small positive integer count c (inv = 1.0f / c): quotient estimate, exact residual, one correction --
 // the correctly rounded quotient (what `/` gives, at a third of its instructions; operands are far from the
 // overflow / underflow ranges where the residual would lose bits)
-__device__ __forceinline__ f32x4 ua_div(const f32x4 x, float c, float inv) {
-  f32x4 o;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const float qe = x[t] * inv;
-    const float r = __builtin_fmaf(-qe, c, x[t]);
-    o[t] = __builtin_fmaf(r, inv, qe);
-  }
-  return o;
+__device__ __forceinline__ float ua_div1(float x, float c, float inv) {
+  const float qe = x * inv;
+  const float r = __builtin_fmaf(-qe, c, x);
+  return __builtin_fmaf(r, inv, qe);
 }
 
 struct UpdateAggArgs {
@@ -69,6 +64,8 @@ struct UpdateAggArgs {
   const float *q;        // [N, 2F] source terms of both towers
   const float *rtab;     // [classes, 2F] edge-class terms
   int classes;           // <= kUaMaxClasses
+  int producer_prio;     // 1: s_setprio 1 for the producer waves
+  unsigned long long *stamps;   // development probe (tools/update_agg_stamps.py) or null: s_memtime stamps of tile 5
   const int32_t *rowptr, *src, *combo;          // destination-sorted CSR (self-loop rows included)
   const int32_t *perm, *tiles, *num_tiles;      // degree tiles (degree.hip)
   int64_t w_stride;      // f32 elements between two degrees' weight blocks (both towers)
@@ -112,6 +109,12 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
   if ((int)blockIdx.x >= a.num_tiles[0]) return;
   const int32_t *tt = a.tiles + 4 * (int64_t)blockIdx.x;
   const TileInfo ti{tt[1], tt[2], (int64_t)tt[0] * a.w_stride};
+  const bool getenv_prio = a.producer_prio != 0;
+  // stamps[role][stage][k]: role 0 = first producer wave, 1 = first consumer wave; lane 0 of tile 5, tower 0
+  unsigned long long *stamp = (a.stamps != nullptr && blockIdx.x == 5 && blockIdx.z == 0 && lane == 0) ? a.stamps : nullptr;
+  auto mark = [&](int role, int stage, int k) {
+    if (stamp != nullptr && stage < 64) stamp[(role * 64 + stage) * 4 + k] = __builtin_readcyclecounter();
+  };
   if (ti.count <= 0) return;   // block-uniform, before any barrier
   const int f = a.f;
   const int tower = blockIdx.z;
@@ -123,6 +126,9 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
 
   if (wave >= CW) {
     // ================================================================ producers: the A operand
+    // (younger than the consumer wave on their SIMD, they would lose every vector-issue arbitration against its MFMAs;
+    // an MFMA needs the port 8 cycles in 32 and its pipe keeps running meanwhile -- MI355X_MICROARCH.md, two waves per SIMD)
+    if (getenv_prio) __builtin_amdgcn_s_setprio(1);
     const int ptid = tid - CW * 64;
     const int q = ptid & 3;
     const int r0 = ptid >> 2;
@@ -160,6 +166,8 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
           g[j][s4][1] = gs_ld4(xrow[j] + 128 * S + 32 * s4 + 16 + 4 * q);
         }
     };
+    // (32-bit byte offsets from a uniform base instead of the 64-bit address per gather: measured SLOWER, 778 vs 733 us
+    // at C3 -- the saddr form's scheduling, not the address arithmetic, is what the gathers wait for)
     auto issue_gather = [&](int c) {       // slab c: the first kUaEdgeBatch in-edges of every row
       const int cb = 32 * c + 4 * q;
 #pragma unroll
@@ -173,60 +181,73 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
     const char *rl = lds + kRtabLds + (4 * q) * 4;    // this lane's columns of the slab's class rows
     // the reduction of k_pna_aggregate<kFusedQ> (aggregate.hip) on the lane's two float4 column slices of row j:
     // out[a][h] = mean | min | max | std
+    // (the in-degree of every row of a degree tile is the tile's degree: a block-uniform count keeps the edge loop
+    // free of per-lane masks.  Degrees the table clamps -- >= kDegreeBuckets, flagged GNNSAFT_FLAG_BAD_DEGREE -- are
+    // garbage in, garbage out on either path.)
+    const int deg = tt[0];
     auto reduce = [&](int c, int j, f32x4(&out)[4][2]) {
       const float inf = __builtin_huge_valf();
+      // the class terms of the lane's columns for the first edges, all requested before the first is needed
+      f32x4 tr[kUaEdgeBatch][2];
+#pragma unroll
+      for (int e = 0; e < kUaEdgeBatch; ++e)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) tr[e][h] = *reinterpret_cast<const f32x4 *>(rl + cidx[j][e] * 128 + 64 * h);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 mn = {inf, inf, inf, inf}, mx = {-inf, -inf, -inf, -inf};
-        const f32x4 v0 = g[j][0][h] + *reinterpret_cast<const f32x4 *>(rl + cidx[j][0] * 128 + 64 * h);
+        // scalar floats on purpose: on f32x4 values hipcc emits packed-f32 VALU (v_pk_add_f32 / v_pk_mul_f32), which
+        // costs extra issue cycles beside the consumer wave's MFMAs on the same SIMD (MI355X_MICROARCH.md)
+        float s[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        float mn[4] = {inf, inf, inf, inf}, mx[4] = {-inf, -inf, -inf, -inf}, v0[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v0[t] = g[j][0][h][t] + tr[0][h][t];
 #pragma unroll
         for (int e = 0; e < kUaEdgeBatch; ++e) {
-          if (e < cnt[j]) {
-            const f32x4 m = g[j][e][h] + *reinterpret_cast<const f32x4 *>(rl + cidx[j][e] * 128 + 64 * h);
-            const f32x4 d = m - v0;
-            s += d;
-            s2 += d * d;
+          if (e < deg) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-              mn[t] = fminf(mn[t], m[t]);
-              mx[t] = fmaxf(mx[t], m[t]);
+              const float m = g[j][e][h][t] + tr[e][h][t];
+              const float d = m - v0[t];
+              s[t] += d;
+              s2[t] += d * d;
+              mn[t] = fminf(mn[t], m);
+              mx[t] = fmaxf(mx[t], m);
             }
           }
         }
-        for (int e = kUaEdgeBatch; e < cnt[j]; ++e) {   // in-degrees above the batch (a 4-valent atom's self-loop): on the spot
+        for (int e = kUaEdgeBatch; e < deg; ++e) {   // in-degrees above the batch (a 4-valent atom's self-loop): on the spot
           const int cb = 32 * c + 4 * q + 16 * h;
           const int r = beg[j] + e;
-          const f32x4 m = gs_ld4(qt + (int64_t)a.src[r] * (2 * f) + cb) +
-                          *reinterpret_cast<const f32x4 *>(rl + a.combo[r] * 128 + 64 * h);
-          const f32x4 d = m - v0;
-          s += d;
-          s2 += d * d;
+          const f32x4 mq = gs_ld4(qt + (int64_t)a.src[r] * (2 * f) + cb);
+          const f32x4 mt = *reinterpret_cast<const f32x4 *>(rl + a.combo[r] * 128 + 64 * h);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            mn[t] = fminf(mn[t], m[t]);
-            mx[t] = fmaxf(mx[t], m[t]);
+            const float m = mq[t] + mt[t];
+            const float d = m - v0[t];
+            s[t] += d;
+            s2[t] += d * d;
+            mn[t] = fminf(mn[t], m);
+            mx[t] = fmaxf(mx[t], m);
           }
         }
-        f32x4 mean = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};
-        if (cnt[j] > 0) {
-          const float fc = (float)cnt[j], inv = 1.f / fc;
-          const f32x4 dmean = ua_div(s, fc, inv);
-          mean = v0 + dmean;
-          const f32x4 var = ua_div(s2, fc, inv) - dmean * dmean;
+        f32x4 mean = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f}, mnv = {0.f, 0.f, 0.f, 0.f}, mxv = {0.f, 0.f, 0.f, 0.f};
+        if (deg > 0) {
+          const float fc = (float)deg, inv = 1.f / fc;
           const float thr = 0.0031622776601683794f;   // PyG StdAggregation: clamp(min=1e-5).sqrt(), 0 where <= sqrt(1e-5)
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const float o = sqrtf(fmaxf(var[t], 1e-5f));
+            const float dmean = ua_div1(s[t], fc, inv);
+            mean[t] = v0[t] + dmean;
+            const float var = ua_div1(s2[t], fc, inv) - dmean * dmean;
+            const float o = sqrtf(fmaxf(var, 1e-5f));
             sd[t] = o <= thr ? 0.f : o;
+            mnv[t] = mn[t];
+            mxv[t] = mx[t];
           }
-        } else {
-          mn = f32x4{0.f, 0.f, 0.f, 0.f};
-          mx = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         out[0][h] = mean;
-        out[1][h] = mn;
-        out[2][h] = mx;
+        out[1][h] = mnv;
+        out[2][h] = mxv;
         out[3][h] = sd;
       }
     };
@@ -282,13 +303,18 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
     // the consumers
     issue_x(0);
     build(0, 3);     // (waits for the loads: super-step 0 starts the tile)
+    const bool pm = wave == CW;
     for (int S = 0; S < ns; ++S) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int s = 4 * S + s4;
+        if (pm) mark(0, s, 0);
         stash(s, v[s4]);
+        if (pm) mark(0, s, 1);
         build(S + 1, s4);
+        if (pm) mark(0, s, 2);
         if (s >= 1) __syncthreads();
+        if (pm) mark(0, s, 3);
       }
     }
     __syncthreads();
@@ -374,6 +400,7 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
   // interval t: B of stage t + 2 requested into buffer (t + 2) % 3 (read last in interval t - 1); MFMAs of stage t;
   // the fragments of the next k16 step (across the stage boundary too) requested ahead of the MFMAs that hide them
   auto interval = [&](int t, int buf, int next, int fill) {
+    if (wave == 0) mark(1, t, 0);
     dma_b(t + 2, fill);
     // beside the producers' slot 0 of super-step S = (t + 2) / 4 (they write stage t + 2 now): the class terms of the
     // slab super-step S + 1 is built from; its previous contents were last read two stages ago, behind a barrier
@@ -389,6 +416,7 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
     mfma(af[1], bf[1]);
     __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN, 0);
+    if (wave == 0) mark(1, t, 1);
   };
   dma_b(0, 0);
   dma_b(1, 1);
@@ -426,6 +454,8 @@ static int launch_update_agg_one(const UpdateAggArgs &a, int64_t max_tiles, hipS
   return GNNSAFT_OK;
 }
 
+static unsigned long long *g_ua_stamps = nullptr;   // development probe: see gnnsaft_debug_update_agg_stamps
+
 // does the fused form cover this hidden size?  (F a multiple of 128: super-steps of four 32-k stages; the tile rows of
 // the degree table must be a tile height built here)
 bool update_agg_supported(int hidden, int classes) {
@@ -448,6 +478,12 @@ int launch_pna_update_agg(const float *x, const float *q, const float *rtab, int
   a.q = q;
   a.rtab = rtab;
   a.classes = classes;
+  static const int prio = [] {
+    const char *e = getenv("GNNSAFT_UA_PRIO");
+    return e != nullptr && e[0] == '1' ? 1 : 0;   // (measured: no gain, 757 vs 733 us at C3)
+  }();
+  a.producer_prio = prio;
+  a.stamps = g_ua_stamps;
   a.rowptr = rowptr;
   a.src = src;
   a.combo = combo;
@@ -468,6 +504,13 @@ int launch_pna_update_agg(const float *x, const float *q, const float *rtab, int
 }
 
 }  // namespace gs
+
+// development probe (tools/update_agg_stamps.py; not part of the product path): a device buffer of 2 * 64 * 4 uint64 that
+// the next launches fill with s_memtime stamps of one tile's first producer / consumer wave; NULL switches it off
+extern "C" int gnnsaft_debug_update_agg_stamps(void *device_buffer) {
+  gs::g_ua_stamps = static_cast<unsigned long long *>(device_buffer);
+  return GNNSAFT_OK;
+}
 
 // stage-test entry point (include/gnnsaft.h): aggregation + folded update in one launch, operands as the two-launch
 // pair gnnsaft_pna_aggregate_src + gnnsaft_pna_update_folded takes them, the folded weights as W3 images

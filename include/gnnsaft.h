@@ -272,6 +272,8 @@ GNNSAFT_API int gnnsaft_pna_update_agg(const float *x, const float *q, const flo
                            const int32_t *tiles, const int32_t *num_tiles, int64_t num_nodes, int32_t hidden,
                            const void *w_eff_images, const float *b_post0, const float *b_post1, float *u,
                            gnnsaft_stream_t stream);
+/* development probe: s_memtime stamps of one tile of the fused kernel into a device buffer of 512 uint64 (NULL: off) */
+GNNSAFT_API int gnnsaft_debug_update_agg_stamps(void *device_buffer);
 /* the wave-specialised kernel (csrc/gemm_w3s.hip: consumer waves = fragment reads + MFMAs, producer waves =   */
 /* operand path); tile_config 0 = 128x128, 1 = 64x128                                                          */
 GNNSAFT_API int gnnsaft_debug_linear_w3s(const float *a, int64_t lda, const void *w_image, const float *bias, float *out,

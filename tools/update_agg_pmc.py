@@ -32,12 +32,12 @@ for name in which:
                                             w_eff.data_ptr(), torch.cuda.current_stream().cuda_stream), "fold")
     images = torch.cat([K.w3_pack(w_eff[dd, t]) for dd in range(buckets) for t in range(2)])
     u = torch.empty((n, h), dtype=torch.float32, device=DEV)
-    st = torch.cuda.current_stream().cuda_stream
 
     def fused():
         check(lib.gnnsaft_pna_update_agg(x.data_ptr(), q.data_ptr(), rtab.data_ptr(), 60, rowptr.data_ptr(), src.data_ptr(),
                                          combo.data_ptr(), perm.data_ptr(), tiles.data_ptr(), nt.data_ptr(), n, h,
-                                         images.data_ptr(), b_post[0].data_ptr(), b_post[1].data_ptr(), u.data_ptr(), st),
+                                         images.data_ptr(), b_post[0].data_ptr(), b_post[1].data_ptr(), u.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream),
               "gnnsaft_pna_update_agg")
 
     def two():
@@ -50,4 +50,5 @@ for name in which:
     torch.cuda.synchronize()
     if "time" in sys.argv:
         from tools.gemm_tune import timeit
-        print(f"{name}: fused {min(timeit(fused) for _ in range(3)):.1f} us")
+        print(f"{name}: fused {min(timeit(fused) for _ in range(3)):.1f} us, two launches {min(timeit(two) for _ in range(3)):.1f} us "
+              "(aggregation + folded update incl. its weight fold launch)")
