@@ -49,7 +49,7 @@ MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA
 MFMA_BF16_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: dense bf16 MFMA (the pipe the split-bf16 GEMMs run on)
 GEMM_X6 = os.environ.get("GNNSAFT_GEMM_X6", "1") != "0"   # csrc/gemm.hip: six bf16 MFMAs per f32-equivalent product
 K4_KERNEL = "k_pna_aggregate<2"    # (rocprofv3 prints k_pna_aggregate<2, false> / <2, true>) the kernel gnnsaft_forward launches for pre_layers == 1 (kFusedQ source)
-PROFILE_TAG = "r03"        # profiles/<tag>_* files are the rocprofv3 evidence of THIS round's kernels
+PROFILE_TAG = "r04"        # profiles/<tag>_* files are the rocprofv3 evidence of THIS round's kernels
 
 
 def k4_algorithmic_bytes(n: int, e_prime: int, hidden: int) -> int:
@@ -221,10 +221,13 @@ def roofline_blocks(wl: Workload, times, event_overhead_ms=None, fused_times=Non
         "rocprofv3_avg_launch_ms": rocprof_ms,   # from profiles/ (kernel time without the event overhead)
         "event_pair_ms_around_empty_kernel": event_overhead_ms,
         "working_set_mb": ws_mb,
-        "launched_by": "the taped (training) forward and this instrumented repeat of the timed steps; the timed no-grad "
-                       "forward itself fuses the aggregation into the update GEMM's operand path (k_update_agg_w3s, "
-                       "`roofline_gemm.fused_update_agg`) where the shape allows (hidden % 128 == 0), so that the "
-                       "aggregates never reach HBM",
+        "launched_by": ("the taped (training) forward and this instrumented repeat of the timed steps; the timed no-grad "
+                        "forward itself fuses the aggregation into the update GEMM's operand path (k_update_agg_w3s, "
+                        "`roofline_gemm.fused_update_agg`: from 64 k nodes up and hidden % 128 == 0), so that the "
+                        "aggregates never reach HBM"
+                        if (fused_times is not None and fused_times["k4"][0] == 0) else
+                        "every forward of this workload (timed no-grad steps, taped training forward, this instrumented "
+                        "repeat): below 64 k nodes the two launches are faster than the fused aggregation + update"),
         "how": "HIP events on the launch stream around every K4 launch of an instrumented repeat of the timed steps; "
                "`achieved` = SURVEY 8(d) algorithmic bytes / event time, `achieved_physical` = the PMC-counted HBM "
                "bytes of `traffic` / the same time.  " +

@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GNNSAFT_LIB") or os.path.join(_HERE, "lib", "libgnnsaft.so")  # override: A/B runs of two builds
 
 MAX_TABLES = 16
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ModelDesc(ctypes.Structure):
@@ -37,6 +37,7 @@ class ModelDesc(ctypes.Structure):
         ("fold_dst_term", c_int32), ("save_tape", c_int32), ("unfused_readout", c_int32), ("bn_eps_f64", ctypes.c_double),
         ("debug_barrier_extra", c_int32), ("readout_dropout", c_float), ("dropout_seed", ctypes.c_uint64),
         ("unfused_bn_apply", c_int32), ("persistent_sync_words", c_int32),
+        ("dropout_step", c_void_p),
     ]
 
 

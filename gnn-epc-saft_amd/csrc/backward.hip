@@ -892,6 +892,7 @@ extern "C" int gnnsaft_backward(const gnnsaft_model_desc *d, const void *const *
     rp.barrier_extra = d->debug_barrier_extra;
     rp.dropout_p = d->training ? d->readout_dropout : 0.f;
     rp.dropout_seed = d->dropout_seed;
+    rp.dropout_step = d->dropout_step;
     GS_TRY(launch_readout_bwd_fused(rp, sq, st));
     GS_TRY(launch_slab_queue_flush(sq, st));
   } else {

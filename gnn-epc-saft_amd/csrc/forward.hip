@@ -882,6 +882,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     rp.barrier_extra = d->debug_barrier_extra;
     rp.dropout_p = d->readout_dropout;
     rp.dropout_seed = d->dropout_seed;
+    rp.dropout_step = d->dropout_step;
     return launch_readout_fused(rp, st);
   }
   // ---- readout (per-op: no dropout kernel here -- the one-launch readout carries it)

@@ -7,8 +7,8 @@
 // (v_mfma_f32_32x32x2_f32, weights straight from L2 -- they total < 100 KB -- in the k order of gemm.hip), and writes
 // the outputs.  Train-mode BatchNorm needs column statistics over ALL graphs: every workgroup publishes the (mean, M2)
 // of its 64 rows, the grid meets at a device-scope barrier (release / acquire atomics on a counter zeroed by the
-// forward's prologue kernel), and every workgroup folds the <= 256 partials itself (f64, same pivot scheme as
-// bn_train.hip).  The barrier is only safe while all workgroups are co-resident: the launcher uses this kernel for up
+// forward's prologue kernel), and every workgroup folds the <= 256 partials itself (plain f64 sums S1, S2 of
+// bn_fold.hpp -- no pivot: see its header for the error budget).  The barrier is only safe while all workgroups are co-resident: the launcher uses this kernel for up
 // to as many workgroups as the device's occupancy calculator says are co-resident (readout_resident_workgroups:
 // hipOccupancyMaxActiveBlocksPerMultiprocessor x CU count, per device) and the per-op path beyond.  What the calculator
 // cannot see -- another process on the GPU, a CU mask -- ends in the bounded spin: the kernel then raises
@@ -64,6 +64,7 @@ struct ReadoutArgs {
   int barrier_extra;         // 0; > 0 (test hook): the barriers expect that many arrivals more than there are workgroups
   float dropout_p;           // 0: no dropout (or eval mode)
   uint64_t dropout_seed;
+  const uint64_t *dropout_step;   // or null: device word mixed into the key when the kernel runs (hipGraph replays)
 };
 
 // all workgroups of the grid meet here; returns true after every one of them has arrived, false when the spin bound
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_fused(ReadoutArgs a) {
       v.y = fmaxf(v.y, 0.f);
       v.z = fmaxf(v.z, 0.f);
       v.w = fmaxf(v.w, 0.f);
-      if (a.dropout_p > 0.f) v = v * dropout_scale4(a.dropout_seed, row0 + r, b, c4, a.dropout_p);   // block-uniform
+      if (a.dropout_p > 0.f) v = v * dropout_scale4(rd_key(a.dropout_seed, a.dropout_step), row0 + r, b, c4, a.dropout_p);   // block-uniform
       gs_st4(at + r * ld + c4, v);
       if (a.ro != nullptr && r < rows) gs_st4(a.ro + b * rs + (row0 + r) * n_out + c4, v);
     }
@@ -376,6 +377,7 @@ struct ReadoutBwdArgs {
   int barrier_extra;
   float dropout_p;
   uint64_t dropout_seed;
+  const uint64_t *dropout_step;
 };
 
 // slab[n][k] = sum over this workgroup's 64 rows of dy[r][n] * in[r][k]: 32 x 32 output tiles round-robin over the
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(kRdThreads) void k_readout_bwd_fused(ReadoutBwdArgs
         const f32x4 mean = gs_ld4(stat + c4), rstd = gs_ld4(stat + n_out + c4);
         const f32x4 gm = gs_ld4(a.gamma[b] + c4), bt = gs_ld4(a.beta[b] + c4);
         f32x4 dv = gs_ld4(dt + r * ld + c4);
-        if (a.dropout_p > 0.f) dv = dv * dropout_scale4(a.dropout_seed, row0 + r, b, c4, a.dropout_p);   // the forward's mask
+        if (a.dropout_p > 0.f) dv = dv * dropout_scale4(rd_key(a.dropout_seed, a.dropout_step), row0 + r, b, c4, a.dropout_p);   // the forward's mask
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           yh[j] = (y[j] - mean[j]) * rstd[j];
@@ -729,6 +731,7 @@ int launch_readout_fused(const ReadoutFusedParams &p, hipStream_t st) {
   GS_REQUIRE(p.dropout_p >= 0.f && p.dropout_p < 1.f, GNNSAFT_ERR_SHAPE);
   a.dropout_p = p.training ? p.dropout_p : 0.f;
   a.dropout_seed = p.dropout_seed;
+  a.dropout_step = p.dropout_step;
   const size_t lds = rd_fwd_lds(p.h);   // (the dynamic-LDS limit of this device was raised by the residency query)
   hipLaunchKernelGGL(k_readout_fused, dim3((unsigned)wgs), dim3(kRdThreads), lds, st, a);
   GS_CHECK_LAUNCH();
@@ -782,6 +785,7 @@ int launch_readout_bwd_fused(const ReadoutBwdParams &p, SlabQueue &q, hipStream_
   a.barrier_extra = p.barrier_extra > 0 ? p.barrier_extra : 0;
   a.dropout_p = p.dropout_p;
   a.dropout_seed = p.dropout_seed;
+  a.dropout_step = p.dropout_step;
   a.part = p.scratch;
   a.bias_part = p.scratch + (size_t)p.nblocks * wgs * 2 * p.h;
   GS_REQUIRE(a.w_final != nullptr && a.dbias_final != nullptr, GNNSAFT_ERR_NULL);

@@ -27,6 +27,7 @@ struct ReadoutFusedParams {
   int barrier_extra;                      // test hook (desc->debug_barrier_extra): arrivals the barriers wait for in vain
   float dropout_p;                        // Dropout behind every ReLU of the readout (models.py:88,95,99); training only
   uint64_t dropout_seed;                  // Philox key of this call's masks
+  const uint64_t *dropout_step = nullptr; // device word mixed into the key at run time (gnnsaft_model_desc), or null
 };
 
 // Backward of the readout in one launch (k_readout_bwd_fused): per-workgroup partial weight gradients go to `q`'s
@@ -49,6 +50,7 @@ struct ReadoutBwdParams {
   int barrier_extra;                         // test hook, as in the forward
   float dropout_p;                           // the forward's Dropout: the masks are regenerated from the same key
   uint64_t dropout_seed;
+  const uint64_t *dropout_step = nullptr;    // as in the forward
 };
 
 // Dropout masks of the readout: Philox4x32-10 keyed by the call's seed, counter = (graph row, block, column / 4):
@@ -73,6 +75,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[3] = c3;
 }
 // keep-scale factors (0 or 1 / (1 - p)) of columns c4 .. c4 + 3 of (row, block)
+// the key of THIS run of the kernel: the call's seed, plus -- under hipGraph replay, where the seed is a frozen kernel
+// argument -- a device word the caller bumps in front of every replay (times an odd constant: distinct keys)
+__device__ __forceinline__ uint64_t rd_key(uint64_t seed, const uint64_t *step) {
+  return step != nullptr ? seed + step[0] * 0x9E3779B97F4A7C15ull : seed;
+}
+
 __device__ __forceinline__ f32x4 dropout_scale4(uint64_t seed, int64_t row, int block, int c4, float p) {
   uint32_t r[4];
   philox4x32_10((uint32_t)row, (uint32_t)((uint64_t)row >> 32), (uint32_t)block, (uint32_t)(c4 >> 2), (uint32_t)seed,

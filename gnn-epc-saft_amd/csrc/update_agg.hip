@@ -59,12 +59,28 @@ __device__ __forceinline__ float ua_div1(float x, float c, float inv) {
   return __builtin_fmaf(r, inv, qe);
 }
 
+// the same for ONE float4 slice: 8 bytes of each plane (PW = 8: two lanes share a chunk)
+__device__ __forceinline__ void ua_split_store_half(char *p, int plane, const f32x4 v0) {
+  uint32_t e[4], m1[4], m2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    e[t] = __float_as_uint(v0[t]);
+    const float r1 = v0[t] - __uint_as_float(e[t] & 0xffff0000u);
+    m1[t] = __float_as_uint(r1);
+    m2[t] = __float_as_uint(r1 - __uint_as_float(m1[t] & 0xffff0000u));
+  }
+  *reinterpret_cast<uint2 *>(p) = uint2{ua_pack2(e[0], e[1]), ua_pack2(e[2], e[3])};
+  *reinterpret_cast<uint2 *>(p + plane) = uint2{ua_pack2(m1[0], m1[1]), ua_pack2(m1[2], m1[3])};
+  *reinterpret_cast<uint2 *>(p + 2 * plane) = uint2{ua_pack2(m2[0], m2[1]), ua_pack2(m2[2], m2[3])};
+}
+
 struct UpdateAggArgs {
   const float *x;        // [N, F] node state
   const float *q;        // [N, 2F] source terms of both towers
   const float *rtab;     // [classes, 2F] edge-class terms
   int classes;           // <= kUaMaxClasses
   int producer_prio;     // 1: s_setprio 1 for the producer waves
+  int debug_var;         // development probe (GNNSAFT_UA_VAR; garbage results): 1 consumers idle, 2 no reductions, 4 no gathers, 8 no stash
   unsigned long long *stamps;   // development probe (tools/update_agg_stamps.py) or null: s_memtime stamps of tile 5
   const int32_t *rowptr, *src, *combo;          // destination-sorted CSR (self-loop rows included)
   const int32_t *perm, *tiles, *num_tiles;      // degree tiles (degree.hip)
@@ -81,18 +97,21 @@ struct UaRows {
   __device__ __forceinline__ int64_t out_row(const TileInfo &t, int lr) const { return perm[t.row0 + lr]; }
 };
 
-constexpr int kUaProducerWaves = 4;
 constexpr int kUaEdgeBatch = 4;   // gathers in flight per lane and row
 constexpr int kUaMaxClasses = 64; // edge classes whose slab of the class-term table fits the LDS left over (the reference: 60)
 
-template <int BM, int BN, int CW_M, int CW_N>
-__global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_update_agg_w3s(UpdateAggArgs a) {
+// PW producer waves: 4 -- a lane owns a whole 16-byte chunk (two float4 column slices) of its rows -- or 8 -- two lanes
+// share a chunk, one float4 slice each (half the serial work per wave, two producer waves per SIMD: a single wave's
+// dependent VALU / LDS stream issues at 5-7 cycles per instruction, measured with the consumers idle)
+template <int BM, int BN, int CW_M, int CW_N, int PW>
+__global__ __launch_bounds__(64 * (CW_M * CW_N + PW)) void k_update_agg_w3s(UpdateAggArgs a) {
   constexpr int CW = CW_M * CW_N;
-  constexpr int PW = kUaProducerWaves;
+  static_assert(PW == 4 || PW == 8, "four or eight producer waves");
+  constexpr int HH = 8 / PW;                     // float4 column slices per lane and (row, stage): 2 or 1
   constexpr int WTM = BM / CW_M, WTN = BN / CW_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile is a multiple of the 32x32 MFMA");
-  constexpr int RPP = PW * 64 / 4;               // 64 rows per producer pass
+  constexpr int RPP = 64;                        // rows per producer pass: PW lanes per row
   constexpr int R = BM / RPP;                    // rows per producer thread
   static_assert(R >= 1 && BM % RPP == 0, "the A tile is a whole number of producer passes");
   constexpr int PLANE = (BM + BN) * kW3RowBytes;
@@ -130,9 +149,10 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
     // an MFMA needs the port 8 cycles in 32 and its pipe keeps running meanwhile -- MI355X_MICROARCH.md, two waves per SIMD)
     if (getenv_prio) __builtin_amdgcn_s_setprio(1);
     const int ptid = tid - CW * 64;
-    const int q = ptid & 3;
-    const int r0 = ptid >> 2;
-    const int a_lds = r0 * kW3RowBytes + w3_chunk_pos(q, r0) * 16;
+    const int q = ptid & 3;                       // chunk of the row's 32 k
+    const int h0 = HH == 1 ? (ptid / 4) & 1 : 0;  // PW = 8: which float4 slice of the chunk this lane owns
+    const int r0 = ptid / PW;
+    const int a_lds = r0 * kW3RowBytes + w3_chunk_pos(q, r0) * 16 + h0 * 8;
     const float *xrow[R];
     int beg[R], cnt[R], sidx[R][kUaEdgeBatch], cidx[R][kUaEdgeBatch];
 #pragma unroll
@@ -154,17 +174,17 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
     // values of the four stages of the CURRENT super-step: [stage][row][half] -- one 16-byte chunk of 8 k per
     // (stage, row); the loads of the NEXT super-step in flight: [row][edge | stage][half]; row 0 of the next super-step
     // reduced one stage early (its stage slots in `v` are still waiting for their buffers)
-    f32x4 v[4][R][2], g[R][kUaEdgeBatch][2], t0[4][2];
+    f32x4 v[4][R][HH], g[R][kUaEdgeBatch][HH], t_std[HH];
     static_assert(kUaEdgeBatch == 4, "the in-flight registers double as the four x stages of a super-step");
 
     auto issue_x = [&](int S) {            // x columns 128 S .. 128 S + 127: plain loads, all rows
 #pragma unroll
       for (int j = 0; j < R; ++j)
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          g[j][s4][0] = gs_ld4(xrow[j] + 128 * S + 32 * s4 + 4 * q);
-          g[j][s4][1] = gs_ld4(xrow[j] + 128 * S + 32 * s4 + 16 + 4 * q);
-        }
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int hh = 0; hh < HH; ++hh)
+            g[j][s4][hh] = gs_ld4(xrow[j] + 128 * S + 32 * s4 + 4 * q + 16 * (HH == 2 ? hh : h0));
     };
     // (32-bit byte offsets from a uniform base instead of the 64-bit address per gather: measured SLOWER, 778 vs 733 us
     // at C3 -- the saddr form's scheduling, not the address arithmetic, is what the gathers wait for)
@@ -173,10 +193,10 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
 #pragma unroll
       for (int j = 0; j < R; ++j)
 #pragma unroll
-        for (int e = 0; e < kUaEdgeBatch; ++e) {
-          g[j][e][0] = gs_ld4(qt + (int64_t)sidx[j][e] * (2 * f) + cb);
-          g[j][e][1] = gs_ld4(qt + (int64_t)sidx[j][e] * (2 * f) + cb + 16);
-        }
+        for (int e = 0; e < kUaEdgeBatch; ++e)
+#pragma unroll
+          for (int hh = 0; hh < HH; ++hh)
+            g[j][e][hh] = gs_ld4(qt + (int64_t)sidx[j][e] * (2 * f) + cb + 16 * (HH == 2 ? hh : h0));
     };
     const char *rl = lds + kRtabLds + (4 * q) * 4;    // this lane's columns of the slab's class rows
     // the reduction of k_pna_aggregate<kFusedQ> (aggregate.hip) on the lane's two float4 column slices of row j:
@@ -185,16 +205,18 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
     // free of per-lane masks.  Degrees the table clamps -- >= kDegreeBuckets, flagged GNNSAFT_FLAG_BAD_DEGREE -- are
     // garbage in, garbage out on either path.)
     const int deg = tt[0];
-    auto reduce = [&](int c, int j, f32x4(&out)[4][2]) {
+    auto reduce = [&](int c, int j, f32x4(&o_mean)[HH], f32x4(&o_min)[HH], f32x4(&o_max)[HH], f32x4(&o_std)[HH]) {
       const float inf = __builtin_huge_valf();
       // the class terms of the lane's columns for the first edges, all requested before the first is needed
-      f32x4 tr[kUaEdgeBatch][2];
+      f32x4 tr[kUaEdgeBatch][HH];
 #pragma unroll
       for (int e = 0; e < kUaEdgeBatch; ++e)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) tr[e][h] = *reinterpret_cast<const f32x4 *>(rl + cidx[j][e] * 128 + 64 * h);
+        for (int h = 0; h < HH; ++h)
+          tr[e][h] = *reinterpret_cast<const f32x4 *>(rl + cidx[j][e] * 128 + 64 * (HH == 2 ? h : h0));
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < HH; ++h) {
+        const int hsel = HH == 2 ? h : h0;
         // scalar floats on purpose: on f32x4 values hipcc emits packed-f32 VALU (v_pk_add_f32 / v_pk_mul_f32), which
         // costs extra issue cycles beside the consumer wave's MFMAs on the same SIMD (MI355X_MICROARCH.md)
         float s[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -216,10 +238,10 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
           }
         }
         for (int e = kUaEdgeBatch; e < deg; ++e) {   // in-degrees above the batch (a 4-valent atom's self-loop): on the spot
-          const int cb = 32 * c + 4 * q + 16 * h;
+          const int cb = 32 * c + 4 * q + 16 * hsel;
           const int r = beg[j] + e;
           const f32x4 mq = gs_ld4(qt + (int64_t)a.src[r] * (2 * f) + cb);
-          const f32x4 mt = *reinterpret_cast<const f32x4 *>(rl + a.combo[r] * 128 + 64 * h);
+          const f32x4 mt = *reinterpret_cast<const f32x4 *>(rl + a.combo[r] * 128 + 64 * hsel);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const float m = mq[t] + mt[t];
@@ -245,15 +267,15 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
             mxv[t] = mx[t];
           }
         }
-        out[0][h] = mean;
-        out[1][h] = mnv;
-        out[2][h] = mxv;
-        out[3][h] = sd;
+        o_mean[h] = mean;
+        o_min[h] = mnv;
+        o_max[h] = mxv;
+        o_std[h] = sd;
       }
     };
     // the piece of building super-step S that rides in stage slot s4 of the super-step before it (called AFTER the
-    // slot's own stage left `v`): loads requested in slot 0; row 0 reduced in slot 2 into `t0`; in slot 3, with all of
-    // `v` written out, `v` takes the next super-step's values.  The slab's class terms were copied to LDS by the
+    // slot's own stage left `v`): loads requested in slot 0; row 0 reduced in slot 2; in slot 3, with all of `v` written
+    // out, row 1 (and the x values of an x super-step).  The slab's class terms were copied to LDS by the
     // consumers in the interval that runs beside slot 0.
     auto build = [&](int S, int s4) {
       if (S >= ns) return;                 // (block-uniform)
@@ -262,41 +284,37 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
       if (s4 == 0) {
         if (is_x)
           issue_x(S);
-        else
+        else if ((a.debug_var & 4) == 0)
           issue_gather(c);
       }
-      if (s4 == 2 && !is_x) reduce(c, 0, t0);
+      if ((a.debug_var & 2) != 0 && !is_x) return;
+      // row 0 in slot 2: the stage slots 0..2 of `v` have been written out by then, only its std waits one more slot
+      if (s4 == 2 && !is_x) reduce(c, 0, v[0][0], v[1][0], v[2][0], t_std);
       if (s4 == 3) {
         if (is_x) {
 #pragma unroll
           for (int j = 0; j < R; ++j)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              v[u][j][0] = g[j][u][0];
-              v[u][j][1] = g[j][u][1];
-            }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int hh = 0; hh < HH; ++hh) v[u][j][hh] = g[j][u][hh];
         } else {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            v[u][0][0] = t0[u][0];
-            v[u][0][1] = t0[u][1];
-          }
-          if constexpr (R == 2) {
-            reduce(c, 1, t0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              v[u][1][0] = t0[u][0];
-              v[u][1][1] = t0[u][1];
-            }
-          }
+          for (int hh = 0; hh < HH; ++hh) v[3][0][hh] = t_std[hh];
+          if constexpr (R == 2) reduce(c, 1, v[0][1], v[1][1], v[2][1], v[3][1]);
           static_assert(R <= 2, "at most two rows per producer lane");
         }
       }
     };
-    auto stash = [&](int s, const f32x4(&vs)[R][2]) {   // stage s -> buffer s % 3
+    auto stash = [&](int s, const f32x4(&vs)[R][HH]) {   // stage s -> buffer s % 3
       char *st = lds + (s % 3) * STAGE + a_lds;
 #pragma unroll
-      for (int j = 0; j < R; ++j) ua_split_store(st + j * (RPP * kW3RowBytes), PLANE, vs[j][0], vs[j][1]);
+      for (int j = 0; j < R; ++j) {
+        if constexpr (HH == 2)
+          ua_split_store(st + j * (RPP * kW3RowBytes), PLANE, vs[j][0], vs[j][1]);
+        else
+          ua_split_store_half(st + j * (RPP * kW3RowBytes), PLANE, vs[j][0]);
+      }
     };
     // stage s is written into its buffer during interval s - 2, i.e. after the barrier that closes interval s - 3 (the
     // buffer's last reader): one barrier behind every stage but the first, two more at the end -- 1 + nk in all, as
@@ -309,7 +327,7 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
       for (int s4 = 0; s4 < 4; ++s4) {
         const int s = 4 * S + s4;
         if (pm) mark(0, s, 0);
-        stash(s, v[s4]);
+        if ((a.debug_var & 8) == 0) stash(s, v[s4]);
         if (pm) mark(0, s, 1);
         build(S + 1, s4);
         if (pm) mark(0, s, 2);
@@ -401,6 +419,7 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
   // the fragments of the next k16 step (across the stage boundary too) requested ahead of the MFMAs that hide them
   auto interval = [&](int t, int buf, int next, int fill) {
     if (wave == 0) mark(1, t, 0);
+    if ((a.debug_var & 1) != 0) return;
     dma_b(t + 2, fill);
     // beside the producers' slot 0 of super-step S = (t + 2) / 4 (they write stage t + 2 now): the class terms of the
     // slab super-step S + 1 is built from; its previous contents were last read two stages ago, behind a barrier
@@ -441,15 +460,15 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + kUaProducerWaves)) void k_updat
   gemm_epilogue<TM, TN, WTM, WTN, BM, BN, CW_M, false, false, false>(acc, rows, ti, ent, epi, n0, n_pad, (int64_t)f, wm, wn, lane);
 }
 
-template <int BM, int BN, int CWM, int CWN>
+template <int BM, int BN, int CWM, int CWN, int PW>
 static int launch_update_agg_one(const UpdateAggArgs &a, int64_t max_tiles, hipStream_t stream) {
   constexpr size_t kLds = (size_t)3 * 3 * (BM + BN) * kW3RowBytes + kUaMaxClasses * 128;
   static_assert(kLds <= 160 * 1024, "three stages and a slab of class terms fit the CU's LDS");
-  auto kern = k_update_agg_w3s<BM, BN, CWM, CWN>;
+  auto kern = k_update_agg_w3s<BM, BN, CWM, CWN, PW>;
   static std::atomic<unsigned long long> raised{0ull};
   if (kLds > 64 * 1024) GS_HIP(gs_raise_dynamic_lds(reinterpret_cast<const void *>(kern), kLds, raised));
   const dim3 grid((unsigned)max_tiles, (unsigned)gs_ceil_div(a.f / 2, BN), 2u);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * (CWM * CWN + kUaProducerWaves)), kLds, stream, a);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * (CWM * CWN + PW)), kLds, stream, a);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }
@@ -484,6 +503,10 @@ int launch_pna_update_agg(const float *x, const float *q, const float *rtab, int
   }();
   a.producer_prio = prio;
   a.stamps = g_ua_stamps;
+  {
+    const char *e = getenv("GNNSAFT_UA_VAR");
+    a.debug_var = e != nullptr ? atoi(e) : 0;
+  }
   a.rowptr = rowptr;
   a.src = src;
   a.combo = combo;
@@ -499,8 +522,17 @@ int launch_pna_update_agg(const float *x, const float *q, const float *rtab, int
   a.out[0] = u;
   a.out[1] = u + hidden / 2;
   const int rows = pna_fold_tile_rows(hidden);
-  if (rows == 128) return launch_update_agg_one<128, 128, 2, 2>(a, max_tiles, stream);
-  return launch_update_agg_one<64, 64, 1, 2>(a, max_tiles, stream);
+  // GNNSAFT_UA_WAVES=16: 8 consumer (64 x 32) + 8 producer waves (two lanes per chunk) on the 128-row tile instead of
+  // 4 + 4.  Measured at C3: 775 vs 786 us per launch, the producers alone 455 vs 518 us -- the kernel's time stays near
+  // the SUM of what its two roles need alone, so halving each producer wave's serial work buys
+  // 1.5 %; the 4 + 4 form (no register spills, 512 threads) stays the default.
+  static const int wide = [] {
+    const char *e = getenv("GNNSAFT_UA_WAVES");
+    return e != nullptr && atoi(e) == 16 ? 1 : 0;
+  }();
+  if (rows == 128 && wide) return launch_update_agg_one<128, 128, 2, 4, 8>(a, max_tiles, stream);   // 8 + 8 waves
+  if (rows == 128) return launch_update_agg_one<128, 128, 2, 2, 4>(a, max_tiles, stream);
+  return launch_update_agg_one<64, 64, 1, 2, 4>(a, max_tiles, stream);
 }
 
 }  // namespace gs

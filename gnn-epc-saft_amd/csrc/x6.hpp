@@ -9,7 +9,12 @@ namespace gs {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// a = hi + mid + lo exactly, each with 8 significand bits (the upper half of an f32 word): truncation splits
+// a = hi + mid + lo exactly, each with 8 significand bits (the upper half of an f32 word): truncation splits.
+// Non-finite operands: a = +-inf gives hi = +-inf and mid = NaN (inf - inf), so every output the element contributes
+// to is NaN where an f32 fma chain would keep +-inf (or produce NaN itself against a zero weight); NaN stays NaN.  Both
+// say "not a number came in" -- a select per element to keep the infinity would cost a tenth of the split's VALU
+// work on every finite element (tests/test_gpu_folded.py pins the behaviour).  Subnormal lo parts keep their value:
+// the split is by subtraction, bf16 has the f32 exponent range.
 __device__ __forceinline__ void gs_split3(float a, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
   hi = __float_as_uint(a) & 0xffff0000u;
   const float r1 = a - __uint_as_float(hi);          // exact: the low 16 significand bits

@@ -203,6 +203,7 @@ class GraphedTrainingStep:
     def __call__(self) -> torch.Tensor:
         """One replay = one optimizer step; returns the (static) loss tensor of that step."""
         self.opt.prepare_replay()
+        self.lit.model.bump_dropout_step()     # (readout dropout: fresh masks per replay; no-op without dropout)
         self.graph.replay()
         if self.sched is not None:
             self.sched.step()

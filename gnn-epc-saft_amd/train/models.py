@@ -196,6 +196,7 @@ class PNAPCSAFT(nn.Module):
         # bottleneck); False = combine + apply everywhere.  All three give the same bits.
         self.fused_batchnorm = "pool"
         self._debug_barrier_extra = 0   # tests only: make the fused readout's grid barriers time out
+        self._dropout_step = None       # device int64: mixed into the dropout key by kernels replayed from a hipGraph
         # Per-graph fused kernel (csrc/graph_eval.hip: one workgroup per molecule, whole network in one launch):
         # always for float64 modules; for float32 in eval mode without autograd when the input has at most this many
         # graphs and nodes.  Measured on MI355X (tools/single_molecule_latency.py, default model H=64 L=6): one
@@ -289,10 +290,16 @@ class PNAPCSAFT(nn.Module):
         if d.readout_dropout > 0.0:
             if not 0.0 <= d.readout_dropout < 1.0:
                 raise ValueError("dropout must be in [0, 1)")
-            if torch.cuda.is_current_stream_capturing():
-                raise NotImplementedError("readout dropout under hipGraph capture would replay ONE mask for ever (the "
-                                          "Philox key is a kernel argument): train with dropout eagerly")
             d.dropout_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            if torch.cuda.is_current_stream_capturing():
+                # the seed is a kernel argument, frozen in the graph: the kernels add a DEVICE word to it when they
+                # run, which bump_dropout_step() advances in front of every replay (GraphedTrainingStep does)
+                if self._dropout_step is None:
+                    raise RuntimeError("readout dropout under hipGraph capture: run one eager training forward first "
+                                       "(it allocates the device word the replays' masks are keyed by)")
+                d.dropout_step = self._dropout_step.data_ptr()
+            elif self._dropout_step is None or self._dropout_step.device != torch.device("cuda", torch.cuda.current_device()):
+                self._dropout_step = torch.zeros(1, dtype=torch.int64, device="cuda")
         return d
 
     def _check_mode(self, x: torch.Tensor) -> None:
@@ -603,6 +610,13 @@ class PNAPCSAFT(nn.Module):
             if params:
                 return _PNAForwardFunction.apply(self, data, weights, *params)
         return self._launch(data, None, tape=False)[0]
+
+    def bump_dropout_step(self) -> None:
+        """In front of every replay of a hipGraph that holds a training forward with readout dropout (on the replay's
+        stream): the kernels mix this device word into their Philox key, so that every replay draws fresh masks and
+        its backward regenerates exactly those."""
+        if self._dropout_step is not None:
+            self._dropout_step.add_(1)
 
     def input_error_flags(self) -> int:
         """Synchronises, returns and clears the OR of the GNNSAFT_FLAG_* bits raised by the forwards since the

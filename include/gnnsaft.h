@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GNNSAFT_ABI_VERSION 4
+#define GNNSAFT_ABI_VERSION 5
 
 /* The library is built with -fvisibility=hidden: only the functions declared  */
 /* in this header (GNNSAFT_API) are exported; kernels, launchers and helpers   */
@@ -244,6 +244,11 @@ GNNSAFT_API int gnnsaft_pna_update_folded(const float *x, const float *agg, cons
                               const int32_t *tiles, const int32_t *num_tiles, int64_t num_nodes,
                               int32_t hidden, const float *w_eff, const float *b_post0,
                               const float *b_post1, float *u, gnnsaft_stream_t stream);
+/* Envelope of every GEMM entry point (gnnsaft_linear, gnnsaft_pna_*, gnnsaft_forward): outputs and residuals are    */
+/* addressed with 32-bit ELEMENT offsets, (rows + 1) * leading dimension < 2^31 (e.g. 4 M edge rows at 2H = 512);       */
+/* beyond it the call returns GNNSAFT_ERR_SHAPE -- split the rows.  Non-finite operands in split-bf16 mode (the        */
+/* default): +-inf or NaN anywhere in a row of A (or of W) makes the outputs it contributes to NaN (an f32 fma chain   */
+/* would keep some of them +-inf).                                                                                     */
 /* tuning / test hook: gnnsaft_linear (no epilogue options) with an explicit tile configuration    */
 /* 0..5 = 256x32, 128x64, 128x128, 64x64, 64x128, 128x32; per call, the library keeps no global state */
 GNNSAFT_API int gnnsaft_debug_linear_tile(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
@@ -366,6 +371,10 @@ typedef struct gnnsaft_model_desc {
                                /* one word): the launches.  Calls that share the words must be ordered (one stream, or  */
                                /* events between streams); not for several PROCESSES sharing one GPU (their waits lose  */
                                /* scheduling quanta: correct, but several times slower than the launches).             */
+  const uint64_t *dropout_step; /* NULL, or a DEVICE word added (times an odd constant) to dropout_seed by the kernels when */
+                               /* they run: a forward captured in a hipGraph draws fresh dropout masks on every replay   */
+                               /* if the caller bumps the word in front of it (stream-ordered); gnnsaft_backward, given  */
+                               /* the same descriptor, regenerates the masks of the replay it belongs to.               */
 } gnnsaft_model_desc;
 
 GNNSAFT_API int32_t gnnsaft_num_weights(const gnnsaft_model_desc *desc);

@@ -204,6 +204,34 @@ def test_fused_aggregate_update_equals_the_two_launches(hidden, graphs, loops):
     assert float(diff.max()) <= 2e-6
 
 
+@pytest.mark.parametrize("kind", ["x6 in-kernel split", "f32 matrix cores", "w3 images"])
+def test_non_finite_operands_poison_only_their_own_rows(kind):
+    """what a +-inf / NaN operand does in the GEMMs, pinned.  Every arithmetic mode returns non-finite
+    values in exactly the rows that hold a non-finite A element (and nowhere else); the split-bf16 modes return NaN
+    there (inf = hi, mid = inf - inf = NaN: csrc/x6.hpp), the f32 fma chain +-inf or NaN."""
+    torch.manual_seed(3)
+    m, k, n_out = 300, 128, 128
+    a = torch.randn(m, k)
+    a[7, 5] = float("inf")
+    a[100, 64] = float("-inf")
+    a[201, 127] = float("nan")
+    w, b = torch.randn(n_out, k) / math.sqrt(k), torch.randn(n_out)
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    if kind.startswith("w3"):
+        out = K().linear_w3(ad, K().w3_pack(wd), n_out, bd, 0).cpu()
+    else:
+        out = K().linear(ad, wd, bd, tile_config=3 + (16 if kind.startswith("x6") else 32)).cpu()
+    bad = ~torch.isfinite(out).all(dim=1)
+    assert sorted(torch.nonzero(bad).flatten().tolist()) == [7, 100, 201]
+    assert not torch.isfinite(out[[7, 100, 201]]).any()
+    if not kind.startswith("f32"):
+        assert torch.isnan(out[[7, 100, 201]]).all()
+    clean = torch.ones(m, dtype=torch.bool)
+    clean[[7, 100, 201]] = False
+    ref = a[clean].double() @ w.double().t() + b.double()
+    assert rel_err(out[clean].double(), ref) < 2e-6
+
+
 W3_TILES = ["128x128", "128x256", "64x128", "64x64", "128x64", "64x256", "128x128 double-buffered", "128x256 double-buffered",
             "wave-specialised 128x128", "wave-specialised 64x128"]
 

@@ -3,6 +3,7 @@ BatchNorm statistics across workgroups through a grid barrier) against the nine 
 (``fused_readout = False``) and against the f64 oracle (reference: models.py:84-103,133-134,191-194)."""
 
 import copy
+import math
 
 import pytest
 import torch
@@ -264,3 +265,50 @@ def test_readout_dropout_masks_statistics_and_gradients():
     with pytest.raises(NotImplementedError):
         hip(dd)
     assert hip.input_error_flags() == 0
+
+
+def test_readout_dropout_draws_fresh_masks_on_every_hipgraph_replay():
+    """a captured training forward used to be refused with readout dropout (the Philox key is a kernel
+    argument: every replay would draw ONE mask for ever).  The kernels now add a device word to the key when they run;
+    ``bump_dropout_step()`` in front of a replay gives it fresh masks, and a replay WITHOUT the bump reproduces the
+    previous one bit for bit (what the backward of a replayed step relies on to regenerate its forward's masks).
+    GraphedTrainingStep (forward + backward + optimizer in one graph) trains with dropout the same way."""
+    import gnn_epc_saft_amd as G
+    from gnn_epc_saft_amd.data.synthetic import degree_histogram, make_synthetic_batch
+    data = make_synthetic_batch(200, 77)
+    oracle = _with_dropout(oracle_model(64, 2, 1, 1, 1, 3, True, True, degree_histogram(data), seed=8), 0.3).train()
+    hip = hip_twin(copy.deepcopy(oracle))
+    dd = data.to(DEV)
+    with torch.no_grad():
+        hip(dd)                                   # eager warm-up: allocates workspace and the device word
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            hip(dd)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        stats_before = {k: v.clone() for k, v in hip.state_dict().items() if "running" in k}
+        with torch.cuda.graph(g):
+            out = hip(dd)
+        outs = []
+        for bump in (True, True, False, True):
+            if bump:
+                hip.bump_dropout_step()
+            g.replay()
+            outs.append(out.clone())
+    torch.cuda.synchronize()
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[3])     # fresh masks
+    assert torch.equal(outs[1], outs[2])                                               # same word, same masks
+    assert all(torch.isfinite(o).all() for o in outs) and hip.input_error_flags() == 0
+    assert stats_before                                                                # (train mode: statistics exist)
+    # the whole training step from one graph, with dropout
+    torch.manual_seed(5)
+    lit = G.create_model(dict(propagation_depth=2, hidden_dim=64, pre_layers=1, post_layers=1, num_mlp_layers=1, num_para=3,
+                              skip_connections=True, add_self_loops=True, dropout_rate=0.3, model="PNAL", optimizer="adam",
+                              learning_rate=1e-3, weight_decay=1e-2, warmup_steps=8, momentum=0.9),
+                         degree_histogram(data)).to(DEV)
+    conf = lit.configure_optimizers()
+    step = G.GraphedTrainingStep(lit, conf["optimizer"], dd, scheduler=conf["lr_scheduler"]["scheduler"], warmup=2)
+    losses = [float(step()) for _ in range(6)]
+    assert all(math.isfinite(v) for v in losses) and len(set(losses)) == len(losses)
+    assert lit.model.input_error_flags() == 0

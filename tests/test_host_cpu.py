@@ -31,7 +31,7 @@ def test_library_exports_every_symbol_declared_in_the_header():
     nm = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], check=True, capture_output=True, text=True)
     exported = {line.split()[-1] for line in nm.stdout.splitlines() if line.strip()}
     assert exported == declared, sorted(exported ^ declared)[:10]
-    assert _native.lib.gnnsaft_abi_version() == _native.ABI_VERSION == 4
+    assert _native.lib.gnnsaft_abi_version() == _native.ABI_VERSION == 5
     assert _native.lib.gnnsaft_error_string(-2) == b"workspace too small"
 
 

@@ -10,7 +10,7 @@ for SET in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_
   rm -rf $D
   rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $D -- python3 "$@" > /dev/null 2> $D.err || (tail -5 $D.err; true)
   F=$(find $D -name "*counter_collection.csv" | head -1)
-  if [ -n "$F" ]; then python3 tools/pmc_summary.py $F $FILT > $OUT/${TAG}_pmc_$(echo $SET | tr ' ' '_').json; fi
+  if [ -n "$F" ]; then python3 tools/pmc_summary.py $F $(echo $FILT | tr "," " ") > $OUT/${TAG}_pmc_$(echo $SET | tr ' ' '_').json; fi
   K=$(find $D -name "*kernel_trace.csv" | head -1)
   if [ -n "$K" ] && [ ! -f $OUT/${TAG}_pmc_kernel_trace.csv ]; then cp $K $OUT/${TAG}_pmc_kernel_trace.csv; fi
   rm -rf $D $D.err
