@@ -172,7 +172,7 @@ def instrumented_kernel_times(wl: Workload, steps: int, stream, barrier, fused: 
     training forward always issues); ``fused``: no aggregation events -- the no-grad forward's own schedule, in which
     the update kernel aggregates inside its operand path (k_update_agg_w3s) and `update` times THAT launch."""
     from gnn_epc_saft_amd import _native
-    mask = _native.PROF_UPDATE | _native.PROF_NODE_TERMS | _native.PROF_LIN
+    mask = _native.PROF_UPDATE | _native.PROF_NODE_TERMS | _native.PROF_LIN | _native.PROF_UPDATE_AGG
     if not fused:
         mask |= _native.PROF_AGGREGATE
     handle = ctypes.c_void_p()
@@ -197,7 +197,8 @@ def instrumented_kernel_times(wl: Workload, steps: int, stream, barrier, fused: 
         return cnt.value, (tot.value / cnt.value if cnt.value else float("nan"))
 
     out = {"k4": kernel_ms(_native.PROF_AGGREGATE), "update": kernel_ms(_native.PROF_UPDATE),
-           "node_terms": kernel_ms(_native.PROF_NODE_TERMS), "lin": kernel_ms(_native.PROF_LIN)}
+           "node_terms": kernel_ms(_native.PROF_NODE_TERMS), "lin": kernel_ms(_native.PROF_LIN),
+           "update_agg": kernel_ms(_native.PROF_UPDATE_AGG)}
     _native.lib.gnnsaft_profile_destroy(handle)
     return out, elapsed
 
@@ -225,7 +226,7 @@ def roofline_blocks(wl: Workload, times, event_overhead_ms=None, fused_times=Non
                         "forward itself fuses the aggregation into the update GEMM's operand path (k_update_agg_w3s, "
                         "`roofline_gemm.fused_update_agg`: from 64 k nodes up and hidden % 128 == 0), so that the "
                         "aggregates never reach HBM"
-                        if (fused_times is not None and fused_times["k4"][0] == 0) else
+                        if (fused_times is not None and fused_times["update_agg"][0] > 0) else
                         "every forward of this workload (timed no-grad steps, taped training forward, this instrumented "
                         "repeat): below 64 k nodes the two launches are faster than the fused aggregation + update"),
         "how": "HIP events on the launch stream around every K4 launch of an instrumented repeat of the timed steps; "
@@ -266,14 +267,14 @@ def roofline_blocks(wl: Workload, times, event_overhead_ms=None, fused_times=Non
                                           "GEMMs; the restructured path issues 16 N H^2 f32-equivalent -- the ratio is an "
                                           "algorithmic saving, not a fraction of peak",
         }
-        if fused_times is not None and fused_times["update"][0] > 0 and fused_times["k4"][0] == 0:
-            ms = fused_times["update"][1]
+        if fused_times is not None and fused_times["update_agg"][0] > 0:
+            ms = fused_times["update_agg"][1]
             two = times["k4"][1] + times["update"][1]
             flop = 10.0 * n * h * h
             gemm["fused_update_agg"] = {
                 "kernel": "k_update_agg_w3s: aggregation (k_pna_aggregate's reduction, by the producer waves) + "
                           "degree-folded update GEMM in one launch -- what the timed no-grad forward runs per layer",
-                "avg_ms": ms, "launches_timed": fused_times["update"][0],
+                "avg_ms": ms, "launches_timed": fused_times["update_agg"][0],
                 "replaces_ms": two, "replaces": "k_pna_aggregate + update GEMM launched separately (above)",
                 "bf16_mfma_tflops_issued": 6.0 * flop / (ms * 1e-3) / 1e12,
                 "frac_of_bf16_mfma_peak": 6.0 * flop / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
@@ -462,7 +463,8 @@ def main() -> None:
             try:
                 import gnn_epc_saft_amd as G
                 with torch.cuda.stream(stream):
-                    graphed = G.GraphedTrainingStep(model, opt, ddev, scheduler=sched, warmup=2)
+                    graphed = G.GraphedTrainingStep(model, opt, ddev, scheduler=sched, warmup=2, choose="auto")
+                    picked, graphed.mode = graphed.mode, "graph"     # time the replay itself ...
                     for _ in range(3):
                         graphed()
                     barrier()
@@ -471,9 +473,13 @@ def main() -> None:
                         graphed()
                     barrier()
                     eg = time.perf_counter() - t3
+                    graphed.mode = picked                            # ... and report what choose="auto" settled on
                 out["hipgraph"] = {"what": "the same step replayed from one captured hipGraph (fixed batch)",
                                    "steps": args.train_steps, "ms_per_step": eg / args.train_steps * 1e3,
-                                   "graphs_per_s": cfg["graphs"] * args.train_steps / eg}
+                                   "graphs_per_s": cfg["graphs"] * args.train_steps / eg,
+                                   "auto_choice": {"mode": picked, "trial_ms": graphed.trial_ms,
+                                                   "what": "GraphedTrainingStep(choose='auto') times replay against "
+                                                           "eager at construction and steps with the faster one"}}
             except Exception as exc:  # noqa: BLE001
                 out["hipgraph"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         return out

@@ -132,7 +132,7 @@ SIGNATURES = {
     "gnnsaft_profile_summary": (c_int32, [P, ctypes.c_uint32, POINTER(c_int32), POINTER(c_float)]),
 }
 
-PROF_AGGREGATE, PROF_UPDATE, PROF_NODE_TERMS, PROF_LIN = 1, 2, 4, 8
+PROF_AGGREGATE, PROF_UPDATE, PROF_NODE_TERMS, PROF_LIN, PROF_UPDATE_AGG = 1, 2, 4, 8, 16
 DTYPE_F32, DTYPE_F64 = 0, 1
 
 

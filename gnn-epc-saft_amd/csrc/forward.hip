@@ -517,7 +517,11 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
   const bool dst_in_prologue = fold_dst && d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS;
   // K0 as cooperating workgroups of the prologue launch: needs the caller's persistent barrier words behind err_flag
   // (gnnsaft_model_desc.persistent_sync_words), the bounded in-degree of the folded update and one stream
-  const bool k0_fused = structure_in == nullptr && aux == nullptr && d->fold_degree_scalers != 0 &&
+  // (at most kK0MaxWgs cooperating workgroups build the structure: beside 20 k nodes' worth of embedding work that
+  // hides four launch boundaries -- C2: -14 us; at C3's 164 k nodes and 492 k edges the chain becomes the launch's
+  // critical path: prologue 165 -> 255 us against 61 us of chain launches (profiles/r02_ / r04_c3_kernel_stats.csv),
+  // so from 64 k nodes up the structure is built by the launches)
+  const bool k0_fused = structure_in == nullptr && aux == nullptr && d->fold_degree_scalers != 0 && n < 65536 &&
                         d->num_layers >= 1 && d->num_layers <= GNNSAFT_MAX_FOLD_LAYERS && err_flag != nullptr &&
                         d->persistent_sync_words >= GNNSAFT_K0_SYNC_WORDS + n;
   // the edge-class tables (cenc, rtab: weights only) as workgroups of the same launch instead of two small GEMMs
@@ -786,7 +790,7 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     // update: first post-layer with scalers on load, then extra post-layers
     float *ua = u_l, *ub = F(p.u1);
     if (fuse_agg) {
-      ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
+      ProfScope ps(prof, GNNSAFT_PROF_UPDATE_AGG, st);
       GS_TRY(launch_pna_update_agg(xc, pq_l, rtab, (int)p.combos, I(p.rowptr), I(p.src), I(p.combo), I(p.perm), I(p.tiles),
                                    I(p.num_tiles), p.tile_cap, n, h, ws + p.w3eff + (size_t)l * p.w3eff_stride,
                                    bpost[0][0], bpost[1][0], ua, st));

@@ -169,7 +169,12 @@ class GraphedTrainingStep:
     after every replay, on the host, as Lightning's ``interval="step"`` does.  ``warmup`` eager steps run first, on a
     side stream, as torch's whole-network capture recipe requires -- they are real training steps."""
 
-    def __init__(self, lit: PNApcsaftL, optimizer, batch, scheduler=None, warmup: int = 3):
+    def __init__(self, lit: PNApcsaftL, optimizer, batch, scheduler=None, warmup: int = 3, choose: str = "graph",
+                 trial_steps: int = 6):
+        """``choose="auto"``: after the capture, ``trial_steps`` replays and ``trial_steps`` eager steps are timed (all of
+        them real training steps) and ``__call__`` uses the faster form from then on (``self.mode``, ``self.trial_ms``):
+        the eager step overlaps its two backward streams, a replayed graph realises only part of that overlap, so on
+        large batches the eager step can be the faster one."""
         from .optim import FusedAdamW
         if not isinstance(optimizer, FusedAdamW):
             raise TypeError("GraphedTrainingStep needs this package's FusedAdamW (optimizer='adam')")
@@ -190,6 +195,24 @@ class GraphedTrainingStep:
             self.loss = lit.training_step(batch)
             self.loss.backward()
             optimizer.step()                       # records copy + kernel; counts nothing (prepare_replay does)
+        self.mode, self.trial_ms = "graph", None
+        if choose == "auto":
+            import time
+
+            def timed(fn):
+                fn()                               # (untimed: the first eager step behind a capture re-allocates its tape)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(max(1, int(trial_steps))):
+                    fn()
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t0) / max(1, int(trial_steps)) * 1e3
+
+            g_ms, e_ms = timed(self._replay), timed(self._eager)
+            self.trial_ms = {"graph": g_ms, "eager": e_ms}
+            self.mode = "graph" if g_ms <= e_ms else "eager"
+        elif choose != "graph":
+            raise ValueError("choose must be 'graph' or 'auto'")
 
     def _eager(self):
         self.opt.zero_grad(set_to_none=True)
@@ -200,14 +223,18 @@ class GraphedTrainingStep:
             self.sched.step()
         return loss
 
-    def __call__(self) -> torch.Tensor:
-        """One replay = one optimizer step; returns the (static) loss tensor of that step."""
+    def _replay(self) -> torch.Tensor:
         self.opt.prepare_replay()
         self.lit.model.bump_dropout_step()     # (readout dropout: fresh masks per replay; no-op without dropout)
         self.graph.replay()
         if self.sched is not None:
             self.sched.step()
         return self.loss
+
+    def __call__(self) -> torch.Tensor:
+        """One optimizer step -- a replay of the captured graph (its static loss tensor), or, when ``choose="auto"``
+        found it faster, the eager step."""
+        return self._replay() if self.mode == "graph" else self._eager()
 
 
 def _get(cfg, name, default):

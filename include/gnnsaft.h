@@ -395,7 +395,8 @@ GNNSAFT_API int32_t gnnsaft_readout_resident_workgroups(int32_t hidden, int32_t 
 #define GNNSAFT_PROF_UPDATE 2      /* PNAConv update GEMM (scalers on load)   */
 #define GNNSAFT_PROF_NODE_TERMS 4  /* message node-term GEMM                  */
 #define GNNSAFT_PROF_LIN 8         /* lin GEMM (+ BN partials / epilogue)     */
-#define GNNSAFT_PROF_NUM_KERNELS 4
+#define GNNSAFT_PROF_UPDATE_AGG 16 /* fused aggregation + update launch (update_agg.hip; never while bit 1 is asked for) */
+#define GNNSAFT_PROF_NUM_KERNELS 5
 typedef struct gnnsaft_profile gnnsaft_profile;
 GNNSAFT_API int gnnsaft_profile_create(int32_t capacity, uint32_t mask, gnnsaft_profile **out);
 GNNSAFT_API void gnnsaft_profile_destroy(gnnsaft_profile *prof);

@@ -216,6 +216,37 @@ def test_c5_standin_default_model_training_loop():
     check_population(got, want32, want)
 
 
+def test_graphed_training_step_auto_choice_trains_like_eager_steps():
+    """GraphedTrainingStep(choose="auto") times replays against eager steps at construction (the graphed
+    step must never be the slower one) -- every trial step is a real training step, replay and eager step compute the
+    same bits, so whatever mix of the two ran, the trajectory equals the plain eager loop's."""
+    import gnn_epc_saft_amd as G
+    lit_a, batches, _ = _setup()
+    lit_b, _, _ = _setup()
+    batch = batches[0]
+    conf = lit_b.configure_optimizers()
+    opt_b, sched_b = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    lit_b.train()
+    graphed = G.GraphedTrainingStep(lit_b, opt_b, batch, scheduler=sched_b, warmup=2, choose="auto", trial_steps=3)
+    assert graphed.mode in ("graph", "eager") and set(graphed.trial_ms) == {"graph", "eager"}
+    print(f"auto choice: {graphed.mode}, trial ms per step {graphed.trial_ms}")
+    for _ in range(3):
+        graphed()
+    total = 2 + (1 + 3) + (1 + 3) + 3      # warm-up, the two trials (one untimed step each), the calls above
+    torch.cuda.synchronize()
+    conf = lit_a.configure_optimizers()
+    opt_a, sched_a = conf["optimizer"], conf["lr_scheduler"]["scheduler"]
+    lit_a.train()
+    for _ in range(total):
+        opt_a.zero_grad(set_to_none=True)
+        lit_a.training_step(batch).backward()
+        opt_a.step()
+        sched_a.step()
+    assert sched_b.last_epoch == sched_a.last_epoch == total
+    for (ka, va), (kb, vb) in zip(lit_a.state_dict().items(), lit_b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+
+
 @pytest.mark.parametrize("two_streams", [False, True], ids=["one-stream", "two-stream-capture"])
 def test_graphed_training_step_equals_eager_steps(two_streams):
     """GraphedTrainingStep (forward + backward + fused AdamW in one captured hipGraph, learning rate and bias
