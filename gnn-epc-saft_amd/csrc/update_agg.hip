@@ -18,6 +18,7 @@
 // Same arithmetic as k_pna_aggregate<kFusedQ> + k_gemm_w3 on its output; the f32 accumulation runs over the k stages
 // in another order (slab-major instead of aggregator-major), so results agree to rounding, not bit for bit.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 #include "gemm_epi.hpp"
@@ -205,43 +206,83 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + PW)) void k_update_agg_w3s(Upda
     // free of per-lane masks.  Degrees the table clamps -- >= kDegreeBuckets, flagged GNNSAFT_FLAG_BAD_DEGREE -- are
     // garbage in, garbage out on either path.)
     const int deg = tt[0];
-    auto reduce = [&](int c, int j, f32x4(&o_mean)[HH], f32x4(&o_min)[HH], f32x4(&o_max)[HH], f32x4(&o_std)[HH]) {
-      const float inf = __builtin_huge_valf();
-      // the class terms of the lane's columns for the first edges, all requested before the first is needed
-      f32x4 tr[kUaEdgeBatch][HH];
+    // Straight-line reduction for the in-degrees a lane's in-flight gathers cover (1 .. kUaEdgeBatch: every heavy atom
+    // with up to three bonds and its self-loop), the degree a compile-time constant: no branch per edge (each branch
+    // cost a block of register moves and made hipcc canonicalise every operand of min / max again), the first edge
+    // folded by hand (d = m - m_first is +0, its sums stay 0, min = max = m_first: what the loop of k_pna_aggregate
+    // computes, bit for bit).  Same operations in the same order as aggregate.hip otherwise.
+    auto finalize = [&](const float (&v0)[4], const float (&s)[4], const float (&s2)[4], const float (&mn)[4],
+                        const float (&mx)[4], int h, f32x4(&o_mean)[HH], f32x4(&o_min)[HH], f32x4(&o_max)[HH],
+                        f32x4(&o_std)[HH]) __attribute__((always_inline)) {
+      const float fc = (float)deg, inv = 1.f / fc;
+      const float thr = 0.0031622776601683794f;   // PyG StdAggregation: clamp(min=1e-5).sqrt(), 0 where <= sqrt(1e-5)
 #pragma unroll
-      for (int e = 0; e < kUaEdgeBatch; ++e)
+      for (int t = 0; t < 4; ++t) {
+        const float dmean = ua_div1(s[t], fc, inv);
+        o_mean[h][t] = v0[t] + dmean;
+        const float var = ua_div1(s2[t], fc, inv) - dmean * dmean;
+        const float o = sqrtf(fmaxf(var, 1e-5f));
+        o_std[h][t] = o <= thr ? 0.f : o;
+        o_min[h][t] = mn[t];
+        o_max[h][t] = mx[t];
+      }
+    };
+    auto reduce_fixed = [&](auto degc, int j, f32x4(&o_mean)[HH], f32x4(&o_min)[HH], f32x4(&o_max)[HH], f32x4(&o_std)[HH]) __attribute__((always_inline)) {
+      constexpr int DEG = decltype(degc)::value;
+      f32x4 tr[DEG][HH];
+#pragma unroll
+      for (int e = 0; e < DEG; ++e)
 #pragma unroll
         for (int h = 0; h < HH; ++h)
           tr[e][h] = *reinterpret_cast<const f32x4 *>(rl + cidx[j][e] * 128 + 64 * (HH == 2 ? h : h0));
 #pragma unroll
       for (int h = 0; h < HH; ++h) {
+        float v0[4], s[4], s2[4], mn[4], mx[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          v0[t] = g[j][0][h][t] + tr[0][h][t];
+          s[t] = 0.f;
+          s2[t] = 0.f;
+          mn[t] = v0[t];
+          mx[t] = v0[t];
+        }
+#pragma unroll
+        for (int e = 1; e < DEG; ++e)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float m = g[j][e][h][t] + tr[e][h][t];
+            const float d = m - v0[t];
+            s[t] = e == 1 ? d : s[t] + d;              // (0 + d = d)
+            s2[t] = e == 1 ? d * d : s2[t] + d * d;    // (0 + d d = d d)
+            mn[t] = fminf(mn[t], m);
+            mx[t] = fmaxf(mx[t], m);
+          }
+        finalize(v0, s, s2, mn, mx, h, o_mean, o_min, o_max, o_std);
+      }
+    };
+    // any in-degree: zero (isolated node without self-loops) and more than kUaEdgeBatch in-edges (the further ones
+    // gathered on the spot)
+    auto reduce_any = [&](int c, int j, f32x4(&o_mean)[HH], f32x4(&o_min)[HH], f32x4(&o_max)[HH], f32x4(&o_std)[HH]) __attribute__((always_inline)) {
+      const float inf = __builtin_huge_valf();
+#pragma unroll
+      for (int h = 0; h < HH; ++h) {
         const int hsel = HH == 2 ? h : h0;
-        // scalar floats on purpose: on f32x4 values hipcc emits packed-f32 VALU (v_pk_add_f32 / v_pk_mul_f32), which
-        // costs extra issue cycles beside the consumer wave's MFMAs on the same SIMD (MI355X_MICROARCH.md)
         float s[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
         float mn[4] = {inf, inf, inf, inf}, mx[4] = {-inf, -inf, -inf, -inf}, v0[4];
+        const f32x4 t0v = *reinterpret_cast<const f32x4 *>(rl + cidx[j][0] * 128 + 64 * hsel);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v0[t] = g[j][0][h][t] + tr[0][h][t];
-#pragma unroll
-        for (int e = 0; e < kUaEdgeBatch; ++e) {
-          if (e < deg) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const float m = g[j][e][h][t] + tr[e][h][t];
-              const float d = m - v0[t];
-              s[t] += d;
-              s2[t] += d * d;
-              mn[t] = fminf(mn[t], m);
-              mx[t] = fmaxf(mx[t], m);
-            }
+        for (int t = 0; t < 4; ++t) v0[t] = g[j][0][h][t] + t0v[t];
+        for (int e = 0; e < deg; ++e) {
+          f32x4 mq, mt;
+          if (e < kUaEdgeBatch) {   // (block-uniform)
+            mq = e == 0 ? g[j][0][h] : (e == 1 ? g[j][1][h] : (e == 2 ? g[j][2][h] : g[j][3][h]));
+            const int cl = e == 0 ? cidx[j][0] : (e == 1 ? cidx[j][1] : (e == 2 ? cidx[j][2] : cidx[j][3]));
+            mt = *reinterpret_cast<const f32x4 *>(rl + cl * 128 + 64 * hsel);
+          } else {
+            const int r = beg[j] + e;
+            mq = gs_ld4(qt + (int64_t)a.src[r] * (2 * f) + 32 * c + 4 * q + 16 * hsel);
+            mt = *reinterpret_cast<const f32x4 *>(rl + a.combo[r] * 128 + 64 * hsel);
           }
-        }
-        for (int e = kUaEdgeBatch; e < deg; ++e) {   // in-degrees above the batch (a 4-valent atom's self-loop): on the spot
-          const int cb = 32 * c + 4 * q + 16 * hsel;
-          const int r = beg[j] + e;
-          const f32x4 mq = gs_ld4(qt + (int64_t)a.src[r] * (2 * f) + cb);
-          const f32x4 mt = *reinterpret_cast<const f32x4 *>(rl + a.combo[r] * 128 + 64 * hsel);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const float m = mq[t] + mt[t];
@@ -252,25 +293,21 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + PW)) void k_update_agg_w3s(Upda
             mx[t] = fmaxf(mx[t], m);
           }
         }
-        f32x4 mean = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f}, mnv = {0.f, 0.f, 0.f, 0.f}, mxv = {0.f, 0.f, 0.f, 0.f};
         if (deg > 0) {
-          const float fc = (float)deg, inv = 1.f / fc;
-          const float thr = 0.0031622776601683794f;   // PyG StdAggregation: clamp(min=1e-5).sqrt(), 0 where <= sqrt(1e-5)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float dmean = ua_div1(s[t], fc, inv);
-            mean[t] = v0[t] + dmean;
-            const float var = ua_div1(s2[t], fc, inv) - dmean * dmean;
-            const float o = sqrtf(fmaxf(var, 1e-5f));
-            sd[t] = o <= thr ? 0.f : o;
-            mnv[t] = mn[t];
-            mxv[t] = mx[t];
-          }
+          finalize(v0, s, s2, mn, mx, h, o_mean, o_min, o_max, o_std);
+        } else {
+          o_mean[h] = o_min[h] = o_max[h] = o_std[h] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        o_mean[h] = mean;
-        o_min[h] = mnv;
-        o_max[h] = mxv;
-        o_std[h] = sd;
+      }
+    };
+    auto reduce = [&](int c, int j, f32x4(&o_mean)[HH], f32x4(&o_min)[HH], f32x4(&o_max)[HH], f32x4(&o_std)[HH]) __attribute__((always_inline)) {
+      static_assert(kUaEdgeBatch == 4, "one straight-line form per in-degree the in-flight gathers cover");
+      switch (deg) {   // (block-uniform)
+        case 1: reduce_fixed(std::integral_constant<int, 1>{}, j, o_mean, o_min, o_max, o_std); break;
+        case 2: reduce_fixed(std::integral_constant<int, 2>{}, j, o_mean, o_min, o_max, o_std); break;
+        case 3: reduce_fixed(std::integral_constant<int, 3>{}, j, o_mean, o_min, o_max, o_std); break;
+        case 4: reduce_fixed(std::integral_constant<int, 4>{}, j, o_mean, o_min, o_max, o_std); break;
+        default: reduce_any(c, j, o_mean, o_min, o_max, o_std); break;
       }
     };
     // the piece of building super-step S that rides in stage slot s4 of the super-step before it (called AFTER the
