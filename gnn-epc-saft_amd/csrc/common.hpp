@@ -183,6 +183,9 @@ int pna_fold_tile_rows(int hidden);
 // ---- split-bf16 GEMMs on pre-split weight images (gemm_w3.hip, w3.hpp); cfg from w3_pick_cfg / w3_cfg_for_update
 int launch_linear_w3(const float *a, int64_t lda, int nbatch, const GemmBatchEntry *entries /* .w3 set */, int n_pad,
                      int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi, hipStream_t stream, int cfg);
+// A operand in registers (gemm_ar.hip): cfg = ArCfg (w3.hpp)
+int launch_linear_ar(const float *a, int64_t lda, int nbatch, const GemmBatchEntry *entries /* .w3 set */, int n_pad,
+                     int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi, hipStream_t stream, int cfg);
 // wave-specialised form (gemm_w3s.hip): cfg 0 = 128 x 128, 1 = 64 x 128
 int launch_linear_w3s(const float *a, int64_t lda, int nbatch, const GemmBatchEntry *entries /* .w3 set */, int n_pad,
                       int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi, hipStream_t stream, int cfg);

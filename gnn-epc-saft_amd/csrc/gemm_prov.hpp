@@ -58,6 +58,8 @@ struct PlainAT {
   __device__ __forceinline__ f32x4 finish_full(const Raw &w, const Row &, int, int) const {
     return RELU ? gs_relu4(w.v) : w.v;
   }
+  // address of the float4 load() would fetch when k0 + c < k (gemm_ar.hip issues its A loads itself)
+  __device__ __forceinline__ const float *ptr(const Row &r, int k0, int c) const { return r.p + k0 + c; }
 };
 using PlainA = PlainAT<false>;       // a row-major matrix
 using PlainReluA = PlainAT<true>;    // ... with ReLU on load (the extra pre / post layers' inputs)
@@ -209,6 +211,7 @@ struct Concat2A {
     return (kt0 + c < k) ? w.v : zero;
   }
   __device__ __forceinline__ f32x4 finish_full(const Raw &w, const Row &, int, int) const { return w.v; }
+  __device__ __forceinline__ const float *ptr(const Row &r, int kt0, int c) const { return (kt0 < k0 ? r.p0 : r.p1) + kt0 + c; }
 };
 
 // Degree-folded PNAConv update: rows are grouped by in-degree (tile table from csr.hip), so
@@ -246,6 +249,10 @@ struct PostFoldA {
   }
   __device__ __forceinline__ f32x4 finish(const Raw &w, const Row &, int, int) const { return w.v; }
   __device__ __forceinline__ f32x4 finish_full(const Raw &w, const Row &, int, int) const { return w.v; }
+  __device__ __forceinline__ const float *ptr(const Row &r, int k0, int c) const {
+    const int j = k0 - f;  // wave-uniform
+    return (j < 0 ? r.px + k0 : r.pa + j) + c;
+  }
 };
 
 // Plain rows addressed through the degree permutation, weights selected per degree tile (backward of
@@ -282,6 +289,7 @@ struct PermPlainA {
     return (k0 + c < k) ? w.v : zero;
   }
   __device__ __forceinline__ f32x4 finish_full(const Raw &w, const Row &, int, int) const { return w.v; }
+  __device__ __forceinline__ const float *ptr(const Row &r, int k0, int c) const { return r.p + k0 + c; }
 };
 
 }  // namespace gs

@@ -363,6 +363,8 @@ int w3_pick_cfg(int64_t m, int n_out, int k, bool stats) {
   // measured (tools/w3_tune.py, profiles/r04_w3_tile_sweep.txt): from 64 k rows up the images win 3-5 % on every shape
   // of the forward; below, the in-kernel split with its smaller tiles is as fast or faster (latency-bound launches)
   if (m >= 65536) return n_out >= 256 ? kW3_128x256 : (n_out >= 128 ? kW3_128x128 : kW3_128x64);
+  // (A/B in the replayed C2 step, round 4: the images for the source terms below 64 k rows -- 128 x 64 tiles, 14.6 us
+  //  against 17.7 stand-alone -- moved the step by 0.3748 -> 0.3722 ms, inside the run-to-run spread: not taken)
   return -1;
 }
 

@@ -60,4 +60,7 @@ int w3_cfg_bm(int cfg);
 int w3_pick_cfg(int64_t m, int n_out, int k, bool stats);
 bool gemm_w3_enabled();   // GNNSAFT_GEMM_W3 = 0 keeps the in-kernel weight split (k_gemm_f32<X6>) everywhere
 
+// tile configurations of k_gemm_ar (gemm_ar.hip: A operand in registers, a wave owns 32 rows x all BN columns)
+enum ArCfg { kAr_128x128 = 0, kAr_128x64 = 1, kAr_64x128 = 2, kAr_64x64 = 3, kAr_256x128 = 4, kNumArCfg = 5 };
+
 }  // namespace gs

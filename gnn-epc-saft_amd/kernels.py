@@ -140,6 +140,16 @@ def linear_w3(a: torch.Tensor, w_image: torch.Tensor, n_out: int, bias: Optional
     return (out, stats) if want_stats else out
 
 
+def linear_ar(a: torch.Tensor, w_image: torch.Tensor, n_out: int, bias: Optional[torch.Tensor], tile_config: int):
+    """out = a W^T + bias on the split-bf16 kernel that keeps the A operand in registers (csrc/gemm_ar.hip); test /
+    tuning hook."""
+    m, k = a.shape
+    out = torch.empty((m, n_out), dtype=torch.float32, device=a.device)
+    check(lib.gnnsaft_debug_linear_ar(_p(a), a.stride(0), _p(w_image), _p(bias), _p(out), n_out, m, n_out, k,
+                                      int(tile_config), _stream(a)), "gnnsaft_debug_linear_ar")
+    return out
+
+
 def pna_node_terms(x: torch.Tensor, w_pre0: torch.Tensor, w_pre1: torch.Tensor) -> torch.Tensor:
     n, h = x.shape
     pq = torch.empty((n, 4 * h), dtype=torch.float32, device=x.device)

@@ -285,6 +285,15 @@ GNNSAFT_API int gnnsaft_debug_linear_w3s(const float *a, int64_t lda, const void
                              int64_t ldo, int64_t m, int32_t n_out, int32_t k, float *stats /* or NULL */,
                              int32_t tile_config, gnnsaft_stream_t stream);
 
+/* the A-operand-in-registers kernel (csrc/gemm_ar.hip: a wave owns 32 rows x all columns of the tile, loads and   */
+/* splits its own A rows, B through an LDS ring of image stages); tile_config 0..3 = 128x128, 128x64, 64x128, 64x64 */
+GNNSAFT_API int gnnsaft_debug_linear_ar(const float *a, int64_t lda, const void *w_image, const float *bias, float *out,
+                            int64_t ldo, int64_t m, int32_t n_out, int32_t k, int32_t tile_config,
+                            gnnsaft_stream_t stream);
+
+/* development probe: s_memtime stamps of one tile of k_gemm_ar into a device buffer of 256 uint64 (NULL: off) */
+GNNSAFT_API int gnnsaft_debug_ar_stamps(void *device_buffer);
+
 /* ------------------------------------------------------------------------ */
 /* BatchNorm (PyG BatchNorm -> torch BatchNorm1d, models.py:82,87,94,98,128).  */
 /* training != 0: combine the (mean, M2) partials written by gnnsaft_linear    */

@@ -204,6 +204,35 @@ def test_fused_aggregate_update_equals_the_two_launches(hidden, graphs, loops):
     assert float(diff.max()) <= 2e-6
 
 
+AR_TILES = ["128x128", "128x64", "64x128", "64x64", "256x128"]
+
+
+@pytest.mark.parametrize("cfg", range(len(AR_TILES)))
+@pytest.mark.parametrize("m,n_out,k", [(1000, 128, 128), (257, 96, 64), (300, 64, 1280), (130, 256, 32), (4099, 512, 256)])
+def test_every_ar_gemm_tile_configuration(cfg, m, n_out, k):
+    """k_gemm_ar (csrc/gemm_ar.hip: the A operand loaded and split by the lane that feeds it to the matrix core, hand-
+    issued loads with counted waits, weights through an LDS ring of image stages) in every tile shape against the f64
+    product under the bar of test_every_gemm_tile_configuration (4e-7 of sum |a||w|) and against k_gemm_w3 on the
+    same image: same k order, same six products -- equal up to the order of the k16 steps.  K of 1, 2, 8 and 40
+    stages: the three-stage loop body, its one- and two-stage tails and the requests past the end."""
+    torch.manual_seed(cfg * 7 + m)
+    a = torch.randn(m, k) * torch.logspace(-1.5, 1.5, m).view(-1, 1)
+    w, b = torch.randn(n_out, k) / math.sqrt(k), torch.randn(n_out)
+    ref = a.double() @ w.double().t() + b.double()
+    row_scale = (a.double().abs() @ w.double().abs().t() + b.double().abs())
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.to(DEV)
+    img = K().w3_pack(wd)
+    out = K().linear_ar(ad, img, n_out, bd, cfg).cpu().double()
+    w3 = K().linear_w3(ad, img, n_out, bd, 0).cpu().double()
+    f32 = K().linear(ad, wd, bd, tile_config=3 + 32).cpu().double()
+    err, err32 = (float(((o - ref).abs() / row_scale).max()) for o in (out, f32))
+    print(f"ar {AR_TILES[cfg]} [{m},{k}]x[{k},{n_out}]: max |err| / sum|a||w| = {err:.2e} (f32 chain {err32:.2e})")
+    assert not torch.isnan(out).any()
+    assert rel_err(out, ref) < 2e-6
+    assert err < 4e-7 and err <= 1.5 * err32 + 1e-8
+    assert float((out - w3).abs().max()) <= 4e-7 * float(row_scale.max())
+
+
 @pytest.mark.parametrize("kind", ["x6 in-kernel split", "f32 matrix cores", "w3 images"])
 def test_non_finite_operands_poison_only_their_own_rows(kind):
     """what a +-inf / NaN operand does in the GEMMs, pinned.  Every arithmetic mode returns non-finite
