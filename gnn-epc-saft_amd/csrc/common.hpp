@@ -279,7 +279,7 @@ size_t wgrad_post_folded_slab_bytes(int64_t tile_cap, int tile_rows, int hidden)
 // out[c, :] = sum of the rows of `a` whose class id is c (one-hot TN GEMM: deterministic, no atomics)
 int launch_sum_rows_by_class(const int32_t *cls, int num_classes, const float *a, int64_t lda, int64_t m, int k,
                              float *out, int64_t ld_out, float *slabs, size_t slab_bytes, hipStream_t st,
-                             SlabQueue *defer = nullptr);
+                             SlabQueue *defer = nullptr, int force_x6 = -1 /* 0: the f32 one-hot GEMM */);
 constexpr int kMaxTransposeBatch = 64;   // 48 B of kernel arguments per entry
 struct TransposeItem {
   const float *in;

@@ -437,6 +437,134 @@ __global__ __launch_bounds__(64 * WN * WK) void k_gemm_tn_x6(const float *__rest
     }
 }
 
+// ---- per-class row sums on the bf16 matrix cores: out[c][:] = sum of the rows of A whose class id is c.
+// (The backward's dR = OneHot(class)^T dm behind the edge-class tables, PNAConv edge_encoder + the edge columns of
+// pre_nns, /root/reference/gnnepcsaft/train/models.py:59,128.)  The one-hot operand is exact in bf16 and has no mid /
+// lo part, so only THREE of the six split products exist -- (1, hi) (1, mid) (1, lo) -- at 16x the f32 matrix-core rate:
+// the sum is then a streaming read of A (1 GB per layer at BASELINE config 3; the f32 64 x 64 kernel spent 412-438 us on
+// it = 2.4 TB/s, matrix-core-bound).  A workgroup of 4 waves owns 64 classes x 256 columns and a chunk of rows, two
+// workgroups per CU (80 KB of LDS each); a stage is 16 rows (one MFMA k16 step), every thread stages 4 rows x 4 columns
+// of A (one 1-KiB row piece per wave instruction) TWO stages ahead (64 KB in flight per CU), transposing in registers
+// as k_gemm_tn_x6 does; the one-hot image is built from the class ids (one 16-byte load per thread).  Rows in slab
+// order, slabs summed in order (k_sum_slabs_batched): bitwise reproducible, no atomics.
+constexpr int kClsX3Cols = 256, kClsX3Rows = 16, kClsX3Classes = 64;
+__global__ __launch_bounds__(256, 2) void k_class_sum_x3(const int32_t *__restrict__ cls, const float *__restrict__ a,
+                                                         int64_t lda, int64_t m, int n_out, int k,
+                                                         float *__restrict__ slabs, int64_t rows_per_z) {
+  constexpr int YIMG = kClsX3Classes * kX6RowBytes;        // one-hot image: [class][16 rows] bf16, hi plane only
+  constexpr int XPLANE = kClsX3Cols * kX6RowBytes;         // one plane of the A image: [col][16 rows]
+  constexpr int STAGE = YIMG + 3 * XPLANE;
+  extern __shared__ __attribute__((aligned(16))) char lds_cs[];   // [2 buffers][Y | X hi | X mid | X lo]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;                 // class tile (32 classes), column tiles 4 wk .. 4 wk + 3
+  const int k0 = blockIdx.x * kClsX3Cols;
+  const int64_t m_beg = (int64_t)blockIdx.z * rows_per_z;
+  int64_t m_end = m_beg + rows_per_z;
+  if (m_end > m) m_end = m;
+
+  // A staging: column group cg (4 columns), row group rg (4 rows) of the 16-row stage
+  const int cg = tid & 63, rg = tid >> 6;
+  const float *acol = a + k0 + 4 * cg;
+  // one-hot staging: class yc, rows 4 yq .. 4 yq + 3
+  const int yc = tid >> 2, yq = tid & 3;
+  f32x4 rr[2][4];
+  typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 rc[2];
+  auto fetch = [&](int64_t mrow0, f32x4(&r)[4], i32x4 &c) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t mm = mrow0 + 4 * rg + j;
+      const bool ok = mm < m_end;
+      mm = ok ? mm : m_end - 1;
+      const f32x4 v = gs_ld4(acol + mm * lda);
+      r[j] = ok ? v : zero;                                // rows past the chunk contribute nothing
+    }
+    const int64_t y0 = mrow0 + 4 * yq;                     // (m_beg and the stage are multiples of 4: aligned)
+    const i32x4 none = {-1, -1, -1, -1};
+    if (y0 + 3 < m_end) {
+      c = *reinterpret_cast<const i32x4 *>(cls + y0);
+    } else {
+      c = none;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (y0 + j < m_end) c[j] = cls[y0 + j];
+    }
+  };
+  auto pack = [](uint32_t x0, uint32_t x1) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); };   // upper halves, x0 low
+  auto stash = [&](int buf, const f32x4(&r)[4], const i32x4 &c) {
+    char *st = lds_cs + buf * STAGE;
+    {
+      char *base = st + YIMG + (4 * cg) * kX6RowBytes + rg * 8;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {   // column 4 cg + e: its four rows as one 8-byte word per plane
+        uint32_t h[4], md[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gs_split3(r[j][e], h[j], md[j], l[j]);
+        char *p = base + e * kX6RowBytes;
+        *reinterpret_cast<uint2 *>(p) = uint2{pack(h[0], h[1]), pack(h[2], h[3])};
+        *reinterpret_cast<uint2 *>(p + XPLANE) = uint2{pack(md[0], md[1]), pack(md[2], md[3])};
+        *reinterpret_cast<uint2 *>(p + 2 * XPLANE) = uint2{pack(l[0], l[1]), pack(l[2], l[3])};
+      }
+    }
+    {
+      const uint32_t one = 0x3f80u;   // bf16 1.0
+      const uint32_t w0 = (c[0] == yc ? one : 0u) | (c[1] == yc ? one << 16 : 0u);
+      const uint32_t w1 = (c[2] == yc ? one : 0u) | (c[3] == yc ? one << 16 : 0u);
+      *reinterpret_cast<uint2 *>(st + yc * kX6RowBytes + yq * 8) = uint2{w0, w1};
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int frag = (lane & 31) * kX6RowBytes + (lane >> 5) * 16;
+  auto compute = [&](int buf) {
+    const char *xs = lds_cs + buf * STAGE;
+    const bf16x8 yf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xs + (wn * 32) * kX6RowBytes + frag));
+    bf16x8 af[4][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        af[j][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(xs + YIMG + p * XPLANE + (wk * 128 + j * 32) * kX6RowBytes + frag));
+#pragma unroll
+    for (int p = 2; p >= 0; --p)   // smallest products first: (1, lo) (1, mid) (1, hi)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf, af[j][p], acc[j], 0, 0, 0);
+  };
+
+  const int64_t steps = (m_end - m_beg + kClsX3Rows - 1) / kClsX3Rows;
+  fetch(m_beg, rr[0], rc[0]);
+  fetch(m_beg + kClsX3Rows, rr[1], rc[1]);
+  stash(0, rr[0], rc[0]);
+  __syncthreads();
+  for (int64_t s = 0; s < steps; s += 2) {   // loads two stages ahead of their stash (unconditional: zeros past the end)
+    fetch(m_beg + (s + 2) * kClsX3Rows, rr[0], rc[0]);
+    compute(0);
+    stash(1, rr[1], rc[1]);
+    __syncthreads();
+    fetch(m_beg + (s + 3) * kClsX3Rows, rr[1], rc[1]);
+    if (s + 1 < steps) compute(1);
+    stash(0, rr[0], rc[0]);
+    __syncthreads();
+  }
+  // C/D: col = lane & 31 (column of A), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (class)
+  float *slab = slabs + (int64_t)blockIdx.z * n_out * (int64_t)k;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kc = k0 + wk * 128 + j * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (c < n_out) slab[(int64_t)c * k + kc] = acc[j][r];
+    }
+  }
+}
+
 // ---- post_nns weight gradient through the degree tiles (the backward twin of the degree-folded update).
 // dW_t = du_t^T cat[x, A_t, amp A_t, att A_t] has K = 13F, but amp / att are constant over a degree tile, so a
 // workgroup contracts only [x | A_t] (K = 5F) and, after every tile (rows of ONE in-degree), folds the tile's
@@ -1024,6 +1152,25 @@ static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, i
     rows_per_z = gs_ceil_div(gs_ceil_div(m, force_chunks), kTnBK) * kTnBK;
     chunks = gs_ceil_div(m, rows_per_z);
   }
+  // per-class sums of many rows: the streaming one-hot kernel (three bf16 products, 64 classes x 256 columns per
+  // workgroup, one workgroup per CU and column block)
+  bool class_x3 = false;
+  if constexpr (Y_CLASS && std::is_same_v<AProv, TnPlain>) {
+    const bool x6_on = force_x6 < 0 ? gemm_x6_enabled() : force_x6 != 0;
+    class_x3 = x6_on && force_wn == 0 && force_chunks == 0 && scatter == nullptr && n_out <= kClsX3Classes &&
+               (k % kClsX3Cols) == 0 && ap.relu == 0 && (ap.lda % 4) == 0 && m >= (force_x6 > 0 ? 64 : 16384) &&
+               (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(ap.a) & 15) == 0;
+    if (class_x3) {
+      const int64_t col_blocks = k / kClsX3Cols;
+      chunks = gs_ceil_div(512, col_blocks);   // two workgroups per CU ...
+      const int64_t by_rows = gs_ceil_div(m, 256);   // ... of at least 16 stages (each chunk costs a slab: C2 36 us with 237 chunks, 46 with 512)
+      if (chunks > by_rows) chunks = by_rows;
+      rows_per_z = gs_ceil_div(gs_ceil_div(m, chunks), kClsX3Rows) * kClsX3Rows;
+      if (rows_per_z < 64) rows_per_z = 64;   // (tn_slab_bytes: never finer than 64 rows)
+      chunks = gs_ceil_div(m, rows_per_z);
+      class_x3 = chunks > 1;
+    }
+  }
   if (defer != nullptr) {
     GS_REQUIRE(defer->count < kMaxSlabJobs, GNNSAFT_ERR_WORKSPACE);
     slabs = defer->take((size_t)chunks * n_out * k);
@@ -1041,6 +1188,18 @@ static int launch_tn(const float *dy, int64_t ldy, const AProv &ap, int64_t m, i
   if constexpr (kHasX6) {
     if (x6 && wn == 4 && wk == 4) {
       launch_tn_x6<4, 4, 2, 2, AProv, Y_CLASS>(dy, ldy, ap, m, n_out, k, slabs, rows_per_z, chunks, direct, st);
+      wn = wk = -1;   // done
+    }
+  }
+  if constexpr (Y_CLASS && std::is_same_v<AProv, TnPlain>) {
+    if (class_x3) {
+      constexpr size_t lds_bytes = (size_t)2 * (kClsX3Classes + 3 * kClsX3Cols) * kX6RowBytes;
+      static_assert(2 * lds_bytes <= 160 * 1024, "two workgroups of two stages per CU");
+      static std::atomic<unsigned long long> lds_raised{0};
+      GS_HIP(gs_raise_dynamic_lds(reinterpret_cast<const void *>(&k_class_sum_x3), lds_bytes, lds_raised));
+      const dim3 grid((unsigned)(k / kClsX3Cols), 1u, (unsigned)chunks);
+      hipLaunchKernelGGL(k_class_sum_x3, grid, dim3(256), lds_bytes, st, reinterpret_cast<const int32_t *>(dy), ap.a, ap.lda,
+                         m, n_out, k, slabs, rows_per_z);
       wn = wk = -1;   // done
     }
   }
@@ -1226,11 +1385,11 @@ int launch_wgrad_onehot(const float *dx, int64_t ldx, const int64_t *idx, int nc
 
 int launch_sum_rows_by_class(const int32_t *cls, int num_classes, const float *a, int64_t lda, int64_t m, int k,
                              float *out /* [num_classes, k] */, int64_t ld_out, float *slabs, size_t slab_bytes,
-                             hipStream_t st, SlabQueue *defer) {
+                             hipStream_t st, SlabQueue *defer, int force_x6) {
   GS_REQUIRE(cls != nullptr && a != nullptr && (lda % 4) == 0 && num_classes >= 1, GNNSAFT_ERR_SHAPE);
   TnPlain ap{a, lda, 0, k};
   return launch_tn<TnPlain, true>(reinterpret_cast<const float *>(cls), 0, ap, m, num_classes, k, out, ld_out, 0, slabs,
-                                  slab_bytes, st, nullptr, 0, 0, 0, defer);
+                                  slab_bytes, st, nullptr, 0, 0, 0, defer, force_x6);
 }
 
 int launch_transpose_list(int count, const TransposeItem *items, hipStream_t st) {
@@ -1332,6 +1491,15 @@ extern "C" int gnnsaft_debug_linear_wgrad(const float *dy, int64_t ldy, const fl
   }
   return gs::launch_tn(dy, ldy, ap, m, n_out, k, dw, ld_dw, 0, static_cast<float *>(scratch), scratch_bytes,
                        static_cast<hipStream_t>(stream), nullptr, wn, wk, chunks, nullptr, force_x6);
+}
+
+// stage-test entry point (include/gnnsaft.h): out[c][:] = sum of the rows of `a` whose class id is c
+extern "C" int gnnsaft_sum_rows_by_class(const int32_t *cls, int32_t num_classes, const float *a, int64_t lda, int64_t m,
+                                         int32_t k, float *out, int64_t ld_out, void *scratch, size_t scratch_bytes,
+                                         int32_t mode, gnnsaft_stream_t stream) {
+  GS_REQUIRE(mode >= 0 && mode <= 2 && out != nullptr && scratch != nullptr, GNNSAFT_ERR_SHAPE);
+  return gs::launch_sum_rows_by_class(cls, num_classes, a, lda, m, k, out, ld_out, static_cast<float *>(scratch),
+                                      scratch_bytes, static_cast<hipStream_t>(stream), nullptr, mode == 0 ? -1 : mode - 1);
 }
 
 extern "C" size_t gnnsaft_wgrad_scratch_bytes(int64_t m, int32_t n_out, int32_t k) {

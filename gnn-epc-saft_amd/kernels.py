@@ -140,6 +140,18 @@ def linear_w3(a: torch.Tensor, w_image: torch.Tensor, n_out: int, bias: Optional
     return (out, stats) if want_stats else out
 
 
+def sum_rows_by_class(cls: torch.Tensor, num_classes: int, a: torch.Tensor, mode: int = 0) -> torch.Tensor:
+    """out[c] = sum of the rows of ``a`` whose int32 class id is c (csrc/gemm_tn.hip; mode 0 = the library's choice,
+    1 = the f32 one-hot GEMM, 2 = the streaming three-product bf16 kernel); test / tuning hook."""
+    m, k = a.shape
+    out = torch.empty((num_classes, k), dtype=torch.float32, device=a.device)
+    need = max(lib.gnnsaft_wgrad_scratch_bytes(m, num_classes, k), 1024)
+    scratch = torch.empty(need // 4 + 64, dtype=torch.float32, device=a.device)
+    check(lib.gnnsaft_sum_rows_by_class(_p(cls), num_classes, _p(a), a.stride(0), m, k, _p(out), k, _p(scratch),
+                                        scratch.numel() * 4, int(mode), _stream(a)), "gnnsaft_sum_rows_by_class")
+    return out
+
+
 def linear_ar(a: torch.Tensor, w_image: torch.Tensor, n_out: int, bias: Optional[torch.Tensor], tile_config: int):
     """out = a W^T + bias on the split-bf16 kernel that keeps the A operand in registers (csrc/gemm_ar.hip); test /
     tuning hook."""

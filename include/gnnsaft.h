@@ -495,6 +495,14 @@ GNNSAFT_API int gnnsaft_debug_linear_wgrad(const float *dy, int64_t ldy, const f
                                int32_t n_out, int32_t k, float *dw, int64_t ld_dw, void *scratch,
                                size_t scratch_bytes, int32_t wn, int32_t wk, int64_t chunks,
                                gnnsaft_stream_t stream);
+/* out[c, :] = sum of the rows of a [m, k] whose class id cls[row] is c (0 <= c < num_classes <= 256; other ids     */
+/* contribute nothing): the backward's per-edge-class sums dR = OneHot(class)^T dm (models.py:59,128) as a one-hot  */
+/* product on the matrix cores, slab-ordered (bitwise reproducible, no atomics).  mode 0: the library's choice (from  */
+/* 16 k rows, <= 64 classes, k % 256 == 0: the streaming three-product bf16 kernel), 1: the f32 one-hot GEMM, 2: the   */
+/* streaming kernel wherever its shape rules allow.  scratch: gnnsaft_wgrad_scratch_bytes(m, num_classes, k).          */
+GNNSAFT_API int gnnsaft_sum_rows_by_class(const int32_t *cls, int32_t num_classes, const float *a, int64_t lda, int64_t m,
+                              int32_t k, float *out, int64_t ld_out, void *scratch, size_t scratch_bytes,
+                              int32_t mode, gnnsaft_stream_t stream);
 /* dW[n_out,k] (+)= dY^T A (deterministic slab reduction), dbias (+)= column sums of dY  */
 GNNSAFT_API size_t gnnsaft_wgrad_scratch_bytes(int64_t m, int32_t n_out, int32_t k);
 GNNSAFT_API int gnnsaft_linear_wgrad(const float *dy, int64_t ldy, const float *a, int64_t lda, int32_t relu_a,

@@ -299,3 +299,31 @@ def test_add_pool_and_mape():
     ref = O.mape(pred.double(), tgt.double())
     assert abs(float(got[0]) - float(ref)) / float(ref) < 1e-6
     assert float(got[2]) == 300.0
+
+
+@pytest.mark.parametrize("m,k,classes", [(70000, 256, 60), (40001, 512, 60), (16390, 256, 64), (999, 256, 7)])
+def test_class_sums_streaming_kernel(m, k, classes):
+    """gnnsaft_sum_rows_by_class (the backward's dR = OneHot(class)^T dm, models.py:59,128): the streaming kernel -- the
+    one-hot operand is exact in bf16, three products (1 x hi | mid | lo) with f32 accumulation, rows in slab order -- against
+    the f64 sums and the f32 one-hot GEMM it replaces from 16 k rows; same bits on a second run (no atomics); ids
+    outside [0, classes) contribute nothing; a ragged last chunk."""
+    torch.manual_seed(m)
+    a = torch.randn(m, k) * torch.logspace(-1, 1, k).view(1, -1)
+    cls = torch.randint(0, classes, (m,), dtype=torch.int32)
+    cls[::3] = 1                      # one dominant class, as the self-loop class of a molecular batch
+    cls[5] = -1
+    cls[6] = classes + 3
+    ok = (cls >= 0) & (cls < classes)
+    want = torch.zeros(classes, k, dtype=torch.float64).index_add_(0, cls[ok].long(), a[ok].double())
+    scale = torch.zeros(classes, k, dtype=torch.float64).index_add_(0, cls[ok].long(), a[ok].double().abs())
+    ad, cd = a.to(DEV), cls.to(DEV)
+    new = K().sum_rows_by_class(cd, classes, ad, mode=2).cpu().double()
+    again = K().sum_rows_by_class(cd, classes, ad, mode=2).cpu().double()
+    old = K().sum_rows_by_class(cd, classes, ad, mode=1).cpu().double()
+    auto = K().sum_rows_by_class(cd, classes, ad, mode=0).cpu().double()
+    e_new = float(((new - want).abs() / (scale + 1e-30)).max())
+    e_old = float(((old - want).abs() / (scale + 1e-30)).max())
+    print(f"class sums [{m},{k}] {classes} classes: streaming kernel {e_new:.2e} of sum|a| (f32 one-hot GEMM {e_old:.2e})")
+    assert torch.equal(new, again)
+    assert e_new < 2e-6 and e_new <= 3 * e_old + 1e-7
+    assert torch.equal(auto, new if m >= 16384 else old)
