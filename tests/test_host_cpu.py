@@ -265,3 +265,24 @@ def test_packed_loader_collates_like_pyg_and_shards_like_distributed_sampler():
     both = torch.cat(parts)
     ref = torch.stack([g.para for g in graphs])
     assert torch.equal(both[both[:, 0].argsort()][:, 0], ref[ref[:, 0].argsort()][:, 0])
+
+
+def test_hand_counted_waits_of_k_gemm_ar_hold_on_the_emitted_isa():
+    """csrc/gemm_ar.hip issues its A loads as inline asm and waits for them with ONE counted s_waitcnt vmcnt per stage:
+    nothing but that count stands between a load and the first use of its registers, and the compiler is free to move
+    or copy registers around it (a build with the probe's extra branches did exactly that: copies of registers whose
+    loads were still in flight, caught on the GPU as a wrong result).  tools/check_ar_isa.py compiles the file for gfx950
+    (no GPU needed) and replays prologue + two loop trips against a model of the in-order vector-memory counter: no
+    instruction may touch a register a load still owns, no vmcnt(0) inside the loop, every stage issues its LDS-DMA
+    pieces before its four loads."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if shutil.which(hipcc) is None and not os.path.exists(hipcc):
+        pytest.skip("no hipcc in this environment")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_ar_isa.py")], capture_output=True, text=True,
+                       timeout=600)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("clean") == 5

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Where one tile of k_gemm_ar (csrc/gemm_ar.hip) spends its time: s_memtime stamps of a mid-grid tile's first wave
 (gnnsaft_debug_ar_stamps), two per 32-k stage: in front of the stage's counted wait + barrier and behind it.
-usage: ar_stamps.py [cfg] (update shape of BASELINE config 3: [163277, 1280] x [128, 1280])"""
+Needs the probe build (the product kernel has no stamps):
+  make -C gnn-epc-saft_amd/csrc stamps; GNNSAFT_LIB=gnn-epc-saft_amd/lib/libgnnsaft_stamps.so python tools/ar_stamps.py [cfg]
+Timing only -- the stamped kernel's extra branches make hipcc copy registers of loads still in flight (tools/check_ar_isa.py
+on a -DGS_AR_STAMPS build), its results are not checked.  Shape: the update of BASELINE config 3, [163277, 1280] x [128, 1280]."""
 import os
 import sys
 
