@@ -286,3 +286,8 @@ def test_hand_counted_waits_of_k_gemm_ar_hold_on_the_emitted_isa():
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("clean") == 5
+    # ... and the checker has teeth: the probe build (stamps behind two extra branches) is the build on which a GPU
+    # parity case failed -- it must be reported
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_ar_isa.py"), "--define", "GS_AR_STAMPS"],
+                        capture_output=True, text=True, timeout=600)
+    assert r2.returncode != 0 and "while a load owns them" in r2.stdout, r2.stdout[-2000:]

@@ -10,7 +10,8 @@ youngest outstanding) and reports
   * any instruction that reads or overwrites a register a global_load still owns,
   * any `s_waitcnt vmcnt(0)` inside the loop (a drained prefetch ring),
   * the vector-memory operations between consecutive barriers of the loop (expected: B_PW LDS-DMA pieces, then 4 loads).
-Exit code 0 = clean.  usage: check_ar_isa.py [--keep /tmp/gemm_ar.s]"""
+Exit code 0 = clean.  usage: check_ar_isa.py [--keep /tmp/gemm_ar.s] [--define MACRO ...]
+(`--define GS_AR_STAMPS` checks the probe build, which is NOT clean: the case this script was written for.)"""
 import os
 import re
 import subprocess
@@ -34,9 +35,9 @@ def regs_of(text):
     return out
 
 
-def compile_isa(path):
+def compile_isa(path, defines=()):
     cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", f"-I{ROOT}/include", "-S",
-           "--cuda-device-only", os.path.join(CSRC, "gemm_ar.hip"), "-o", path]
+           "--cuda-device-only", os.path.join(CSRC, "gemm_ar.hip"), "-o", path] + [f"-D{d}" for d in defines]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
@@ -125,8 +126,9 @@ def check(name, body):
 
 def main():
     keep = sys.argv[sys.argv.index("--keep") + 1] if "--keep" in sys.argv else None
+    defines = [sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--define"]   # e.g. --define GS_AR_STAMPS
     path = keep or os.path.join(tempfile.mkdtemp(), "gemm_ar.s")
-    compile_isa(path)
+    compile_isa(path, defines)
     ks = kernels(open(path).read().splitlines())
     if not ks:
         print("no k_gemm_ar kernel in the assembly")

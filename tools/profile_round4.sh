@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 evidence in one GPU-box session -> gpurun_out/r03_*  (copied to profiles/ afterwards)
+# Round-4 evidence in one GPU-box session -> gpurun_out/r04_*  (copied to profiles/ afterwards)
 set -e -o pipefail
 TAG=r04
 OUT=gpurun_out
