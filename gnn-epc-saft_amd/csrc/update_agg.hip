@@ -211,18 +211,28 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + PW)) void k_update_agg_w3s(Upda
     // cost a block of register moves and made hipcc canonicalise every operand of min / max again), the first edge
     // folded by hand (d = m - m_first is +0, its sums stay 0, min = max = m_first: what the loop of k_pna_aggregate
     // computes, bit for bit).  Same operations in the same order as aggregate.hip otherwise.
-    auto finalize = [&](const float (&v0)[4], const float (&s)[4], const float (&s2)[4], const float (&mn)[4],
+    // DEGC: the in-degree as a compile-time constant (0: run-time `deg`).  A quotient by 1, 2 or 4 is an exact
+    // multiplication; by 3 (and by any run-time count) the correctly rounded quotient of ua_div1.
+    auto finalize = [&](auto degc, const float (&v0)[4], const float (&s)[4], const float (&s2)[4], const float (&mn)[4],
                         const float (&mx)[4], int h, f32x4(&o_mean)[HH], f32x4(&o_min)[HH], f32x4(&o_max)[HH],
                         f32x4(&o_std)[HH]) __attribute__((always_inline)) {
-      const float fc = (float)deg, inv = 1.f / fc;
-      const float thr = 0.0031622776601683794f;   // PyG StdAggregation: clamp(min=1e-5).sqrt(), 0 where <= sqrt(1e-5)
+      constexpr int DEGC = decltype(degc)::value;
+      constexpr bool kPow2 = DEGC == 1 || DEGC == 2 || DEGC == 4;
+      const float fc = DEGC > 0 ? (float)DEGC : (float)deg, inv = 1.f / fc;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float dmean = ua_div1(s[t], fc, inv);
+        const float dmean = kPow2 ? s[t] * inv : ua_div1(s[t], fc, inv);
         o_mean[h][t] = v0[t] + dmean;
-        const float var = ua_div1(s2[t], fc, inv) - dmean * dmean;
-        const float o = sqrtf(fmaxf(var, 1e-5f));
-        o_std[h][t] = o <= thr ? 0.f : o;
+        const float var = (kPow2 ? s2[t] * inv : ua_div1(s2[t], fc, inv)) - dmean * dmean;
+        // PyG: std = var.clamp(min=1e-5).sqrt(), zeroed where std <= sqrt(1e-5).  With a correctly rounded sqrt that
+        // mask is exactly `var <= 1e-5f` (sqrt(1e-5f) rounds to the threshold, the next float above it does not), so
+        // the mask is taken on the variance -- the clamp then has nothing left to do: what it would clamp is masked,
+        // and a NaN variance stays NaN as in torch -- and the root itself is the 1-ulp v_sqrt_f32: hipcc expands
+        // sqrtf() into ~13 instructions per element (scaling + two correction steps for the last ulp), a third of
+        // this reduction's instruction stream, for an ulp of std that changes nothing at the 1e-5 bar
+        // (k_pna_aggregate, the tape's kernel, keeps the IEEE root: it is HBM-bound either way).  Measured on one box:
+        // 750 -> 718 us per launch at C3.
+        o_std[h][t] = var <= 1e-5f ? 0.f : __builtin_amdgcn_sqrtf(var);
         o_min[h][t] = mn[t];
         o_max[h][t] = mx[t];
       }
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + PW)) void k_update_agg_w3s(Upda
             mn[t] = fminf(mn[t], m);
             mx[t] = fmaxf(mx[t], m);
           }
-        finalize(v0, s, s2, mn, mx, h, o_mean, o_min, o_max, o_std);
+        finalize(std::integral_constant<int, DEG>{}, v0, s, s2, mn, mx, h, o_mean, o_min, o_max, o_std);
       }
     };
     // any in-degree: zero (isolated node without self-loops) and more than kUaEdgeBatch in-edges (the further ones
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + PW)) void k_update_agg_w3s(Upda
           }
         }
         if (deg > 0) {
-          finalize(v0, s, s2, mn, mx, h, o_mean, o_min, o_max, o_std);
+          finalize(std::integral_constant<int, 0>{}, v0, s, s2, mn, mx, h, o_mean, o_min, o_max, o_std);
         } else {
           o_mean[h] = o_min[h] = o_max[h] = o_std[h] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
