@@ -113,17 +113,21 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict
   const int cnt = end - beg;
   f32x4 mean = {0.f, 0.f, 0.f, 0.f}, sd = {0.f, 0.f, 0.f, 0.f};
   if (cnt > 0) {
-    const float fc = (float)cnt;
-    const f32x4 dmean = s / fc;
-    mean = v0 + dmean;
-    const f32x4 var = s2 / fc - dmean * dmean;
-    // PyG StdAggregation: var.clamp(min=1e-5).sqrt(), then 0 where <= sqrt(1e-5)
-    const float thr = 0.0031622776601683794f;
-    float sv[4] = {var.x, var.y, var.z, var.w};
+    // (round 4: hipcc expands every f32 `/` into ~10 and every sqrtf into ~13 instructions -- 140 of this thread's ~225
+    //  for a node of three in-edges.  The quotients by the edge count keep their correct rounding at a third of the
+    //  instructions (gs_div_count); PyG's mask -- std = var.clamp(min=1e-5).sqrt(), 0 where std <= sqrt(1e-5) -- is
+    //  exactly `var <= 1e-5f` with a correctly rounded root (sqrt(1e-5f) rounds to the threshold, the next float above
+    //  it does not), so it is taken on the variance, the clamp has nothing left to do (what it would clamp is masked;
+    //  a NaN variance stays NaN, as in torch) and the root is gs_sqrt_rn: v_sqrt_f32 + the one-ulp residual test,
+    //  correctly rounded without the expansion's rescaling of tiny arguments.  Same bits as before.)
+    const float fc = (float)cnt, inv = 1.f / fc;
+    float sv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float o = sqrtf(fmaxf(sv[j], 1e-5f));
-      sv[j] = o <= thr ? 0.f : o;
+      const float dm = gs_div_count(s[j], fc, inv);
+      mean[j] = v0[j] + dm;
+      const float var = gs_div_count(s2[j], fc, inv) - dm * dm;
+      sv[j] = var <= 1e-5f ? 0.f : gs_sqrt_rn(var);
     }
     sd = f32x4{sv[0], sv[1], sv[2], sv[3]};
   } else {

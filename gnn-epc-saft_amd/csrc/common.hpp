@@ -147,6 +147,31 @@ struct EpiArgs {
   float bn_eps;
 };
 
+// x / c for a small positive integer count c (inv = 1.0f / c): quotient estimate, exact residual, one correction --
+// the correctly rounded quotient (what `/` gives, at a third of its instructions: hipcc expands an f32 division into
+// v_div_scale x 2, v_rcp, four fmas, v_div_fmas, v_div_fixup; operands are far from the overflow / underflow ranges
+// where the residual would lose bits).  Used by the segment means / variances of the PNA aggregation.
+__device__ __forceinline__ float gs_div_count(float x, float c, float inv) {
+  const float qe = x * inv;
+  const float r = __builtin_fmaf(-qe, c, x);
+  return __builtin_fmaf(r, inv, qe);
+}
+
+// sqrt(x), correctly rounded, for x in the normal range (callers pass variances above PyG's 1e-5 mask): the 1-ulp
+// v_sqrt_f32 plus the one-ulp-down / one-ulp-up residual test of hipcc's own sqrtf() expansion -- without that
+// expansion's rescaling of tiny arguments and its special-value selects (9 instructions instead of ~13; same bits).
+// (A bare v_sqrt_f32 was measured first: 5 % off the fused aggregation + update, and the frozen population bar of
+// tests/helpers.py failed on one train-mode case -- an ulp of std is visible through train-mode BatchNorm.)
+__device__ __forceinline__ float gs_sqrt_rn(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float vp = __builtin_fmaf(-down, s, x);   // x - down s
+  const float vs = __builtin_fmaf(-up, s, x);     // x - up s
+  float r = vp <= 0.f ? down : s;
+  r = vs > 0.f ? up : r;
+  return r;
+}
+
 __device__ __forceinline__ f32x4 gs_relu4(f32x4 v) {
   v.x = fmaxf(v.x, 0.f);
   v.y = fmaxf(v.y, 0.f);

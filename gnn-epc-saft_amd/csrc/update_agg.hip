@@ -51,15 +51,6 @@ __device__ __forceinline__ void ua_split_store(char *p, int plane, const f32x4 v
       uint4{ua_pack2(m2[0], m2[1]), ua_pack2(m2[2], m2[3]), ua_pack2(m2[4], m2[5]), ua_pack2(m2[6], m2[7])};
 }
 
-// x / c for a small positive integer count c (inv = 1.0f / c): quotient estimate, exact residual, one correction --
-// the correctly rounded quotient (what `/` gives, at a third of its instructions; operands are far from the
-// overflow / underflow ranges where the residual would lose bits)
-__device__ __forceinline__ float ua_div1(float x, float c, float inv) {
-  const float qe = x * inv;
-  const float r = __builtin_fmaf(-qe, c, x);
-  return __builtin_fmaf(r, inv, qe);
-}
-
 // the same for ONE float4 slice: 8 bytes of each plane (PW = 8: two lanes share a chunk)
 __device__ __forceinline__ void ua_split_store_half(char *p, int plane, const f32x4 v0) {
   uint32_t e[4], m1[4], m2[4];
@@ -178,7 +169,7 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + PW)) void k_update_agg_w3s(Upda
     f32x4 v[4][R][HH], g[R][kUaEdgeBatch][HH], t_std[HH];
     static_assert(kUaEdgeBatch == 4, "the in-flight registers double as the four x stages of a super-step");
 
-    auto issue_x = [&](int S) {            // x columns 128 S .. 128 S + 127: plain loads, all rows
+    auto issue_x = [&](int S) __attribute__((always_inline)) {            // x columns 128 S .. 128 S + 127: plain loads, all rows
 #pragma unroll
       for (int j = 0; j < R; ++j)
 #pragma unroll
@@ -189,7 +180,7 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + PW)) void k_update_agg_w3s(Upda
     };
     // (32-bit byte offsets from a uniform base instead of the 64-bit address per gather: measured SLOWER, 778 vs 733 us
     // at C3 -- the saddr form's scheduling, not the address arithmetic, is what the gathers wait for)
-    auto issue_gather = [&](int c) {       // slab c: the first kUaEdgeBatch in-edges of every row
+    auto issue_gather = [&](int c) __attribute__((always_inline)) {       // slab c: the first kUaEdgeBatch in-edges of every row
       const int cb = 32 * c + 4 * q;
 #pragma unroll
       for (int j = 0; j < R; ++j)
@@ -221,18 +212,10 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + PW)) void k_update_agg_w3s(Upda
       const float fc = DEGC > 0 ? (float)DEGC : (float)deg, inv = 1.f / fc;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float dmean = kPow2 ? s[t] * inv : ua_div1(s[t], fc, inv);
+        const float dmean = kPow2 ? s[t] * inv : gs_div_count(s[t], fc, inv);
         o_mean[h][t] = v0[t] + dmean;
-        const float var = (kPow2 ? s2[t] * inv : ua_div1(s2[t], fc, inv)) - dmean * dmean;
-        // PyG: std = var.clamp(min=1e-5).sqrt(), zeroed where std <= sqrt(1e-5).  With a correctly rounded sqrt that
-        // mask is exactly `var <= 1e-5f` (sqrt(1e-5f) rounds to the threshold, the next float above it does not), so
-        // the mask is taken on the variance -- the clamp then has nothing left to do: what it would clamp is masked,
-        // and a NaN variance stays NaN as in torch -- and the root itself is the 1-ulp v_sqrt_f32: hipcc expands
-        // sqrtf() into ~13 instructions per element (scaling + two correction steps for the last ulp), a third of
-        // this reduction's instruction stream, for an ulp of std that changes nothing at the 1e-5 bar
-        // (k_pna_aggregate, the tape's kernel, keeps the IEEE root: it is HBM-bound either way).  Measured on one box:
-        // 750 -> 718 us per launch at C3.
-        o_std[h][t] = var <= 1e-5f ? 0.f : __builtin_amdgcn_sqrtf(var);
+        const float var = (kPow2 ? s2[t] * inv : gs_div_count(s2[t], fc, inv)) - dmean * dmean;
+        o_std[h][t] = var;   // (the root is taken once behind the switch over the in-degree: std_of_var)
         o_min[h][t] = mn[t];
         o_max[h][t] = mx[t];
       }
@@ -319,12 +302,26 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + PW)) void k_update_agg_w3s(Upda
         case 4: reduce_fixed(std::integral_constant<int, 4>{}, j, o_mean, o_min, o_max, o_std); break;
         default: reduce_any(c, j, o_mean, o_min, o_max, o_std); break;
       }
+      // variance -> PyG's std, once for every in-degree.  std = var.clamp(min=1e-5).sqrt(), zeroed where std <=
+      // sqrt(1e-5): with a correctly rounded root that mask is exactly `var <= 1e-5f` (sqrt(1e-5f) rounds to the
+      // threshold, the next float above it does not), so it is taken on the variance; the clamp then has nothing left
+      // to do (what it would clamp is masked, a NaN variance stays NaN as in torch).  The root is gs_sqrt_rn
+      // (common.hpp: v_sqrt_f32 + the one-ulp residual test, 9 instructions for the ~13 of hipcc's sqrtf(), same bits
+      // as k_pna_aggregate).  A bare 1-ulp v_sqrt_f32 was measured first (745 -> 707 us per launch at C3) and dropped: an
+      // ulp of std is visible through train-mode BatchNorm (the population bar of tests/helpers.py).
+#pragma unroll
+      for (int h = 0; h < HH; ++h)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float var = o_std[h][t];
+          o_std[h][t] = var <= 1e-5f ? 0.f : gs_sqrt_rn(var);
+        }
     };
     // the piece of building super-step S that rides in stage slot s4 of the super-step before it (called AFTER the
     // slot's own stage left `v`): loads requested in slot 0; row 0 reduced in slot 2; in slot 3, with all of `v` written
     // out, row 1 (and the x values of an x super-step).  The slab's class terms were copied to LDS by the
     // consumers in the interval that runs beside slot 0.
-    auto build = [&](int S, int s4) {
+    auto build = [&](int S, int s4) __attribute__((always_inline)) {
       if (S >= ns) return;                 // (block-uniform)
       const bool is_x = S < nx / 4;
       const int c = S - nx / 4;
@@ -353,7 +350,7 @@ __global__ __launch_bounds__(64 * (CW_M * CW_N + PW)) void k_update_agg_w3s(Upda
         }
       }
     };
-    auto stash = [&](int s, const f32x4(&vs)[R][HH]) {   // stage s -> buffer s % 3
+    auto stash = [&](int s, const f32x4(&vs)[R][HH]) __attribute__((always_inline)) {   // stage s -> buffer s % 3
       char *st = lds + (s % 3) * STAGE + a_lds;
 #pragma unroll
       for (int j = 0; j < R; ++j) {
