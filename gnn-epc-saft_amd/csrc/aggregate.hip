@@ -30,7 +30,10 @@ namespace gs {
 constexpr int kEdgeBatch = 4;  // gathers kept in flight per thread
 enum AggSource { kMsgs = 0, kFusedPQ = 1, kFusedQ = 2 };
 
-template <int MODE, bool STREAM_OUT = false>
+// UNIFORM: a node's 2F / 4 lanes are a whole number of waves (F a multiple of 128), so the node, its CSR range and the
+// edge loop's trip count are wave-uniform: read as scalars (readfirstlane), the loop control and the edge-guard run on the
+// scalar unit (no per-lane exec masks), the neighbour / class indices come through scalar loads.
+template <int MODE, bool STREAM_OUT = false, bool UNIFORM = false>
 __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict__ rowptr,
                                                        const int32_t *__restrict__ src,
                                                        const int32_t *__restrict__ combo,
@@ -44,6 +47,10 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict
   int lane_in_node;
   gs_split(rs, slot, node, lane_in_node);
   if (node >= num_nodes) return;
+  if constexpr (UNIFORM) {
+    const int nlo = __builtin_amdgcn_readfirstlane((int)node), nhi = __builtin_amdgcn_readfirstlane((int)(node >> 32));
+    node = ((int64_t)nhi << 32) | (uint32_t)nlo;
+  }
   const int c = lane_in_node * 4;  // column in [0, 2F)
   const int tower = c >= f ? 1 : 0;
   const int col = c - tower * f;
@@ -51,8 +58,12 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const int32_t *__restrict
   const int q_stride = MODE == kFusedPQ ? 4 * f : 2 * f;
   const int q_off = MODE == kFusedPQ ? 2 * f : 0;
 
-  const int beg = rowptr[node];
-  const int end = rowptr[node + 1];
+  int beg = rowptr[node];
+  int end = rowptr[node + 1];
+  if constexpr (UNIFORM) {
+    beg = __builtin_amdgcn_readfirstlane(beg);
+    end = __builtin_amdgcn_readfirstlane(end);
+  }
 
   f32x4 p = {0.f, 0.f, 0.f, 0.f};
   if (MODE == kFusedPQ) p = gs_ld4(pq + node * (int64_t)(4 * f) + c);
@@ -179,28 +190,34 @@ static int launch_aggregate(int mode, const int32_t *rowptr, const int32_t *src,
   // 432 -> 400 us; at C2 (84 MB) they make the update GEMM, which finds the aggregates in cache, 3 us slower
   const int stream_out = num_nodes * (int64_t)(8 * hidden) * 4 > ((int64_t)256 << 20) ? 1 : 0;
   const RowSplit rs = gs_row_split(hidden / 2);
+  const bool uni = (hidden / 2) % 64 == 0;   // a node = whole waves
+  GS_REQUIRE(mode == kMsgs ? msgs != nullptr : (src && combo && pq && rtab), GNNSAFT_ERR_NULL);
+#define GS_K4(MODE_, STREAM_, UNI_)                                                                                  \
+  hipLaunchKernelGGL((k_pna_aggregate<MODE_, STREAM_, UNI_>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg, \
+                     num_nodes, hidden, rs)
+#define GS_K4_MODE(MODE_)                  \
+  do {                                     \
+    if (stream_out && uni)                 \
+      GS_K4(MODE_, true, true);            \
+    else if (stream_out)                   \
+      GS_K4(MODE_, true, false);           \
+    else if (uni)                          \
+      GS_K4(MODE_, false, true);           \
+    else                                   \
+      GS_K4(MODE_, false, false);          \
+  } while (0)
   if (mode == kMsgs) {
-    GS_REQUIRE(msgs != nullptr, GNNSAFT_ERR_NULL);
-    hipLaunchKernelGGL((k_pna_aggregate<kMsgs>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
-                       num_nodes, hidden, rs);
+    if (uni)
+      GS_K4(kMsgs, false, true);
+    else
+      GS_K4(kMsgs, false, false);
+  } else if (mode == kFusedPQ) {
+    GS_K4_MODE(kFusedPQ);
   } else {
-    GS_REQUIRE(src && combo && pq && rtab, GNNSAFT_ERR_NULL);
-    if (mode == kFusedPQ) {
-      if (stream_out)
-        hipLaunchKernelGGL((k_pna_aggregate<kFusedPQ, true>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs,
-                           agg, num_nodes, hidden, rs);
-      else
-        hipLaunchKernelGGL((k_pna_aggregate<kFusedPQ>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
-                           num_nodes, hidden, rs);
-    } else {
-      if (stream_out)
-        hipLaunchKernelGGL((k_pna_aggregate<kFusedQ, true>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs,
-                           agg, num_nodes, hidden, rs);
-      else
-        hipLaunchKernelGGL((k_pna_aggregate<kFusedQ>), grid, block, 0, st, rowptr, src, combo, pq, rtab, msgs, agg,
-                           num_nodes, hidden, rs);
-    }
+    GS_K4_MODE(kFusedQ);
   }
+#undef GS_K4_MODE
+#undef GS_K4
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
 }
