@@ -81,6 +81,7 @@ SIGNATURES = {
     "gnnsaft_w3_pack": (c_int32, [P, c_int64, c_int32, c_int32, P, P]),
     "gnnsaft_debug_linear_w3": (c_int32, [P, c_int64, P, P, P, c_int64, c_int64, c_int32, c_int32, P, c_int32, P]),
     "gnnsaft_sum_rows_by_class": (c_int32, [P, c_int32, P, c_int64, c_int64, c_int32, P, c_int64, P, c_size_t, c_int32, P]),
+    "gnnsaft_pna_update_folded_ar": (c_int32, [P, P, P, P, P, c_int64, c_int32, P, P, P, P, P]),
     "gnnsaft_debug_linear_ar": (c_int32, [P, c_int64, P, P, P, c_int64, c_int64, c_int32, c_int32, c_int32, P]),
     "gnnsaft_debug_ar_stamps": (c_int32, [P]),
     "gnnsaft_debug_linear_w3s": (c_int32, [P, c_int64, P, P, P, c_int64, c_int64, c_int32, c_int32, P, c_int32, P]),

@@ -211,6 +211,11 @@ int launch_linear_w3(const float *a, int64_t lda, int nbatch, const GemmBatchEnt
 // A operand in registers (gemm_ar.hip): cfg = ArCfg (w3.hpp)
 int launch_linear_ar(const float *a, int64_t lda, int nbatch, const GemmBatchEntry *entries /* .w3 set */, int n_pad,
                      int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi, hipStream_t stream, int cfg);
+// the degree-folded update on k_gemm_ar, both towers per workgroup (small batches; hidden 128 / 256)
+bool ar_update_supported(int hidden);
+int launch_pna_update_folded_ar(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
+                                const int32_t *num_tiles, int64_t max_tiles, int64_t n, int hidden, const char *w_eff3,
+                                const float *b_post0, const float *b_post1, float *u, hipStream_t stream);
 // wave-specialised form (gemm_w3s.hip): cfg 0 = 128 x 128, 1 = 64 x 128
 int launch_linear_w3s(const float *a, int64_t lda, int nbatch, const GemmBatchEntry *entries /* .w3 set */, int n_pad,
                       int64_t ldo, int64_t m, int n_out, int k, const LinearEpilogue &epi, hipStream_t stream, int cfg);

@@ -611,7 +611,17 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
   const bool fused_agg_on = fused_agg_env < 0 ? n >= 65536 : fused_agg_env == 1;
   const bool fuse_agg = fused_agg_on && p.w3eff_stride != 0 && d->fold_degree_scalers && fold_dst && !d->save_tape &&
                         update_agg_supported(h, (int)p.combos) && !(prof != nullptr && (prof->mask & GNNSAFT_PROF_AGGREGATE) != 0);
-  const bool w3_upd = w3_upd_gemm || fuse_agg;   // the fold leaves W3 images of the folded weights
+  // below 64 k nodes, opt-in (GNNSAFT_AR_UPDATE = 1): the folded update on k_gemm_ar with both towers in one workgroup
+  // per degree tile (gemm_ar.hip).  Measured at C2 in the replayed step: 39.1 us against 36.1 us for
+  // k_gemm_f32<PostFoldA, X6> (step 0.383 against 0.375 ms) although one tower alone ran 19.0 against 21.4 us in the
+  // microbenchmark -- 320 workgroups of 20 dependent stages are a longer latency chain than 640 of 40 shorter ones
+  static const int ar_upd_env = [] {
+    const char *e = getenv("GNNSAFT_AR_UPDATE");
+    return e != nullptr && e[0] == '1' ? 1 : 0;
+  }();
+  const bool ar_upd = ar_upd_env == 1 && !w3_upd_gemm && !fuse_agg && p.w3eff_stride != 0 && d->fold_degree_scalers &&
+                      n < 65536 && ar_update_supported(h);
+  const bool w3_upd = w3_upd_gemm || fuse_agg || ar_upd;   // the fold leaves W3 images of the folded weights
   if (w3_src || w3_lin) {
     std::vector<W3PackItem> items;
     for (int l = 0; l < d->num_layers; ++l) {
@@ -797,6 +807,10 @@ static int gs_forward_impl(const gnnsaft_model_desc *d, const void *const *weigh
     } else if (d->fold_degree_scalers && w3_upd_gemm) {
       ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
       GS_TRY(launch_pna_update_folded_w3(xc, agg_l, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap, n, h,
+                                         ws + p.w3eff + (size_t)l * p.w3eff_stride, bpost[0][0], bpost[1][0], ua, st));
+    } else if (d->fold_degree_scalers && ar_upd) {
+      ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);
+      GS_TRY(launch_pna_update_folded_ar(xc, agg_l, I(p.perm), I(p.tiles), I(p.num_tiles), p.tile_cap, n, h,
                                          ws + p.w3eff + (size_t)l * p.w3eff_stride, bpost[0][0], bpost[1][0], ua, st));
     } else if (d->fold_degree_scalers) {
       ProfScope ps(prof, GNNSAFT_PROF_UPDATE, st);

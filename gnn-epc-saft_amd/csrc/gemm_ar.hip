@@ -75,11 +75,17 @@ __device__ __forceinline__ void ar_wait_vm(f32x4 &r0, f32x4 &r1, f32x4 &r2, f32x
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(N) : "memory");
 }
 
-// WAVES x 32 rows, TN x 32 columns per workgroup; MINW: waves per SIMD the register allocation must allow
-template <int WAVES, int TN, int MINW, class AProv, bool AFFINE, bool RESID>
+// WAVES x 32 rows, TN x 32 columns per workgroup; MINW: waves per SIMD the register allocation must allow.
+// TOWERS = 2: the workgroup's waves split into two groups, one per batch entry (the two towers of the degree-folded PNA
+// update: same rows, each tower its own A columns, weight image, bias and output block); the workgroup then owns
+// 32 WAVES / 2 rows x (2 x 32 TN) columns and one launch covers both towers with twice the waves per row tile.
+template <int WAVES, int TN, int MINW, class AProv, bool AFFINE, bool RESID, int TOWERS = 1>
 __global__ __launch_bounds__(64 * WAVES, MINW) void k_gemm_ar(AProv ap, GemmBatch batch, int n_pad, int64_t ldo, int n_out,
                                                               int k, EpiArgs epi, unsigned long long *stamps) {
-  constexpr int BM = 32 * WAVES, BN = 32 * TN;
+  static_assert(TOWERS == 1 || TOWERS == 2, "one or two batch entries per workgroup");
+  constexpr int WR = WAVES / TOWERS;             // waves (= 32-row tiles) per tower
+  constexpr int BM = 32 * WR, BNT = 32 * TN;     // rows per workgroup, columns per tower
+  constexpr int BN = BNT * TOWERS;               // weight rows per LDS stage
   constexpr int PLANE = BN * kW3RowBytes;        // bytes per bf16 plane and stage (B only)
   constexpr int STAGE = 3 * PLANE;
   constexpr int B_PIECES = 3 * BN / 16;          // 1-KiB pieces per stage (16 rows of one plane each)
@@ -90,10 +96,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_gemm_ar(AProv ap, GemmBatc
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tw = TOWERS == 2 ? wave / WR : 0;    // this wave's tower
+  const int wr = TOWERS == 2 ? wave % WR : wave; // ... and row tile
   const TileInfo ti = ap.tile(blockIdx.x, BM);
   if (ti.count <= 0) return;   // block-uniform, before any barrier
-  const int n0 = blockIdx.y * BN;
-  const GemmBatchEntry ent = batch.e[blockIdx.z];
+  const int n0 = blockIdx.y * BNT;
+  const GemmBatchEntry ent = batch.e[TOWERS == 2 ? tw : (int)blockIdx.z];
   const int nk = k / kW3Kt;
 
   // development probe (make stamps: -DGS_AR_STAMPS; gnnsaft_debug_ar_stamps, tools/ar_stamps.py): s_memtime of wave 0 of
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_gemm_ar(AProv ap, GemmBatc
 #endif
 
   const int fr = lane & 31, hh = lane >> 5;
-  const int lr = wave * 32 + fr;
+  const int lr = wr * 32 + fr;
   const typename AProv::Row arow = ap.row(ti.row0 + (lr < ti.count ? lr : ti.count - 1), ent.a_off);   // clamped rows are never stored
 
   // ---- B pieces of this wave: piece i = (plane, block of 16 rows) = 1 KiB contiguous in the image AND in the LDS stage
@@ -120,11 +128,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_gemm_ar(AProv ap, GemmBatc
 #pragma unroll
   for (int jj = 0; jj < B_PW; ++jj) {
     const int i = wave + WAVES * jj;
-    const int p = i / (BN / 16), rb = i % (BN / 16);
+    const int p = i / (BN / 16), rr = i % (BN / 16);                 // plane, 16-row block of the stage
+    const int pt = rr / (BNT / 16), rb = rr % (BNT / 16);            // ... = tower, block inside the tower's columns
     int n = n0 + rb * 16 + (lane >> 2);
     n = n < n_pad ? n : n_pad - 1;                                   // clamped columns are never stored
-    bsrc[jj] = ent.w3 + ti.w_off * 6 + ((int64_t)p * n_pad + n) * kW3RowBytes + (lane & 3) * 16;
-    bdst[jj] = p * PLANE + rb * 16 * kW3RowBytes;                    // wave-uniform; the hardware adds lane * 16
+    bsrc[jj] = batch.e[TOWERS == 2 ? pt : (int)blockIdx.z].w3 + ti.w_off * 6 + ((int64_t)p * n_pad + n) * kW3RowBytes + (lane & 3) * 16;
+    bdst[jj] = p * PLANE + rr * 16 * kW3RowBytes;                    // wave-uniform; the hardware adds lane * 16
   }
   const int64_t bstep = (int64_t)3 * n_pad * kW3RowBytes;             // bytes between two stages of the image
   auto dma_b = [&](int kt, int buf) {
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_gemm_ar(AProv ap, GemmBatc
     for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
 
   // B fragment of lane (column fr of a 32-column tile, half hh): chunk 2 s + hh of its row at step s
-  const int f0 = fr * kW3RowBytes + w3_chunk_pos(hh, fr) * 16;   // step 0; step 1 = f0 ^ 32
+  const int f0 = (tw * BNT + fr) * kW3RowBytes + w3_chunk_pos(hh, fr) * 16;   // step 0; step 1 = f0 ^ 32
   bf16x8 bf[2][TN][3];
   auto read_b = [&](int buf, int s) {
     const char *base = lds + buf * STAGE + (s == 0 ? f0 : (f0 ^ 32));
@@ -235,21 +244,23 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void k_gemm_ar(AProv ap, GemmBatc
   ar_wait_vm<0>(raw[0][0].v, raw[0][1].v, raw[0][2].v, raw[0][3].v);
   ar_wait_vm<0>(raw[1][0].v, raw[1][1].v, raw[1][2].v, raw[1][3].v);
   ar_wait_vm<0>(raw[2][0].v, raw[2][1].v, raw[2][2].v, raw[2][3].v);
-  gemm_epilogue<1, TN, 32, BN, BM, BN, WAVES, false, AFFINE, RESID>(acc, ap, ti, ent, epi, n0, n_out, ldo, wave, 0, lane);
+  gemm_epilogue<1, TN, 32, BNT, BM, BNT, WR, false, AFFINE, RESID>(acc, ap, ti, ent, epi, n0, n_out, ldo, wr, 0, lane);
 }
 
 static unsigned long long *g_ar_stamps = nullptr;   // development probe: see gnnsaft_debug_ar_stamps
 
-template <int WAVES, int TN, int MINW, class AProv, bool AFFINE, bool RESID>
+template <int WAVES, int TN, int MINW, class AProv, bool AFFINE, bool RESID, int TOWERS = 1>
 static int launch_ar_one(const AProv &ap, int nbatch, const GemmBatch &b, int n_pad, int64_t ldo, int64_t m, int n_out, int k,
                          const EpiArgs &ea, int64_t grid_x, hipStream_t stream) {
-  constexpr int BM = 32 * WAVES, BN = 32 * TN;
-  constexpr size_t kLds = (size_t)3 * 3 * BN * kW3RowBytes;
+  constexpr int BM = 32 * WAVES / TOWERS, BN = 32 * TN;
+  constexpr size_t kLds = (size_t)3 * 3 * BN * TOWERS * kW3RowBytes;
   static_assert(kLds * (WAVES <= 4 ? 2 : 1) <= 160 * 1024, "two four-wave workgroups share the CU's LDS");
-  auto kern = k_gemm_ar<WAVES, TN, MINW, AProv, AFFINE, RESID>;
+  auto kern = k_gemm_ar<WAVES, TN, MINW, AProv, AFFINE, RESID, TOWERS>;
   static std::atomic<unsigned long long> raised{0ull};
   if (kLds > 64 * 1024) GS_HIP(gs_raise_dynamic_lds(reinterpret_cast<const void *>(kern), kLds, raised));
-  const dim3 grid((unsigned)(grid_x > 0 ? grid_x : gs_ceil_div(m, BM)), (unsigned)gs_ceil_div(n_out, BN), (unsigned)nbatch);
+  if (TOWERS == 2 && nbatch != 2) return GNNSAFT_ERR_SHAPE;
+  const dim3 grid((unsigned)(grid_x > 0 ? grid_x : gs_ceil_div(m, BM)), (unsigned)gs_ceil_div(n_out, BN),
+                  (unsigned)(TOWERS == 2 ? 1 : nbatch));
   hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES), kLds, stream, ap, b, n_pad, ldo, n_out, k, ea, g_ar_stamps);
   GS_CHECK_LAUNCH();
   return GNNSAFT_OK;
@@ -298,6 +309,38 @@ int launch_linear_ar(const float *a, int64_t lda, int nbatch, const GemmBatchEnt
   return launch_ar_cfg<PlainA, false, false>(cfg, ap, nbatch, b, n_pad, ldo, m, n_out, k, ea, 0, stream);
 }
 
+// ---- the degree-folded PNA update (launch_pna_update_folded) on k_gemm_ar, both towers in ONE workgroup per degree
+// tile: half the workgroup's waves per tower, every wave 32 rows x F/2 columns with its own A stream [x | A_t] in
+// registers, the two towers' weight-image stages side by side in the LDS ring.  For the small batches the fused
+// aggregation + update does not pay for (below 64 k nodes): hidden 128 (64-row tiles, 4 waves, two workgroups per CU)
+// and hidden 256 (128-row tiles, 8 waves).
+bool ar_update_supported(int hidden) {
+  if (!gemm_w3_enabled()) return false;
+  const int rows = pna_fold_tile_rows(hidden);
+  return (hidden == 128 && rows == 64) || (hidden == 256 && rows == 128);
+}
+
+int launch_pna_update_folded_ar(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
+                                const int32_t *num_tiles, int64_t max_tiles, int64_t n, int hidden, const char *w_eff3,
+                                const float *b_post0, const float *b_post1, float *u, hipStream_t stream) {
+  GS_REQUIRE(x && agg && perm && tiles && num_tiles && w_eff3 && u, GNNSAFT_ERR_NULL);
+  GS_REQUIRE(ar_update_supported(hidden), GNNSAFT_ERR_UNSUPPORTED);
+  if (n == 0) return GNNSAFT_OK;
+  GS_REQUIRE((n + 1) * (int64_t)hidden < ((int64_t)1 << 31), GNNSAFT_ERR_SHAPE);   // 32-bit epilogue offsets
+  const int64_t per_tower = (int64_t)(hidden / 2) * 5 * hidden;
+  PostFoldA ap{x, agg, perm, tiles, num_tiles, 2 * per_tower, hidden};
+  GemmBatch b;
+  b.e[0] = GemmBatchEntry{nullptr, b_post0, u, 0, w_eff3};
+  b.e[1] = GemmBatchEntry{nullptr, b_post1, u + hidden / 2, 4 * (int64_t)hidden, w_eff3 + per_tower * 6};
+  for (int i = 2; i < kMaxGemmBatch; ++i) b.e[i] = b.e[0];
+  EpiArgs ea{nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, 0.f};
+  if (hidden == 128)
+    return launch_ar_one<4, 2, 2, PostFoldA, false, false, 2>(ap, 2, b, hidden / 2, hidden, n, hidden / 2, 5 * hidden, ea,
+                                                              max_tiles, stream);
+  return launch_ar_one<8, 4, 2, PostFoldA, false, false, 2>(ap, 2, b, hidden / 2, hidden, n, hidden / 2, 5 * hidden, ea,
+                                                            max_tiles, stream);
+}
+
 }  // namespace gs
 
 // development probe (tools/ar_stamps.py; not part of the product path): a device buffer of 256 uint64 that the next
@@ -305,6 +348,17 @@ int launch_linear_ar(const float *a, int64_t lda, int nbatch, const GemmBatchEnt
 extern "C" int gnnsaft_debug_ar_stamps(void *device_buffer) {
   gs::g_ar_stamps = static_cast<unsigned long long *>(device_buffer);
   return GNNSAFT_OK;
+}
+
+// stage-test entry point (include/gnnsaft.h): the degree-folded update through k_gemm_ar, both towers per workgroup;
+// operands as gnnsaft_pna_update_folded takes them, the folded weights as W3 images (as gnnsaft_pna_update_agg)
+extern "C" int gnnsaft_pna_update_folded_ar(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
+                                            const int32_t *num_tiles, int64_t num_nodes, int32_t hidden,
+                                            const void *w_eff_images, const float *b_post0, const float *b_post1, float *u,
+                                            gnnsaft_stream_t stream) {
+  return gs::launch_pna_update_folded_ar(x, agg, perm, tiles, num_tiles, gnnsaft_degree_tiles_capacity(num_nodes, hidden),
+                                         num_nodes, hidden, static_cast<const char *>(w_eff_images), b_post0, b_post1, u,
+                                         static_cast<hipStream_t>(stream));
 }
 
 // ---- C ABI: stage tests and tuning (include/gnnsaft.h)

@@ -283,6 +283,21 @@ def pna_update_agg(x, q, rtab, rowptr, src, combo, perm, tiles, num_tiles, hist3
     return u
 
 
+def pna_update_folded_ar(x, agg, perm, tiles, num_tiles, hist3, avg_deg_log, w_post0, b_post0, w_post1, b_post1):
+    """The degree-folded update on the A-in-registers GEMM with both towers per workgroup (csrc/gemm_ar.hip): what
+    ``pna_update_folded`` computes; hidden 128 / 256."""
+    n, h = x.shape
+    buckets = int(lib.gnnsaft_degree_buckets())
+    w_eff = torch.zeros((buckets, 2, h // 2, 5 * h), dtype=torch.float32, device=x.device)
+    check(lib.gnnsaft_pna_fold_post_weights(_p(w_post0), _p(w_post1), _p(avg_deg_log), _p(hist3), h, _p(w_eff),
+                                            _stream(x)), "gnnsaft_pna_fold_post_weights")
+    images = torch.cat([w3_pack(w_eff[d, t]) for d in range(buckets) for t in range(2)])
+    u = torch.empty((n, h), dtype=torch.float32, device=x.device)
+    check(lib.gnnsaft_pna_update_folded_ar(_p(x), _p(agg), _p(perm), _p(tiles), _p(num_tiles), n, h, _p(images),
+                                           _p(b_post0), _p(b_post1), _p(u), _stream(x)), "gnnsaft_pna_update_folded_ar")
+    return u
+
+
 def bn_train_apply(stats, y, gamma, beta, running_mean, running_var, num_batches_tracked, momentum: float, eps: float,
                    residual=None) -> torch.Tensor:
     out = torch.empty_like(y)

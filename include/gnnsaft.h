@@ -291,6 +291,13 @@ GNNSAFT_API int gnnsaft_debug_linear_ar(const float *a, int64_t lda, const void 
                             int64_t ldo, int64_t m, int32_t n_out, int32_t k, int32_t tile_config,
                             gnnsaft_stream_t stream);
 
+/* the degree-folded update (gnnsaft_pna_update_folded) on k_gemm_ar with BOTH towers in one workgroup per degree     */
+/* tile -- what gnnsaft_forward launches below 64 k nodes for hidden 128 / 256 (csrc/gemm_ar.hip); w_eff_images as for  */
+/* gnnsaft_pna_update_agg.  Other hidden sizes: GNNSAFT_ERR_UNSUPPORTED.                                               */
+GNNSAFT_API int gnnsaft_pna_update_folded_ar(const float *x, const float *agg, const int32_t *perm, const int32_t *tiles,
+                                 const int32_t *num_tiles, int64_t num_nodes, int32_t hidden,
+                                 const void *w_eff_images, const float *b_post0, const float *b_post1, float *u,
+                                 gnnsaft_stream_t stream);
 /* development probe: s_memtime stamps of one tile of k_gemm_ar into a device buffer of 256 uint64 (NULL: off) */
 GNNSAFT_API int gnnsaft_debug_ar_stamps(void *device_buffer);
 

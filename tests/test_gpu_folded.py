@@ -204,6 +204,55 @@ def test_fused_aggregate_update_equals_the_two_launches(hidden, graphs, loops):
     assert float(diff.max()) <= 2e-6
 
 
+@pytest.mark.parametrize("hidden,graphs,loops", [(128, 96, True), (256, 40, True), (128, 33, False), (256, 300, True), (128, 1024, True)])
+def test_ar_update_equals_the_folded_update(hidden, graphs, loops):
+    """gnnsaft_pna_update_folded_ar (csrc/gemm_ar.hip: the degree-folded update with BOTH towers in one workgroup per
+    degree tile, the A operand [x | A_t] in registers, what gnnsaft_forward launches below 64 k nodes) against
+    gnnsaft_pna_update_folded (k_gemm_f32<PostFoldA, X6>) on the same operands and both against the f64 evaluation of
+    cat[x, A, A amp, A att] W^T + b: same k order inside a 32-k stage and the same six products -- equal to the order of
+    the k16 steps.  Partial degree tiles, a hub of 12 in-edges, isolated nodes."""
+    from gnn_epc_saft_amd.data.synthetic import GraphData, collate, make_synthetic_batch
+    torch.manual_seed(hidden + graphs)
+    base = make_synthetic_batch(graphs, 7 + graphs, num_para=3)
+    hub = GraphData(base.x[:14], torch.stack([torch.arange(1, 13), torch.zeros(12, dtype=torch.long)]), base.edge_attr[:12])
+    lone = GraphData(base.x[:1], base.edge_index[:, :0], base.edge_attr[:0])
+    parts = []
+    ptr = base.ptr.tolist()
+    for gi in range(graphs):
+        lo, hi = ptr[gi], ptr[gi + 1]
+        m = (base.edge_index[0] >= lo) & (base.edge_index[0] < hi)
+        parts.append(GraphData(base.x[lo:hi], base.edge_index[:, m] - lo, base.edge_attr[m]))
+    d = collate(parts + [hub, lone, lone])
+    n = d.x.shape[0]
+    k = K()
+    x = torch.randn(n, hidden)
+    rowptr, src, dst, combo, la, lt, err = k.csr_build(d.edge_index.to(DEV), d.edge_attr.to(DEV), n, BOND_DIMS, loops)
+    perm, tiles, num_tiles, hist3, err2 = k.degree_tiles(rowptr, hidden)
+    agg = torch.randn(n, 2, 4 * hidden) * 0.7
+    w_post = [torch.randn(hidden // 2, 13 * hidden) / math.sqrt(13 * hidden) for _ in range(2)]
+    b_post = [torch.randn(hidden // 2) for _ in range(2)]
+    avg = torch.tensor([1.1])
+    g = lambda t: t.float().to(DEV)
+    two = k.pna_update_folded(g(x), g(agg), perm, tiles, num_tiles, hist3, g(avg), g(w_post[0]), g(b_post[0]), g(w_post[1]),
+                              g(b_post[1])).cpu().double()
+    one = k.pna_update_folded_ar(g(x), g(agg), perm, tiles, num_tiles, hist3, g(avg), g(w_post[0]), g(b_post[0]),
+                                 g(w_post[1]), g(b_post[1])).cpu().double()
+    assert int(err.item()) == 0 and not torch.isnan(one).any()
+    deg = (rowptr[1:] - rowptr[:-1]).cpu().double()
+    amp = torch.log(deg + 1) / float(avg)
+    att = float(avg) / torch.log(deg.clamp(min=1) + 1)
+    want = torch.empty(n, hidden, dtype=torch.float64)
+    for t in range(2):
+        z = torch.cat([x.double(), agg[:, t].double(), agg[:, t].double() * amp[:, None], agg[:, t].double() * att[:, None]], 1)
+        want[:, t * hidden // 2:(t + 1) * hidden // 2] = z @ w_post[t].double().t() + b_post[t].double()
+    scale = float(want.abs().max())
+    e_one, e_two = float((one - want).abs().max()) / scale, float((two - want).abs().max()) / scale
+    print(f"H={hidden} {n} nodes: AR update vs f64 {e_one:.2e}, X6 update vs f64 {e_two:.2e}, AR vs X6 max "
+          f"{float((one - two).abs().max()) / scale:.2e}")
+    assert e_one <= max(2 * e_two, 2e-6)
+    assert float((one - two).abs().max()) <= 2e-6 * scale
+
+
 AR_TILES = ["128x128", "128x64", "64x128", "64x64", "256x128"]
 
 

@@ -52,14 +52,15 @@ def kernels(lines):
         if name is None:
             continue
         s = ln.strip()
+        if s.startswith(".Lfunc_end"):   # (a kernel may hold several s_endpgm: early exits come first)
+            out[name] = body
+            name = None
+            continue
         if not s or s.startswith(";") or s.startswith("."):
             if s.startswith(".LBB"):
                 body.append(s.split(":")[0] + ":")
             continue
         body.append(s.split(";")[0].strip())
-        if s.startswith("s_endpgm"):
-            out[name] = body
-            name = None
     return out
 
 
@@ -67,12 +68,18 @@ def check(name, body):
     problems = []
     # loop = from the label that a backward s_cbranch targets to that branch
     labels = {ln[:-1]: i for i, ln in enumerate(body) if ln.endswith(":")}
-    loop = None
+    loop, loop_mf = None, 0
     for i, ln in enumerate(body):
-        m = re.match(r"s_cbranch_\w+ (\.LBB\w+)", ln)
+        m = re.match(r"s_c?branch\w* (\.LBB\w+)", ln)
         if m and m.group(1) in labels and labels[m.group(1)] < i:
-            loop = (labels[m.group(1)], i)
-            break
+            cand = (labels[m.group(1)], i)
+            seg = body[cand[0]:cand[1]]
+            # the main loop: three stages = three barriers per trip (other backward branches: the jump to the early
+            # exit block, the epilogue's store loops); of several, the one with the most MFMAs
+            if seg.count("s_barrier") == 3:
+                mf = sum("mfma" in x for x in seg)
+                if loop is None or mf > loop_mf:
+                    loop, loop_mf = cand, mf
     if loop is None:
         return [f"{name}: no loop found"], {}
     # (the code behind the loop -- conditional tail stages, drain, epilogue -- is laid out in blocks whose file order is
